@@ -1,0 +1,88 @@
+"""In-tree build of ``libgs_hip.so`` with hipcc for gfx950 (no cmake, no JIT cache).
+
+The step kernels are compiled twice from one source (``gs_step_kernels.hip``):
+
+* strict: ``-DGS_MATH_FUSED=0`` with f32 denormal mode "flush results, keep inputs"
+  (``-fdenormal-fp-math-f32=preserve-sign,ieee`` -> ``.amdhsa_float_denorm_mode_32 1``),
+  the GPU equivalent of the reference's MXCSR.FTZ ``DenormalsFlusher``;
+* fused:  ``-DGS_MATH_FUSED=1`` with hipcc's default (keep denormals).
+
+Both with ``-ffp-contract=off``: parity with the reference's naive backend is bit for
+bit, so the compiler must never contract ``a*b+c`` on its own.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libgs_hip.so")
+ARCH = "gfx950"
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
+          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+UNITS = [
+    # (source, object, extra flags)
+    ("gs_step_kernels.hip", "gs_step_strict.o",
+     ["-DGS_MATH_FUSED=0", "-Xclang", "-fdenormal-fp-math-f32=preserve-sign,ieee"]),
+    ("gs_step_kernels.hip", "gs_step_fused.o", ["-DGS_MATH_FUSED=1"]),
+    ("gs_util_kernels.hip", "gs_util.o", []),
+    ("gs_api.cpp", "gs_api.o", ["-x", "hip"]),
+]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libgs_hip.so cannot be built")
+    return exe
+
+
+def _sources():
+    out = [os.path.join(CSRC, n) for n in os.listdir(CSRC)]
+    out.append(os.path.join(HERE, os.pardir, "include", "gs_hip.h"))
+    out.append(os.path.abspath(__file__))
+    return out
+
+
+def up_to_date() -> bool:
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    return all(os.path.getmtime(s) <= t for s in _sources())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP translation unit and link ``libgs_hip.so``; returns its path."""
+    if not force and up_to_date():
+        return LIB
+    os.makedirs(BUILD, exist_ok=True)
+    cc = hipcc()
+    procs = []
+    for src, obj, extra in UNITS:
+        flags = list(COMMON)
+        cmd = [cc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(BUILD, obj)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+        if verbose and out:
+            sys.stderr.write(out.decode(errors="replace"))
+    objs = [os.path.join(BUILD, obj) for _, obj, _ in UNITS]
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stdout.decode(errors="replace")))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,150 @@
+"""ctypes binding of ``libgs_hip.so`` -- the same C ABI (``include/gs_hip.h``) that the
+reference-side Rust shim binds (``rust/compute_hip/src/ffi.rs``).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, this
+module raises (``GsError``).  Nothing here imports ``oracle``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgs_hip.so")
+
+GS_OK = 0
+GS_ERR_INVALID = -1
+GS_ERR_HIP = -2
+GS_ERR_RCCL = -3
+GS_ERR_NO_DEVICE = -4
+GS_ERR_UNSUPPORTED = -5
+GS_ERR_NOMEM = -6
+
+GS_MATH_STRICT, GS_MATH_FUSED = 0, 1
+GS_KERNEL_AUTO, GS_KERNEL_SIMPLE, GS_KERNEL_STREAM, GS_KERNEL_LDS = 0, 1, 2, 3
+GS_UNIQUE_ID_BYTES = 128
+
+# Every symbol include/gs_hip.h declares; tests check that the library exports them all.
+EXPORTS = (
+    "gs_default_params", "gs_default_options", "gs_abi_version", "gs_last_error",
+    "gs_device_count", "gs_get_unique_id", "gs_ctx_create", "gs_ctx_destroy",
+    "gs_ctx_set_params", "gs_field_create", "gs_field_destroy", "gs_field_shape",
+    "gs_field_local_rows", "gs_field_raw_shape", "gs_field_fill", "gs_field_fill_slice",
+    "gs_field_finalize", "gs_field_upload", "gs_field_download", "gs_field_device_ptr",
+    "gs_step", "gs_run", "gs_sync", "gs_timer_start", "gs_timer_stop", "gs_ctx_info",
+)
+
+
+class GsError(RuntimeError):
+    """A non-zero ``gs_status`` (the Rust shim maps the same codes to ``HipError``)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"gs_hip error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class GsParams(ctypes.Structure):
+    """``gs_params`` = ``Parameters`` (data/src/parameters.rs:13-33)."""
+
+    _fields_ = [
+        ("w", (ctypes.c_float * 3) * 3),
+        ("du", ctypes.c_float),
+        ("dv", ctypes.c_float),
+        ("feed", ctypes.c_float),
+        ("kill", ctypes.c_float),
+        ("dt", ctypes.c_float),
+    ]
+
+
+class GsOptions(ctypes.Structure):
+    _fields_ = [
+        ("math", ctypes.c_int32),
+        ("kernel", ctypes.c_int32),
+        ("rows_per_block", ctypes.c_int32),
+        ("fuse_steps", ctypes.c_int32),
+        ("use_graph", ctypes.c_int32),
+        ("pitch_pad", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 10),
+    ]
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load ``libgs_hip.so`` (building is ``__graft_entry__.build()``'s job); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GsError(GS_ERR_NO_DEVICE,
+                      f"{LIB_PATH} is missing: build it with `python -m grayscott_amd._build` "
+                      "(there is no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, u64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64, ctypes.c_float
+    P = ctypes.POINTER
+    sig = {
+        "gs_default_params": (None, [P(GsParams)]),
+        "gs_default_options": (None, [P(GsOptions)]),
+        "gs_abi_version": (i32, []),
+        "gs_last_error": (ctypes.c_char_p, []),
+        "gs_device_count": (i32, [P(i32)]),
+        "gs_get_unique_id": (i32, [vp]),
+        "gs_ctx_create": (i32, [P(vp), P(GsParams), P(GsOptions), P(i32), i32, i32, i32, vp]),
+        "gs_ctx_destroy": (i32, [vp]),
+        "gs_ctx_set_params": (i32, [vp, P(GsParams)]),
+        "gs_field_create": (i32, [vp, P(vp), u64, u64]),
+        "gs_field_destroy": (i32, [vp, vp]),
+        "gs_field_shape": (i32, [vp, P(u64), P(u64)]),
+        "gs_field_local_rows": (i32, [vp, P(u64), P(u64)]),
+        "gs_field_raw_shape": (i32, [vp, P(u64), P(u64)]),
+        "gs_field_fill": (i32, [vp, vp, f32]),
+        "gs_field_fill_slice": (i32, [vp, vp, u64, u64, u64, u64, f32]),
+        "gs_field_finalize": (i32, [vp, vp]),
+        "gs_field_upload": (i32, [vp, vp, vp]),
+        "gs_field_download": (i32, [vp, vp, vp]),
+        "gs_field_device_ptr": (i32, [vp, i32, P(vp), P(u64), P(u64), P(u64), P(i32)]),
+        "gs_step": (i32, [vp, vp, vp, vp, vp]),
+        "gs_run": (i32, [vp, vp, vp, vp, vp, u64, P(i32)]),
+        "gs_sync": (i32, [vp]),
+        "gs_timer_start": (i32, [vp]),
+        "gs_timer_stop": (i32, [vp, P(f32)]),
+        "gs_ctx_info": (i32, [vp, ctypes.c_char_p, ctypes.c_size_t, P(u64)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != GS_OK:
+        msg = load().gs_last_error()
+        raise GsError(status, msg.decode(errors="replace") if msg else "unknown error")
+
+
+def default_params() -> GsParams:
+    p = GsParams()
+    load().gs_default_params(ctypes.byref(p))
+    return p
+
+
+def default_options() -> GsOptions:
+    o = GsOptions()
+    load().gs_default_options(ctypes.byref(o))
+    return o
+
+
+def device_count() -> int:
+    n = ctypes.c_int32(0)
+    status = load().gs_device_count(ctypes.byref(n))
+    return int(n.value) if status == GS_OK else 0
+
+
+def get_unique_id() -> bytes:
+    buf = ctypes.create_string_buffer(GS_UNIQUE_ID_BYTES)
+    check(load().gs_get_unique_id(buf))
+    return buf.raw

@@ -1,0 +1,823 @@
+// gs_api.cpp -- implementation of the C ABI in include/gs_hip.h.
+//
+// Host-side runtime of the backend: contexts (devices, streams, row partition, RCCL
+// communicator), planes (row slabs with ghost rows in HBM), the per-step launch and
+// ghost-row exchange schedule, and the small amount of plumbing the reference's
+// Concentration contract needs (fill, fill_slice, finalize, upload, download).
+//
+// Step schedule for a chain of S > 1 slabs (per slab i; p = parity of the step counter):
+//
+//   halo stream (high priority)                     compute stream
+//   ---------------------------                     --------------
+//   wait done[p^1][i], halo[p^1][local nbrs]        wait halo[p^1][i]
+//   kernel: rows {0, rows-1}        -> out          kernel: rows [1, rows-1)  -> out
+//   out row 0      -> upper nbr's out ghost         record done[p][i]
+//   out row rows-1 -> lower nbr's out ghost
+//     (same process: device-to-device copy; other process: ncclSend / ncclRecv pair)
+//   record halo[p][i]
+//
+// so the exchange of step n overlaps the interior update of step n, and step n+1's
+// interior only waits for its own slab's boundary rows.  Every dependency is an event on
+// the consumer's stream; the host never blocks inside gs_step / gs_run.
+#include "../../include/gs_hip.h"
+#include "gs_kernels.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_last_error;
+
+int32_t fail(int32_t code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define GS_HIP(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(GS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+#define GS_TRY(expr)                                                                           \
+    do {                                                                                       \
+        int32_t s_ = (expr);                                                                   \
+        if (s_ != GS_OK) return s_;                                                            \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// RCCL, loaded on first use so that single-process users never touch it
+// ---------------------------------------------------------------------------------------
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.handle ? &r : nullptr;
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) return nullptr;
+    bool ok = true;
+    auto sym = [&](const char *n) {
+        void *p = dlsym(r.handle, n);
+        if (!p) ok = false;
+        return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) {
+        dlclose(r.handle);
+        r.handle = nullptr;
+        return nullptr;
+    }
+    return &r;
+}
+
+#define GS_NCCL(R, expr)                                                                       \
+    do {                                                                                       \
+        ncclResult_t e_ = (expr);                                                              \
+        if (e_ != ncclSuccess)                                                                 \
+            return fail(GS_ERR_RCCL, "%s failed: %s", #expr, (R)->GetErrorString(e_));          \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) == GS_UNIQUE_ID_BYTES, "RCCL unique id size changed");
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------
+// objects
+// ---------------------------------------------------------------------------------------
+struct SlabRt {
+    int device = 0;
+    hipStream_t compute = nullptr, halo = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr}, halod[2] = {nullptr, nullptr};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+struct gs_ctx {
+    gs_params p;
+    gs_options o;
+    std::vector<SlabRt> slabs; // local slabs, top to bottom
+    int rank = 0, world = 1;
+    uint64_t step_no = 0;
+    ncclComm_t comm = nullptr;
+    const char *last_kernel = "none";
+    uint64_t launches = 0;
+    int total_slabs() const { return world * (int)slabs.size(); }
+    int global_index(int i) const { return rank * (int)slabs.size() + i; }
+};
+
+struct FieldSlab {
+    float *alloc = nullptr; // hipMalloc'ed block: guard | ghost | rows | ghost | guard
+    float *row0 = nullptr;  // local row 0, column 0
+    uint64_t g_row0 = 0;    // global index of local row 0
+    int32_t rows = 0;
+};
+
+struct gs_field {
+    gs_ctx *ctx = nullptr;
+    uint64_t rows = 0, cols = 0;
+    int32_t pitch = 0;
+    std::vector<FieldSlab> s;
+    bool ghosts_dirty = true;
+};
+
+namespace {
+
+constexpr int kGuardFloats = 64; // 256 B in front of / behind every plane
+
+bool is_pow2_or_zero(float w)
+{
+    if (w == 0.0f) return true;
+    int e = 0;
+    const float m = std::frexp(std::fabs(w), &e);
+    return m == 0.5f;
+}
+
+int32_t check_math(const gs_params &p, int32_t math)
+{
+    if (math != GS_MATH_STRICT && math != GS_MATH_FUSED)
+        return fail(GS_ERR_INVALID, "unknown math flavour %d", math);
+    if (math == GS_MATH_FUSED)
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                if (!is_pow2_or_zero(p.w[i][j]))
+                    return fail(GS_ERR_UNSUPPORTED,
+                                "GS_MATH_FUSED needs stencil weights that are 0 or a power of two "
+                                "(w[%d][%d] = %g); use GS_MATH_STRICT", i, j, (double)p.w[i][j]);
+    return GS_OK;
+}
+
+int32_t same_shape(const gs_field *a, const gs_field *b)
+{
+    if (a->rows != b->rows || a->cols != b->cols || a->pitch != b->pitch || a->ctx != b->ctx)
+        return fail(GS_ERR_INVALID, "fields of one step must share context and shape "
+                                    "([%llu,%llu] vs [%llu,%llu])",
+                    (unsigned long long)a->rows, (unsigned long long)a->cols,
+                    (unsigned long long)b->rows, (unsigned long long)b->cols);
+    return GS_OK;
+}
+
+int32_t sync_all(gs_ctx *ctx)
+{
+    for (auto &sl : ctx->slabs) {
+        GS_HIP(hipSetDevice(sl.device));
+        GS_HIP(hipStreamSynchronize(sl.halo));
+        GS_HIP(hipStreamSynchronize(sl.compute));
+    }
+    return GS_OK;
+}
+
+int32_t copy_row(gs_ctx *ctx, int src_slab, const float *src, int dst_slab, float *dst, size_t bytes,
+                 hipStream_t stream)
+{
+    const int sd = ctx->slabs[src_slab].device, dd = ctx->slabs[dst_slab].device;
+    if (sd == dd)
+        GS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+    else
+        GS_HIP(hipMemcpyPeerAsync(dst, dd, src, sd, bytes, stream));
+    return GS_OK;
+}
+
+// Push the boundary rows of `planes` to the ghost rows of the neighbouring slabs, from
+// local slab i, on `stream`.  Rows travel whole (pitch floats) so U and V need one message
+// each per direction.
+int32_t push_halo(gs_ctx *ctx, gs_field *const *planes, int nplanes, int i, hipStream_t stream)
+{
+    const int n_local = (int)ctx->slabs.size();
+    const int k = ctx->global_index(i), S = ctx->total_slabs();
+    const bool up_remote = (k > 0) && (i == 0);
+    const bool down_remote = (k < S - 1) && (i == n_local - 1);
+    for (int f = 0; f < nplanes; ++f) {
+        gs_field *pl = planes[f];
+        const FieldSlab &me = pl->s[i];
+        const size_t bytes = (size_t)pl->cols * sizeof(float);
+        if (i > 0) { // my first row -> bottom ghost of the slab above
+            const FieldSlab &nb = pl->s[i - 1];
+            GS_TRY(copy_row(ctx, i, me.row0, i - 1, nb.row0 + (ptrdiff_t)nb.rows * pl->pitch, bytes,
+                            stream));
+        }
+        if (i < n_local - 1) { // my last row -> top ghost of the slab below
+            const FieldSlab &nb = pl->s[i + 1];
+            GS_TRY(copy_row(ctx, i, me.row0 + (ptrdiff_t)(me.rows - 1) * pl->pitch, i + 1,
+                            nb.row0 - pl->pitch, bytes, stream));
+        }
+    }
+    if (up_remote || down_remote) {
+        Rccl *R = rccl();
+        if (!R || !ctx->comm) return fail(GS_ERR_RCCL, "RCCL communicator missing");
+        GS_NCCL(R, R->GroupStart());
+        for (int f = 0; f < nplanes; ++f) {
+            gs_field *pl = planes[f];
+            const FieldSlab &me = pl->s[i];
+            const size_t n = (size_t)pl->cols;
+            if (up_remote) {
+                GS_NCCL(R, R->Send(me.row0, n, ncclFloat, ctx->rank - 1, ctx->comm, stream));
+                GS_NCCL(R, R->Recv(me.row0 - pl->pitch, n, ncclFloat, ctx->rank - 1, ctx->comm, stream));
+            }
+            if (down_remote) {
+                GS_NCCL(R, R->Send(me.row0 + (ptrdiff_t)(me.rows - 1) * pl->pitch, n, ncclFloat,
+                                   ctx->rank + 1, ctx->comm, stream));
+                GS_NCCL(R, R->Recv(me.row0 + (ptrdiff_t)me.rows * pl->pitch, n, ncclFloat, ctx->rank + 1,
+                                   ctx->comm, stream));
+            }
+        }
+        GS_NCCL(R, R->GroupEnd());
+    }
+    return GS_OK;
+}
+
+// Bring the ghost rows of one plane up to date (after fill / fill_slice / upload).
+int32_t refresh_ghosts(gs_ctx *ctx, gs_field *f)
+{
+    if (ctx->total_slabs() > 1) {
+        GS_TRY(sync_all(ctx));
+        gs_field *planes[1] = {f};
+        for (int i = 0; i < (int)ctx->slabs.size(); ++i) {
+            GS_HIP(hipSetDevice(ctx->slabs[i].device));
+            GS_TRY(push_halo(ctx, planes, 1, i, ctx->slabs[i].halo));
+        }
+        GS_TRY(sync_all(ctx));
+    }
+    f->ghosts_dirty = false;
+    return GS_OK;
+}
+
+int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols)
+{
+    if (ctx->o.rows_per_block > 0) return ctx->o.rows_per_block;
+    const long strips = (cols + 255) / 256;
+    long rpu = ((long)rows * strips + 8191) / 8192; // aim for >= 8192 waves in flight
+    if (rpu < 8) rpu = 8;
+    if (rpu > 32) rpu = 32;
+    return (int32_t)rpu;
+}
+
+int32_t launch_rows(gs_ctx *ctx, const GsStepArgs &a, hipStream_t stream)
+{
+    int32_t kernel = ctx->o.kernel;
+    if (kernel == GS_KERNEL_AUTO) kernel = GS_KERNEL_STREAM;
+    const bool fused = ctx->o.math == GS_MATH_FUSED;
+    const char *name = nullptr;
+    hipError_t e;
+    switch (kernel) {
+    case GS_KERNEL_SIMPLE:
+        e = fused ? gs_launch_simple_fused(a, stream, &name) : gs_launch_simple_strict(a, stream, &name);
+        break;
+    case GS_KERNEL_STREAM:
+        e = fused ? gs_launch_stream_fused(a, stream, &name) : gs_launch_stream_strict(a, stream, &name);
+        break;
+    default:
+        return fail(GS_ERR_UNSUPPORTED, "kernel variant %d is not built", kernel);
+    }
+    if (e != hipSuccess) return fail(GS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    ctx->last_kernel = name;
+    ctx->launches++;
+    return GS_OK;
+}
+
+GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in_v,
+                     const gs_field *out_u, const gs_field *out_v, int i)
+{
+    GsStepArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in_u = in_u->s[i].row0;
+    a.in_v = in_v->s[i].row0;
+    a.out_u = out_u->s[i].row0;
+    a.out_v = out_v->s[i].row0;
+    a.rows = in_u->s[i].rows;
+    a.cols = (int32_t)in_u->cols;
+    a.pitch = in_u->pitch;
+    const int k = ctx->global_index(i);
+    a.top_present = k > 0;
+    a.bottom_present = k < ctx->total_slabs() - 1;
+    a.rows_per_unit = pick_rows_per_unit(ctx, a.rows, a.cols);
+    std::memcpy(a.w, ctx->p.w, sizeof a.w);
+    a.du = ctx->p.du;
+    a.dv = ctx->p.dv;
+    a.feed = ctx->p.feed;
+    // (feed_rate + kill_rate) is an f32 add in the reference (compute/naive/src/lib.rs:77);
+    // both operands are normal numbers, so forming it here in f32 gives the same bits.
+    a.feed_plus_kill = ctx->p.feed + ctx->p.kill;
+    a.dt = ctx->p.dt;
+    return a;
+}
+
+int32_t step_impl(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs_field *out_v)
+{
+    const int n_local = (int)ctx->slabs.size();
+    const int S = ctx->total_slabs();
+    if (S == 1) {
+        SlabRt &sl = ctx->slabs[0];
+        GS_HIP(hipSetDevice(sl.device));
+        GsStepArgs a = make_args(ctx, in_u, in_v, out_u, out_v, 0);
+        a.ra0 = 0;
+        a.ra1 = a.rows;
+        GS_TRY(launch_rows(ctx, a, sl.compute));
+    } else {
+        const int p = (int)(ctx->step_no & 1), q = p ^ 1;
+        gs_field *outs[2] = {out_u, out_v};
+        for (int i = 0; i < n_local; ++i) {
+            SlabRt &sl = ctx->slabs[i];
+            GS_HIP(hipSetDevice(sl.device));
+            GsStepArgs a = make_args(ctx, in_u, in_v, out_u, out_v, i);
+            // halo stream: boundary rows, then the exchange
+            GS_HIP(hipStreamWaitEvent(sl.halo, sl.done[q], 0));
+            if (i > 0) GS_HIP(hipStreamWaitEvent(sl.halo, ctx->slabs[i - 1].halod[q], 0));
+            if (i < n_local - 1) GS_HIP(hipStreamWaitEvent(sl.halo, ctx->slabs[i + 1].halod[q], 0));
+            GsStepArgs b = a;
+            b.ra0 = 0;
+            b.ra1 = 1;
+            b.rb0 = a.rows > 1 ? a.rows - 1 : 0;
+            b.rb1 = a.rows > 1 ? a.rows : 0;
+            b.rows_per_unit = 1;
+            GS_TRY(launch_rows(ctx, b, sl.halo));
+            GS_TRY(push_halo(ctx, outs, 2, i, sl.halo));
+            GS_HIP(hipEventRecord(sl.halod[p], sl.halo));
+            // compute stream: interior rows
+            GS_HIP(hipStreamWaitEvent(sl.compute, sl.halod[q], 0));
+            if (a.rows > 2) {
+                a.ra0 = 1;
+                a.ra1 = a.rows - 1;
+                GS_TRY(launch_rows(ctx, a, sl.compute));
+            }
+            GS_HIP(hipEventRecord(sl.done[p], sl.compute));
+        }
+    }
+    ctx->step_no++;
+    out_u->ghosts_dirty = false;
+    out_v->ghosts_dirty = false;
+    return GS_OK;
+}
+
+int32_t check_step_fields(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs_field *out_v)
+{
+    if (!ctx || !in_u || !in_v || !out_u || !out_v) return fail(GS_ERR_INVALID, "null handle");
+    if (in_u->ctx != ctx) return fail(GS_ERR_INVALID, "field belongs to another context");
+    GS_TRY(same_shape(in_u, in_v));
+    GS_TRY(same_shape(in_u, out_u));
+    GS_TRY(same_shape(in_u, out_v));
+    if (in_u == out_u || in_v == out_v || in_u == in_v || out_u == out_v || in_u == out_v || in_v == out_u)
+        return fail(GS_ERR_INVALID, "the four planes of a step must be distinct");
+    if (in_u->ghosts_dirty) GS_TRY(refresh_ghosts(ctx, in_u));
+    if (in_v->ghosts_dirty) GS_TRY(refresh_ghosts(ctx, in_v));
+    return GS_OK;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+void gs_default_params(gs_params *out)
+{
+    if (!out) return;
+    static const float w[3][3] = {{0.25f, 0.5f, 0.25f}, {0.5f, 0.0f, 0.5f}, {0.25f, 0.5f, 0.25f}};
+    std::memcpy(out->w, w, sizeof w);
+    out->du = 0.1f;
+    out->dv = 0.05f;
+    out->feed = 0.014f;
+    out->kill = 0.054f;
+    out->dt = 1.0f;
+}
+
+void gs_default_options(gs_options *out)
+{
+    if (!out) return;
+    std::memset(out, 0, sizeof *out);
+    out->math = GS_MATH_STRICT;
+    out->kernel = GS_KERNEL_AUTO;
+}
+
+int32_t gs_abi_version(void) { return GS_ABI_VERSION; }
+
+const char *gs_last_error(void) { return g_last_error.c_str(); }
+
+int32_t gs_device_count(int32_t *out)
+{
+    if (!out) return fail(GS_ERR_INVALID, "null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out = 0;
+        return fail(GS_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *out = n;
+    return GS_OK;
+}
+
+int32_t gs_get_unique_id(void *out128)
+{
+    if (!out128) return fail(GS_ERR_INVALID, "null output");
+    Rccl *R = rccl();
+    if (!R) return fail(GS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+    ncclUniqueId id;
+    GS_NCCL(R, R->GetUniqueId(&id));
+    std::memcpy(out128, &id, sizeof id);
+    return GS_OK;
+}
+
+int32_t gs_ctx_destroy(gs_ctx *ctx)
+{
+    if (!ctx) return GS_OK;
+    for (auto &sl : ctx->slabs) {
+        if (hipSetDevice(sl.device) != hipSuccess) continue;
+        if (sl.halo) (void)hipStreamSynchronize(sl.halo);
+        if (sl.compute) (void)hipStreamSynchronize(sl.compute);
+    }
+    if (ctx->comm) {
+        if (Rccl *R = rccl()) R->CommDestroy(ctx->comm);
+    }
+    for (auto &sl : ctx->slabs) {
+        if (hipSetDevice(sl.device) != hipSuccess) continue;
+        for (int k = 0; k < 2; ++k) {
+            if (sl.done[k]) (void)hipEventDestroy(sl.done[k]);
+            if (sl.halod[k]) (void)hipEventDestroy(sl.halod[k]);
+        }
+        if (sl.t0) (void)hipEventDestroy(sl.t0);
+        if (sl.t1) (void)hipEventDestroy(sl.t1);
+        if (sl.halo) (void)hipStreamDestroy(sl.halo);
+        if (sl.compute) (void)hipStreamDestroy(sl.compute);
+    }
+    delete ctx;
+    return GS_OK;
+}
+
+int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *opts,
+                      const int32_t *device_ids, int32_t n_local, int32_t rank, int32_t world,
+                      const void *unique_id)
+{
+    if (!out) return fail(GS_ERR_INVALID, "null output");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(GS_ERR_INVALID, "bad rank %d / world %d", rank, world);
+    if (n_local < 0 || (n_local > 0 && !device_ids)) return fail(GS_ERR_INVALID, "bad device list");
+    if (world > 1 && !unique_id) return fail(GS_ERR_INVALID, "world > 1 needs the RCCL unique id of rank 0");
+    if (world > 1 && n_local > 1)
+        return fail(GS_ERR_UNSUPPORTED, "multi-process contexts drive one slab (one GPU) per process");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(GS_ERR_NO_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+
+    gs_ctx *ctx = new (std::nothrow) gs_ctx();
+    if (!ctx) return fail(GS_ERR_NOMEM, "out of host memory");
+    if (params) ctx->p = *params; else gs_default_params(&ctx->p);
+    if (opts) ctx->o = *opts; else gs_default_options(&ctx->o);
+    ctx->rank = rank;
+    ctx->world = world;
+    int32_t st = check_math(ctx->p, ctx->o.math);
+    if (st != GS_OK) { delete ctx; return st; }
+
+    const int32_t one = 0;
+    if (n_local == 0) { device_ids = &one; n_local = 1; }
+    ctx->slabs.resize(n_local);
+    auto bail = [&](int32_t code) { gs_ctx_destroy(ctx); return code; };
+    for (int i = 0; i < n_local; ++i) {
+        SlabRt &sl = ctx->slabs[i];
+        sl.device = device_ids[i];
+        if (sl.device < 0 || sl.device >= ndev)
+            return bail(fail(GS_ERR_NO_DEVICE, "device %d out of range (have %d)", sl.device, ndev));
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, sl.device) != hipSuccess)
+            return bail(fail(GS_ERR_HIP, "hipGetDeviceProperties(%d) failed", sl.device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return bail(fail(GS_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                             sl.device, prop.gcnArchName));
+#define GS_HIP_B(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t e2_ = (expr);                                                               \
+        if (e2_ != hipSuccess)                                                                 \
+            return bail(fail(GS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e2_)));     \
+    } while (0)
+        GS_HIP_B(hipSetDevice(sl.device));
+        int least = 0, greatest = 0;
+        GS_HIP_B(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        GS_HIP_B(hipStreamCreateWithPriority(&sl.compute, hipStreamNonBlocking, least));
+        GS_HIP_B(hipStreamCreateWithPriority(&sl.halo, hipStreamNonBlocking, greatest));
+        for (int k = 0; k < 2; ++k) {
+            GS_HIP_B(hipEventCreateWithFlags(&sl.done[k], hipEventDisableTiming));
+            GS_HIP_B(hipEventCreateWithFlags(&sl.halod[k], hipEventDisableTiming));
+        }
+        GS_HIP_B(hipEventCreate(&sl.t0));
+        GS_HIP_B(hipEventCreate(&sl.t1));
+    }
+    // Peer access between neighbouring local slabs on different devices (best effort: the
+    // copies fall back to staged transfers when it is unavailable).
+    for (int i = 0; i + 1 < n_local; ++i) {
+        const int a = ctx->slabs[i].device, b = ctx->slabs[i + 1].device;
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
+            (void)hipSetDevice(a);
+            (void)hipDeviceEnablePeerAccess(b, 0);
+            (void)hipSetDevice(b);
+            (void)hipDeviceEnablePeerAccess(a, 0);
+            (void)hipGetLastError();
+        }
+    }
+    if (world > 1) {
+        Rccl *R = rccl();
+        if (!R) return bail(fail(GS_ERR_RCCL, "librccl could not be loaded"));
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id, sizeof id);
+        GS_HIP_B(hipSetDevice(ctx->slabs[0].device));
+        ncclResult_t r = R->CommInitRank(&ctx->comm, world, id, rank);
+        if (r != ncclSuccess)
+            return bail(fail(GS_ERR_RCCL, "ncclCommInitRank failed: %s", R->GetErrorString(r)));
+    }
+#undef GS_HIP_B
+    *out = ctx;
+    return GS_OK;
+}
+
+int32_t gs_ctx_set_params(gs_ctx *ctx, const gs_params *params)
+{
+    if (!ctx || !params) return fail(GS_ERR_INVALID, "null argument");
+    GS_TRY(check_math(*params, ctx->o.math));
+    ctx->p = *params;
+    return GS_OK;
+}
+
+int32_t gs_field_destroy(gs_ctx *ctx, gs_field *f)
+{
+    if (!f) return GS_OK;
+    if (ctx) (void)sync_all(ctx);
+    for (size_t i = 0; i < f->s.size(); ++i)
+        if (f->s[i].alloc) {
+            if (ctx && i < ctx->slabs.size()) (void)hipSetDevice(ctx->slabs[i].device);
+            (void)hipFree(f->s[i].alloc);
+        }
+    delete f;
+    return GS_OK;
+}
+
+int32_t gs_field_create(gs_ctx *ctx, gs_field **out, uint64_t rows, uint64_t cols)
+{
+    if (!ctx || !out) return fail(GS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const uint64_t S = (uint64_t)ctx->total_slabs();
+    if (rows == 0 || cols == 0) return fail(GS_ERR_INVALID, "empty shape [%llu, %llu]",
+                                            (unsigned long long)rows, (unsigned long long)cols);
+    if (rows < S) return fail(GS_ERR_INVALID, "%llu rows cannot be split over %llu slabs",
+                              (unsigned long long)rows, (unsigned long long)S);
+    const int pad = ctx->o.pitch_pad > 0 ? ((ctx->o.pitch_pad + 3) / 4) * 4 : 0;
+    const uint64_t pitch = ((cols + 63) / 64) * 64 + (uint64_t)pad;
+    if (pitch > 0x7ffffff0ull) return fail(GS_ERR_UNSUPPORTED, "too many columns");
+    gs_field *f = new (std::nothrow) gs_field();
+    if (!f) return fail(GS_ERR_NOMEM, "out of host memory");
+    f->ctx = ctx;
+    f->rows = rows;
+    f->cols = cols;
+    f->pitch = (int32_t)pitch;
+    f->s.resize(ctx->slabs.size());
+    for (size_t i = 0; i < ctx->slabs.size(); ++i) {
+        const uint64_t k = (uint64_t)ctx->global_index((int)i);
+        const uint64_t r0 = k * rows / S, r1 = (k + 1) * rows / S;
+        if (r1 - r0 > 0x7ffffff0ull || (r1 - r0 + 2) * pitch > 0x7ffffff0ull * 4ull) {
+            gs_field_destroy(ctx, f);
+            return fail(GS_ERR_UNSUPPORTED, "slab too large for 32-bit row indexing");
+        }
+        FieldSlab &fs = f->s[i];
+        fs.g_row0 = r0;
+        fs.rows = (int32_t)(r1 - r0);
+        const size_t n = (size_t)(fs.rows + 2) * pitch + 2 * kGuardFloats;
+        hipError_t e = hipSetDevice(ctx->slabs[i].device);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&fs.alloc), n * sizeof(float));
+        // Concentration::default() is zero-filled in the reference (ndarray default); ghost
+        // rows and padding start as zeros too.
+        if (e == hipSuccess) e = hipMemsetAsync(fs.alloc, 0, n * sizeof(float), ctx->slabs[i].compute);
+        if (e != hipSuccess) {
+            gs_field_destroy(ctx, f);
+            return fail(e == hipErrorOutOfMemory ? GS_ERR_NOMEM : GS_ERR_HIP, "plane allocation failed: %s",
+                        hipGetErrorString(e));
+        }
+        fs.row0 = fs.alloc + kGuardFloats + pitch;
+    }
+    int32_t st = sync_all(ctx);
+    if (st != GS_OK) { gs_field_destroy(ctx, f); return st; }
+    f->ghosts_dirty = false; // all zeros, ghosts included
+    *out = f;
+    return GS_OK;
+}
+
+int32_t gs_field_shape(const gs_field *f, uint64_t *rows, uint64_t *cols)
+{
+    if (!f) return fail(GS_ERR_INVALID, "null field");
+    if (rows) *rows = f->rows;
+    if (cols) *cols = f->cols;
+    return GS_OK;
+}
+
+int32_t gs_field_local_rows(const gs_field *f, uint64_t *row0, uint64_t *row1)
+{
+    if (!f || f->s.empty()) return fail(GS_ERR_INVALID, "null field");
+    if (row0) *row0 = f->s.front().g_row0;
+    if (row1) *row1 = f->s.back().g_row0 + (uint64_t)f->s.back().rows;
+    return GS_OK;
+}
+
+int32_t gs_field_raw_shape(const gs_field *f, uint64_t *raw_rows, uint64_t *pitch)
+{
+    if (!f) return fail(GS_ERR_INVALID, "null field");
+    uint64_t n = 0;
+    for (auto &fs : f->s) n += (uint64_t)fs.rows + 2;
+    if (raw_rows) *raw_rows = n;
+    if (pitch) *pitch = (uint64_t)f->pitch;
+    return GS_OK;
+}
+
+int32_t gs_field_fill_slice(gs_ctx *ctx, gs_field *f, uint64_t r0, uint64_t r1, uint64_t c0, uint64_t c1,
+                            float value)
+{
+    if (!ctx || !f || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad handle");
+    // ndarray slicing panics on out-of-range or reversed ranges (concentration/mod.rs:333-334)
+    if (r0 > r1 || c0 > c1 || r1 > f->rows || c1 > f->cols)
+        return fail(GS_ERR_INVALID, "slice [%llu..%llu, %llu..%llu] outside [%llu, %llu]",
+                    (unsigned long long)r0, (unsigned long long)r1, (unsigned long long)c0,
+                    (unsigned long long)c1, (unsigned long long)f->rows, (unsigned long long)f->cols);
+    for (size_t i = 0; i < f->s.size(); ++i) {
+        const FieldSlab &fs = f->s[i];
+        const uint64_t lo = r0 > fs.g_row0 ? r0 : fs.g_row0;
+        const uint64_t hi = r1 < fs.g_row0 + fs.rows ? r1 : fs.g_row0 + fs.rows;
+        if (lo >= hi || c0 >= c1) continue;
+        GS_HIP(hipSetDevice(ctx->slabs[i].device));
+        hipError_t e = gs_launch_fill_rect(fs.row0, f->pitch, (int32_t)(lo - fs.g_row0),
+                                           (int32_t)(hi - fs.g_row0), (int32_t)c0, (int32_t)c1, value,
+                                           ctx->slabs[i].compute);
+        if (e != hipSuccess) return fail(GS_ERR_HIP, "fill launch failed: %s", hipGetErrorString(e));
+    }
+    GS_TRY(sync_all(ctx));
+    f->ghosts_dirty = true;
+    return GS_OK;
+}
+
+int32_t gs_field_fill(gs_ctx *ctx, gs_field *f, float value)
+{
+    if (!f) return fail(GS_ERR_INVALID, "null field");
+    return gs_field_fill_slice(ctx, f, 0, f->rows, 0, f->cols, value);
+}
+
+int32_t gs_field_finalize(gs_ctx *ctx, gs_field *f)
+{
+    if (!ctx || !f || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad handle");
+    if (f->ghosts_dirty) GS_TRY(refresh_ghosts(ctx, f));
+    return GS_OK;
+}
+
+int32_t gs_field_upload(gs_ctx *ctx, gs_field *f, const float *host)
+{
+    if (!ctx || !f || !host || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad argument");
+    GS_TRY(sync_all(ctx));
+    const uint64_t first = f->s.front().g_row0;
+    for (size_t i = 0; i < f->s.size(); ++i) {
+        const FieldSlab &fs = f->s[i];
+        GS_HIP(hipSetDevice(ctx->slabs[i].device));
+        GS_HIP(hipMemcpy2D(fs.row0, (size_t)f->pitch * sizeof(float), host + (fs.g_row0 - first) * f->cols,
+                           (size_t)f->cols * sizeof(float), (size_t)f->cols * sizeof(float), (size_t)fs.rows,
+                           hipMemcpyHostToDevice));
+    }
+    f->ghosts_dirty = true;
+    return GS_OK;
+}
+
+int32_t gs_field_download(gs_ctx *ctx, gs_field *f, float *host)
+{
+    if (!ctx || !f || !host || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad argument");
+    GS_TRY(sync_all(ctx));
+    const uint64_t first = f->s.front().g_row0;
+    for (size_t i = 0; i < f->s.size(); ++i) {
+        const FieldSlab &fs = f->s[i];
+        GS_HIP(hipSetDevice(ctx->slabs[i].device));
+        GS_HIP(hipMemcpy2D(host + (fs.g_row0 - first) * f->cols, (size_t)f->cols * sizeof(float), fs.row0,
+                           (size_t)f->pitch * sizeof(float), (size_t)f->cols * sizeof(float), (size_t)fs.rows,
+                           hipMemcpyDeviceToHost));
+    }
+    return GS_OK;
+}
+
+int32_t gs_field_device_ptr(const gs_field *f, int32_t slab, void **ptr, uint64_t *pitch, uint64_t *slab_row0,
+                            uint64_t *slab_rows, int32_t *device)
+{
+    if (!f || slab < 0 || (size_t)slab >= f->s.size()) return fail(GS_ERR_INVALID, "bad slab index");
+    if (ptr) *ptr = f->s[slab].row0;
+    if (pitch) *pitch = (uint64_t)f->pitch;
+    if (slab_row0) *slab_row0 = f->s[slab].g_row0;
+    if (slab_rows) *slab_rows = (uint64_t)f->s[slab].rows;
+    if (device) *device = f->ctx->slabs[slab].device;
+    return GS_OK;
+}
+
+int32_t gs_step(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs_field *out_v)
+{
+    GS_TRY(check_step_fields(ctx, in_u, in_v, out_u, out_v));
+    return step_impl(ctx, in_u, in_v, out_u, out_v);
+}
+
+int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *v1, uint64_t steps,
+               int32_t *result_slot)
+{
+    GS_TRY(check_step_fields(ctx, u0, v0, u1, v1));
+    gs_field *u[2] = {u0, u1}, *v[2] = {v0, v1};
+    int in = 0;
+    for (uint64_t n = 0; n < steps; ++n) {
+        GS_TRY(step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in]));
+        in = 1 - in;
+    }
+    if (result_slot) *result_slot = in;
+    return GS_OK;
+}
+
+int32_t gs_sync(gs_ctx *ctx)
+{
+    if (!ctx) return fail(GS_ERR_INVALID, "null context");
+    return sync_all(ctx);
+}
+
+int32_t gs_timer_start(gs_ctx *ctx)
+{
+    if (!ctx) return fail(GS_ERR_INVALID, "null context");
+    for (auto &sl : ctx->slabs) {
+        GS_HIP(hipSetDevice(sl.device));
+        GS_HIP(hipEventRecord(sl.t0, sl.compute));
+    }
+    return GS_OK;
+}
+
+int32_t gs_timer_stop(gs_ctx *ctx, float *elapsed_ms)
+{
+    if (!ctx || !elapsed_ms) return fail(GS_ERR_INVALID, "null argument");
+    const int last = (int)((ctx->step_no + 1) & 1); // parity of the most recent step
+    for (auto &sl : ctx->slabs) {
+        GS_HIP(hipSetDevice(sl.device));
+        if (ctx->total_slabs() > 1 && ctx->step_no > 0)
+            GS_HIP(hipStreamWaitEvent(sl.compute, sl.halod[last], 0));
+        GS_HIP(hipEventRecord(sl.t1, sl.compute));
+    }
+    float worst = 0.0f;
+    for (auto &sl : ctx->slabs) {
+        GS_HIP(hipSetDevice(sl.device));
+        GS_HIP(hipEventSynchronize(sl.t1));
+        float ms = 0.0f;
+        GS_HIP(hipEventElapsedTime(&ms, sl.t0, sl.t1));
+        if (ms > worst) worst = ms;
+    }
+    *elapsed_ms = worst;
+    return GS_OK;
+}
+
+int32_t gs_ctx_info(const gs_ctx *ctx, char *kernel_name, size_t cap, uint64_t *launches)
+{
+    if (!ctx) return fail(GS_ERR_INVALID, "null context");
+    if (kernel_name && cap) {
+        std::strncpy(kernel_name, ctx->last_kernel, cap - 1);
+        kernel_name[cap - 1] = '\0';
+    }
+    if (launches) *launches = ctx->launches;
+    return GS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,38 @@
+// gs_kernels.h -- host/device contract between gs_api.cpp and the gfx950 kernels.
+//
+// One "plane" is a row-major f32 array of one species in one slot for one row slab:
+//   element (r, c) of the slab, r in [-1, rows] (row -1 / row `rows` = ghost rows),
+//   c in [0, pitch), lives at  base + r * pitch + c ;  pitch % 64 == 0 (256-B rows).
+// Columns [cols, pitch) are padding: readable, writable, never used as neighbours.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct GsStepArgs {
+    const float *in_u, *in_v; // local row 0, col 0 of the input planes
+    float *out_u, *out_v;     // same for the output planes
+    int32_t rows;             // rows owned by this slab
+    int32_t cols;             // valid columns
+    int32_t pitch;            // row pitch in floats
+    // Up to two half-open local row ranges to update: [ra0, ra1) and [rb0, rb1).
+    int32_t ra0, ra1, rb0, rb1;
+    // 1 when the ghost row above / below holds a neighbouring slab's row (slab seam),
+    // 0 when that side is a global edge (naive's clipped window applies there).
+    int32_t top_present, bottom_present;
+    int32_t rows_per_unit; // rows one wave marches over (stream kernel)
+    float w[3][3];         // stencil weights, row-major (parameters.rs:87-88)
+    float du, dv, feed, feed_plus_kill, dt;
+};
+
+// Launchers, one set per arithmetic flavour (see gs_math in include/gs_hip.h).  Each
+// returns the hipError_t of the launch.  `name` receives a static kernel-variant label.
+#define GS_DECLARE_LAUNCHERS(SUFFIX)                                                           \
+    hipError_t gs_launch_simple_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name); \
+    hipError_t gs_launch_stream_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name);
+
+GS_DECLARE_LAUNCHERS(strict)
+GS_DECLARE_LAUNCHERS(fused)
+
+// Plane utilities (math-agnostic, defined once in gs_util_kernels.hip).
+hipError_t gs_launch_fill_rect(float *row0, int32_t pitch, int32_t r0, int32_t r1, int32_t c0,
+                               int32_t c1, float value, hipStream_t s);

@@ -1,0 +1,336 @@
+// gs_step_kernels.hip -- gfx950 (CDNA4, wave64) kernels for one Gray-Scott time step.
+//
+// Arithmetic spec: compute_naive::Simulation::perform_step,
+// /root/reference/compute/naive/src/lib.rs:42-83 -- for every cell, a row-major fold
+//     acc = acc + w[i][j] * (elem - centre)
+// over the 3x3 window CLIPPED to the grid, weights indexed from the window's top-left
+// corner (:57-71), then the reaction update (:74-79).  Each reference operation is one
+// rounded f32 operation here, in the same order; this file is compiled with
+// -ffp-contract=off so the compiler never fuses.  It is compiled twice:
+//   GS_MATH_FUSED=0 ("strict"): taps are sub, mul, add; f32 denormal mode = flush results,
+//       keep inputs (-fdenormal-fp-math-f32=preserve-sign,ieee -> FP_DENORM 1), which is
+//       MXCSR.FTZ without DAZ, i.e. the reference's DenormalsFlusher
+//       (compute/shared/src/lib.rs:161-180).
+//   GS_MATH_FUSED=1 ("fused"):  taps are sub, fma; denormals kept.  Exact for weights that
+//       are 0 or a power of two whenever the product is a normal number.
+//
+// Facts the kernels rely on (derived from the spec, checked by tests/test_oracle_kat.py):
+//   * the centre tap contributes w * (u - u) = +0 and acc is never -0, so it is skipped;
+//   * a clipped (absent) neighbour equals "neighbour value := centre value" (adds +0);
+//   * with the row above absent (global top edge) the centre row takes weight row 0 and the
+//     row below weight row 1; same shift for the columns on the global left edge;
+//   * "0.0f + first tap" is kept: it turns a -0 product into +0 exactly as the fold does.
+//
+// Kernels
+//   gs_step_simple_k   one thread per cell, literal window loop (cross-check kernel).
+//   gs_step_stream_k   the production kernel: a wave owns a 256-column strip (one 16-B
+//       load per lane per row and species), marches down `rows_per_unit` rows keeping a
+//       3-row window in registers, and gets its left/right neighbours from the adjacent
+//       lanes with DPP wave shifts (no LDS, no extra memory traffic); only lanes 0 and 63
+//       fetch one halo column each.  Each input element is read from HBM once per step
+//       except the 2 rows shared by vertically adjacent units.  HBM-bound: 16 B per cell.
+#include "gs_kernels.h"
+
+#ifndef GS_MATH_FUSED
+#error "compile with -DGS_MATH_FUSED=0 or 1"
+#endif
+
+#if GS_MATH_FUSED
+#define GS_SUFFIX(x) x##_fused
+#define GS_TAP(acc, w, s, c) (acc) = __builtin_fmaf((w), (s) - (c), (acc))
+#define GS_MATH_NAME "fused"
+#else
+#define GS_SUFFIX(x) x##_strict
+#define GS_TAP(acc, w, s, c) (acc) = (acc) + (w) * ((s) - (c))
+#define GS_MATH_NAME "strict"
+#endif
+
+namespace {
+
+// compute/naive/src/lib.rs:74-79, one rounded op per reference op.
+__device__ __forceinline__ void react(const GsStepArgs &a, float u, float v, float acc_u,
+                                      float acc_v, float &out_u, float &out_v)
+{
+    const float uv_square = (u * v) * v;
+    const float du = (a.du * acc_u - uv_square) + a.feed * (1.0f - u);
+    const float dv = (a.dv * acc_v + uv_square) - a.feed_plus_kill * v;
+    out_u = u + du * a.dt;
+    out_v = v + dv * a.dt;
+}
+
+// Map a linear "row slot" onto the two row ranges of GsStepArgs.
+__device__ __forceinline__ int range_row(const GsStepArgs &a, int slot)
+{
+    const int na = a.ra1 - a.ra0;
+    return slot < na ? a.ra0 + slot : a.rb0 + (slot - na);
+}
+
+// ------------------------------------------------------------------------------------
+// Cross-check kernel: literal restatement, one thread per cell.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_simple_k)(GsStepArgs a)
+{
+    const int bpr = (a.cols + 255) >> 8;
+    const int slot = blockIdx.x / bpr;
+    const int c = (blockIdx.x - slot * bpr) * 256 + threadIdx.x;
+    const int r = range_row(a, slot);
+    if (c >= a.cols) return;
+
+    const bool top = (r > 0) || a.top_present;
+    const bool bottom = (r + 1 < a.rows) || a.bottom_present;
+    const bool left = c > 0;
+    const bool right = c + 1 < a.cols;
+    const ptrdiff_t pitch = a.pitch;
+    const ptrdiff_t o = (ptrdiff_t)r * pitch + c;
+    const float u = a.in_u[o], v = a.in_v[o];
+
+    float acc_u = 0.0f, acc_v = 0.0f;
+    const int i_off = top ? 1 : 0, j_off = left ? 1 : 0;
+    for (int di = top ? -1 : 0; di <= (bottom ? 1 : 0); ++di)
+        for (int dj = left ? -1 : 0; dj <= (right ? 1 : 0); ++dj) {
+            const float w = a.w[di + i_off][dj + j_off];
+            const float su = a.in_u[o + di * pitch + dj];
+            const float sv = a.in_v[o + di * pitch + dj];
+            GS_TAP(acc_u, w, su, u);
+            GS_TAP(acc_v, w, sv, v);
+        }
+    float ou, ov;
+    react(a, u, v, acc_u, acc_v, ou, ov);
+    a.out_u[o] = ou;
+    a.out_v[o] = ov;
+}
+
+// ------------------------------------------------------------------------------------
+// Production kernel: register sliding window + DPP halo exchange.
+// ------------------------------------------------------------------------------------
+
+// lane i receives lane i-1's `own`; lane 0 keeps `lane0_value`  (DPP wave_shr:1)
+__device__ __forceinline__ float from_prev_lane(float own, float lane0_value)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lane0_value),
+                                           __builtin_bit_cast(int, own), 0x138, 0xf, 0xf, false));
+}
+// lane i receives lane i+1's `own`; lane 63 keeps `lane63_value`  (DPP wave_shl:1)
+__device__ __forceinline__ float from_next_lane(float own, float lane63_value)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lane63_value),
+                                           __builtin_bit_cast(int, own), 0x130, 0xf, 0xf, false));
+}
+
+struct RowIn { // one row of this lane's 4 columns as it arrives from memory
+    float4 u, v;
+    float hu, hv; // halo column: lane 0 holds column c0-1, lane 63 holds column c0+256
+};
+struct RowW { // the same row widened with the neighbouring lanes' edge columns
+    float u[6], v[6]; // [0] = column c-1, [1..4] = own columns, [5] = column c+4
+};
+
+struct LaneCtx {
+    bool lane_ok;  // this lane's 4 columns lie inside the row pitch
+    bool halo_ok;  // this lane fetches a halo column
+    int halo_off;  // -1 (lane 0) or +4 (lane 63)
+};
+
+template <bool EDGE>
+__device__ __forceinline__ RowIn load_row(const float *pu, const float *pv, const LaneCtx &lc)
+{
+    RowIn r;
+    if (!EDGE || lc.lane_ok) {
+        r.u = *reinterpret_cast<const float4 *>(pu);
+        r.v = *reinterpret_cast<const float4 *>(pv);
+    } else {
+        r.u = make_float4(0.f, 0.f, 0.f, 0.f);
+        r.v = r.u;
+    }
+    r.hu = 0.f;
+    r.hv = 0.f;
+    if (lc.halo_ok) {
+        r.hu = pu[lc.halo_off];
+        r.hv = pv[lc.halo_off];
+    }
+    return r;
+}
+
+__device__ __forceinline__ RowW widen(const RowIn &r)
+{
+    RowW w;
+    w.u[1] = r.u.x; w.u[2] = r.u.y; w.u[3] = r.u.z; w.u[4] = r.u.w;
+    w.v[1] = r.v.x; w.v[2] = r.v.y; w.v[3] = r.v.z; w.v[4] = r.v.w;
+    w.u[0] = from_prev_lane(r.u.w, r.hu);
+    w.u[5] = from_next_lane(r.u.x, r.hu);
+    w.v[0] = from_prev_lane(r.v.w, r.hv);
+    w.v[5] = from_next_lane(r.v.x, r.hv);
+    return w;
+}
+
+// One output cell.  k = 1..4 indexes the centre inside RowW.  Interior flavour: all eight
+// neighbours exist.  EDGE flavour: `mrow` / `prow` say whether the row above / below exists
+// (wave-uniform), `la` / `ra` whether the left / right neighbour column is absent (per lane).
+template <bool EDGE>
+__device__ __forceinline__ void cell(const GsStepArgs &a, const RowW &m, const RowW &z,
+                                     const RowW &p, int k, bool mrow, bool prow, bool la, bool ra,
+                                     float &out_u, float &out_v)
+{
+    const float u = z.u[k], v = z.v[k];
+    float acc_u = 0.0f, acc_v = 0.0f;
+    if (!EDGE) {
+        GS_TAP(acc_u, a.w[0][0], m.u[k - 1], u); GS_TAP(acc_v, a.w[0][0], m.v[k - 1], v);
+        GS_TAP(acc_u, a.w[0][1], m.u[k], u);     GS_TAP(acc_v, a.w[0][1], m.v[k], v);
+        GS_TAP(acc_u, a.w[0][2], m.u[k + 1], u); GS_TAP(acc_v, a.w[0][2], m.v[k + 1], v);
+        GS_TAP(acc_u, a.w[1][0], z.u[k - 1], u); GS_TAP(acc_v, a.w[1][0], z.v[k - 1], v);
+        GS_TAP(acc_u, a.w[1][2], z.u[k + 1], u); GS_TAP(acc_v, a.w[1][2], z.v[k + 1], v);
+        GS_TAP(acc_u, a.w[2][0], p.u[k - 1], u); GS_TAP(acc_v, a.w[2][0], p.v[k - 1], v);
+        GS_TAP(acc_u, a.w[2][1], p.u[k], u);     GS_TAP(acc_v, a.w[2][1], p.v[k], v);
+        GS_TAP(acc_u, a.w[2][2], p.u[k + 1], u); GS_TAP(acc_v, a.w[2][2], p.v[k + 1], v);
+    } else {
+        // Weight row of the centre row: 1 normally, 0 when the row above is clipped away.
+        // Weight column of the centre column: 1 normally, 0 when the left column is clipped.
+        // An absent left/right neighbour is replaced by the centre value (adds +0).
+        const int zi = mrow ? 1 : 0;
+#define GS_ROW_TAPS(R, WI, WITH_CENTRE)                                                        \
+    {                                                                                          \
+        const float wl = a.w[WI][0];                                                           \
+        const float wc = la ? a.w[WI][0] : a.w[WI][1];                                         \
+        const float wr = la ? a.w[WI][1] : a.w[WI][2];                                         \
+        const float ul = la ? u : R.u[k - 1], vl = la ? v : R.v[k - 1];                        \
+        const float ur = ra ? u : R.u[k + 1], vr = ra ? v : R.v[k + 1];                        \
+        GS_TAP(acc_u, wl, ul, u); GS_TAP(acc_v, wl, vl, v);                                    \
+        if (WITH_CENTRE) { GS_TAP(acc_u, wc, R.u[k], u); GS_TAP(acc_v, wc, R.v[k], v); }       \
+        GS_TAP(acc_u, wr, ur, u); GS_TAP(acc_v, wr, vr, v);                                    \
+    }
+        if (mrow) GS_ROW_TAPS(m, 0, true)
+        GS_ROW_TAPS(z, zi, false)
+        if (prow) GS_ROW_TAPS(p, zi + 1, true)
+#undef GS_ROW_TAPS
+    }
+    react(a, u, v, acc_u, acc_v, out_u, out_v);
+}
+
+template <int G, bool EDGE>
+__device__ __forceinline__ void march(const GsStepArgs &a, int ur0, int ur1, int c0, int lane)
+{
+    const int c = c0 + lane * 4;
+    LaneCtx lc;
+    lc.lane_ok = !EDGE || (c < a.pitch);
+    lc.halo_off = (lane == 0) ? -1 : 4;
+    lc.halo_ok = EDGE ? ((lane == 0 && c0 > 0) || (lane == 63 && c + 4 < a.pitch))
+                      : (lane == 0 || lane == 63);
+
+    const ptrdiff_t pitch = a.pitch;
+    const float *bu = a.in_u + c, *bv = a.in_v + c; // row 0 of this lane's columns
+    float *ou = a.out_u + (ptrdiff_t)ur0 * pitch + c;
+    float *ov = a.out_v + (ptrdiff_t)ur0 * pitch + c;
+
+    // Rows are fetched one group (G rows) ahead of the group being computed.  Row indices
+    // are clamped to ur1 (the row below the last output row, at most the bottom ghost
+    // row), so every load is in bounds and the tail needs no branches around loads.
+    auto fetch = [&](int row) {
+        const int rr = row < ur1 ? row : ur1;
+        return load_row<EDGE>(bu + (ptrdiff_t)rr * pitch, bv + (ptrdiff_t)rr * pitch, lc);
+    };
+
+    RowW q[G + 2];
+    RowIn n[G];
+    q[0] = widen(fetch(ur0 - 1));
+    q[1] = widen(fetch(ur0));
+#pragma unroll
+    for (int g = 0; g < G; ++g) n[g] = fetch(ur0 + 1 + g);
+
+    bool la[4], ra[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        la[k] = EDGE && (c + k == 0);
+        ra[k] = EDGE && (c + k + 1 >= a.cols);
+    }
+
+    for (int r = ur0; r < ur1; r += G) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) q[g + 2] = widen(n[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) n[g] = fetch(r + G + 1 + g);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int row = r + g;
+            if (row < ur1) {
+                const bool mrow = !EDGE || (row > 0) || a.top_present;
+                const bool prow = !EDGE || (row + 1 < a.rows) || a.bottom_present;
+                float4 nu, nv;
+                cell<EDGE>(a, q[g], q[g + 1], q[g + 2], 1, mrow, prow, la[0], ra[0], nu.x, nv.x);
+                cell<EDGE>(a, q[g], q[g + 1], q[g + 2], 2, mrow, prow, la[1], ra[1], nu.y, nv.y);
+                cell<EDGE>(a, q[g], q[g + 1], q[g + 2], 3, mrow, prow, la[2], ra[2], nu.z, nv.z);
+                cell<EDGE>(a, q[g], q[g + 1], q[g + 2], 4, mrow, prow, la[3], ra[3], nu.w, nv.w);
+                if (lc.lane_ok) {
+                    *reinterpret_cast<float4 *>(ou) = nu;
+                    *reinterpret_cast<float4 *>(ov) = nv;
+                }
+                ou += pitch;
+                ov += pitch;
+            }
+        }
+        q[0] = q[G];
+        q[1] = q[G + 1];
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_stream_k)(GsStepArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int strips = (a.cols + 255) >> 8;
+    const int unit = blockIdx.x * 4 + wave;
+    const int chunk = unit / strips;
+    const int strip = unit - chunk * strips;
+    const int rpu = a.rows_per_unit;
+    const int chunks_a = (a.ra1 - a.ra0 + rpu - 1) / rpu;
+    const int chunks_b = (a.rb1 - a.rb0 + rpu - 1) / rpu;
+    if (chunk >= chunks_a + chunks_b) return; // wave-uniform
+
+    int ur0, ur1;
+    if (chunk < chunks_a) {
+        ur0 = a.ra0 + chunk * rpu;
+        ur1 = min(ur0 + rpu, a.ra1);
+    } else {
+        ur0 = a.rb0 + (chunk - chunks_a) * rpu;
+        ur1 = min(ur0 + rpu, a.rb1);
+    }
+    const int c0 = strip << 8;
+    // Units that touch a global edge or the ragged right end take the general path; the
+    // interior path has no per-lane bounds logic at all.
+    const bool edge = (c0 == 0) || (c0 + 256 >= a.cols) || (ur0 == 0 && !a.top_present) ||
+                      (ur1 == a.rows && !a.bottom_present);
+    if (edge)
+        march<G, true>(a, ur0, ur1, c0, lane);
+    else
+        march<G, false>(a, ur0, ur1, c0, lane);
+}
+
+} // namespace
+
+hipError_t GS_SUFFIX(gs_launch_simple)(const GsStepArgs &a, hipStream_t s, const char **name)
+{
+    if (name) *name = "simple/" GS_MATH_NAME;
+    const long nrows = (long)(a.ra1 - a.ra0) + (a.rb1 - a.rb0);
+    if (nrows <= 0 || a.cols <= 0) return hipSuccess;
+    const long bpr = (a.cols + 255) >> 8;
+    const long blocks = nrows * bpr;
+    if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(GS_SUFFIX(gs_step_simple_k), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const char **name)
+{
+    if (name) *name = "stream-g2/" GS_MATH_NAME;
+    if (a.cols <= 0 || a.rows_per_unit <= 0) return hipErrorInvalidValue;
+    const long rpu = a.rows_per_unit;
+    const long chunks = ((long)(a.ra1 - a.ra0) + rpu - 1) / rpu + ((long)(a.rb1 - a.rb0) + rpu - 1) / rpu;
+    if (chunks <= 0) return hipSuccess;
+    const long strips = (a.cols + 255) >> 8;
+    const long blocks = (chunks * strips + 3) / 4;
+    if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(GS_SUFFIX(gs_step_stream_k)<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

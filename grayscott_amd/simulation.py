@@ -1,0 +1,355 @@
+"""Host-side mirror of the reference's backend interface, over the C ABI.
+
+Same names, argument meaning and error behaviour as the Rust items they mirror, so that
+the parity tests read like tests of a reference backend:
+
+=========================  ==========================================================
+here                       reference (/root/reference/...)
+=========================  ==========================================================
+``Parameters``             data/src/parameters.rs:13-33, ``Default`` :72-83
+``HipConcentration``       ``Concentration`` trait, data/src/concentration/mod.rs:198-296
+``Evolving`` / ``Species`` data/src/concentration/mod.rs:17-187
+``HipArgs``                ``SimulateBase::CliArgs`` (defaults + env), compute/shared/src/lib.rs:20-25
+``Simulation``             ``SimulateBase`` / ``SimulateCreate`` / ``Simulate``,
+                           compute/shared/src/lib.rs:19-58
+=========================  ==========================================================
+
+The Rust shim a maintainer would add (rust/compute_hip) has exactly this shape; this
+module is what the Python harness (tests, bench) uses in its place because the image has
+no Rust toolchain.  All arithmetic happens in ``libgs_hip.so``; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import capi
+from .capi import GsError
+
+STENCIL_WEIGHTS = ((0.25, 0.5, 0.25), (0.5, 0.0, 0.5), (0.25, 0.5, 0.25))  # parameters.rs:116-122
+
+
+@dataclass
+class Parameters:
+    """``Parameters`` with ``Parameters::default()`` values (parameters.rs:72-83)."""
+
+    weights: Tuple[Tuple[float, float, float], ...] = STENCIL_WEIGHTS
+    diffusion_rate_u: float = 0.1
+    diffusion_rate_v: float = 0.05
+    feed_rate: float = 0.014
+    kill_rate: float = 0.054
+    time_step: float = 1.0
+
+    def to_c(self) -> capi.GsParams:
+        p = capi.GsParams()
+        for i in range(3):
+            for j in range(3):
+                p.w[i][j] = self.weights[i][j]
+        p.du, p.dv = self.diffusion_rate_u, self.diffusion_rate_v
+        p.feed, p.kill, p.dt = self.feed_rate, self.kill_rate, self.time_step
+        return p
+
+
+def _env_int(name: str, default: int) -> int:
+    v = os.environ.get(name)
+    return int(v) if v not in (None, "") else default
+
+
+@dataclass
+class HipArgs:
+    """Backend ``CliArgs``: every field has a default and an environment variable, as the
+    reference requires so that its criterion harness can build a backend from the
+    environment alone (compute/shared/src/lib.rs:20-25, benchmark.rs:36-40)."""
+
+    devices: Sequence[int] = field(default_factory=lambda: [
+        int(x) for x in os.environ.get("GS_HIP_DEVICES", "0").split(",") if x != ""])
+    math: int = field(default_factory=lambda: _env_int("GS_HIP_MATH", capi.GS_MATH_STRICT))
+    kernel: int = field(default_factory=lambda: _env_int("GS_HIP_KERNEL", capi.GS_KERNEL_AUTO))
+    rows_per_block: int = field(default_factory=lambda: _env_int("GS_HIP_ROWS_PER_BLOCK", 0))
+    fuse_steps: int = field(default_factory=lambda: _env_int("GS_HIP_FUSE_STEPS", 0))
+    use_graph: int = field(default_factory=lambda: _env_int("GS_HIP_USE_GRAPH", 0))
+    pitch_pad: int = field(default_factory=lambda: _env_int("GS_HIP_PITCH_PAD", 0))
+    rank: int = 0
+    world: int = 1
+    unique_id: Optional[bytes] = None
+
+    def to_c(self) -> capi.GsOptions:
+        o = capi.default_options()
+        o.math, o.kernel = self.math, self.kernel
+        o.rows_per_block, o.fuse_steps = self.rows_per_block, self.fuse_steps
+        o.use_graph, o.pitch_pad = self.use_graph, self.pitch_pad
+        return o
+
+
+class HipContext:
+    """``Concentration::Context`` of ``HipConcentration``: devices, streams, row partition
+    and (multi-process) the RCCL communicator -- one ``gs_ctx``."""
+
+    def __init__(self, params: Parameters, args: Optional[HipArgs] = None):
+        args = args or HipArgs()
+        lib = capi.load()
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        cp, co = params.to_c(), args.to_c()
+        devs = (ctypes.c_int32 * len(args.devices))(*args.devices)
+        uid = ctypes.create_string_buffer(args.unique_id, capi.GS_UNIQUE_ID_BYTES) \
+            if args.unique_id else None
+        capi.check(lib.gs_ctx_create(ctypes.byref(self._h), ctypes.byref(cp), ctypes.byref(co),
+                                     devs, len(args.devices), args.rank, args.world, uid))
+        self.args = args
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise GsError(capi.GS_ERR_INVALID, "context already destroyed")
+        return self._h
+
+    def set_params(self, params: Parameters) -> None:
+        cp = params.to_c()
+        capi.check(self._lib.gs_ctx_set_params(self.handle, ctypes.byref(cp)))
+
+    def sync(self) -> None:
+        capi.check(self._lib.gs_sync(self.handle))
+
+    def timer_start(self) -> None:
+        capi.check(self._lib.gs_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = ctypes.c_float(0)
+        capi.check(self._lib.gs_timer_stop(self.handle, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def info(self) -> Tuple[str, int]:
+        buf = ctypes.create_string_buffer(64)
+        n = ctypes.c_uint64(0)
+        capi.check(self._lib.gs_ctx_info(self.handle, buf, 64, ctypes.byref(n)))
+        return buf.value.decode(), int(n.value)
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.gs_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipConcentration:
+    """One species plane in HBM: the ``Concentration`` implementation of this backend."""
+
+    def __init__(self, context: HipContext, shape: Sequence[int]):
+        rows, cols = int(shape[0]), int(shape[1])
+        self._ctx = context
+        self._h = ctypes.c_void_p()
+        capi.check(context._lib.gs_field_create(context.handle, ctypes.byref(self._h), rows, cols))
+        self._shape = (rows, cols)
+
+    # -- constructors (Concentration::default / zeros / ones, mod.rs:205-218) -------------
+    @classmethod
+    def default(cls, context: HipContext, shape) -> "HipConcentration":
+        return cls(context, shape)
+
+    @classmethod
+    def zeros(cls, context: HipContext, shape) -> "HipConcentration":
+        return cls(context, shape)  # planes are created zero-filled
+
+    @classmethod
+    def ones(cls, context: HipContext, shape) -> "HipConcentration":
+        c = cls(context, shape)
+        capi.check(context._lib.gs_field_fill(context.handle, c._h, 1.0))
+        return c
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise GsError(capi.GS_ERR_INVALID, "concentration already destroyed")
+        return self._h
+
+    def shape(self) -> Tuple[int, int]:
+        return self._shape
+
+    def raw_shape(self) -> Tuple[int, int]:
+        r, p = ctypes.c_uint64(), ctypes.c_uint64()
+        capi.check(self._ctx._lib.gs_field_raw_shape(self.handle, ctypes.byref(r), ctypes.byref(p)))
+        return int(r.value), int(p.value)
+
+    def local_rows(self) -> Tuple[int, int]:
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        capi.check(self._ctx._lib.gs_field_local_rows(self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
+
+    def fill_slice(self, context: HipContext, slice_: Sequence[range], value: float) -> None:
+        """``fill_slice(ctx, [rows, cols], value)`` with half-open ranges (mod.rs:230-243)."""
+        rr, cc = slice_
+        capi.check(context._lib.gs_field_fill_slice(context.handle, self.handle, rr.start, rr.stop,
+                                                    cc.start, cc.stop, value))
+
+    def finalize(self, context: HipContext) -> None:
+        capi.check(context._lib.gs_field_finalize(context.handle, self.handle))
+
+    def upload(self, context: HipContext, host: np.ndarray) -> None:
+        """Test/bench helper: overwrite this process's rows from a dense float32 array."""
+        r0, r1 = self.local_rows()
+        host = np.ascontiguousarray(host, np.float32)
+        if host.shape != (r1 - r0, self._shape[1]):
+            raise AssertionError(f"upload shape {host.shape} != local shape {(r1 - r0, self._shape[1])}")
+        capi.check(context._lib.gs_field_upload(context.handle, self.handle,
+                                                host.ctypes.data_as(ctypes.c_void_p)))
+
+    def make_scalar_view(self, context: HipContext) -> np.ndarray:
+        """Owned dense copy of this process's rows (mod.rs:261-275)."""
+        r0, r1 = self.local_rows()
+        out = np.empty((r1 - r0, self._shape[1]), np.float32)
+        self.write_scalar_view(context, out)
+        return out
+
+    def write_scalar_view(self, context: HipContext, target: np.ndarray) -> None:
+        """``write_scalar_view``; like ``validate_write`` (mod.rs:291-295) a shape mismatch is
+        a programming error and asserts."""
+        r0, r1 = self.local_rows()
+        assert target.shape == (r1 - r0, self._shape[1]), (target.shape, (r1 - r0, self._shape[1]))
+        assert target.dtype == np.float32 and target.flags.c_contiguous
+        capi.check(context._lib.gs_field_download(context.handle, self.handle,
+                                                  target.ctypes.data_as(ctypes.c_void_p)))
+
+    def destroy(self) -> None:
+        if self._h and self._ctx._h:
+            self._ctx._lib.gs_field_destroy(self._ctx._h, self._h)
+        self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Evolving:
+    """Input/output pair of one species (mod.rs:140-187): slot 0 is the input."""
+
+    def __init__(self, pair: List[HipConcentration]):
+        self._pair = pair
+
+    @classmethod
+    def zeros_out(cls, context, shape):
+        return cls([HipConcentration.default(context, shape), HipConcentration.zeros(context, shape)])
+
+    @classmethod
+    def ones_out(cls, context, shape):
+        return cls([HipConcentration.default(context, shape), HipConcentration.ones(context, shape)])
+
+    def in_out(self):
+        return self._pair[0], self._pair[1]
+
+    def out(self):
+        return self._pair[1]
+
+    def shape(self):
+        return self._pair[0].shape()
+
+    def raw_shape(self):
+        return self._pair[0].raw_shape()
+
+    def flip(self, context) -> None:
+        self._pair[1].finalize(context)
+        self._pair.reverse()
+
+
+class Species:
+    """``Species<HipConcentration>``; ``Species.new`` = ``Species::new`` (mod.rs:36-59)."""
+
+    def __init__(self, context: HipContext, u: Evolving, v: Evolving):
+        self._context, self.u, self.v = context, u, v
+
+    @classmethod
+    def new(cls, context: HipContext, shape: Sequence[int]) -> "Species":
+        shape = (int(shape[0]), int(shape[1]))
+        u = Evolving.ones_out(context, shape)
+        v = Evolving.zeros_out(context, shape)
+        num_range, frac, row_shift = (7, 8), 16, 4
+        sl = []
+        for i in (0, 1):
+            shift = row_shift if i == 0 else 0
+            start, end = (max(shape[i] * num_range[j] // frac - shift, 0) for j in (0, 1))
+            sl.append(range(start, end))
+        u.out().fill_slice(context, sl, 0.0)
+        v.out().fill_slice(context, sl, 1.0)
+        s = cls(context, u, v)
+        s.flip()
+        return s
+
+    def context(self) -> HipContext:
+        return self._context
+
+    def shape(self):
+        return self.u.shape()
+
+    def raw_shape(self):
+        return self.u.raw_shape()
+
+    def in_out(self):
+        in_u, out_u = self.u.in_out()
+        in_v, out_v = self.v.in_out()
+        return in_u, in_v, out_u, out_v
+
+    def flip(self) -> None:
+        self.u.flip(self._context)
+        self.v.flip(self._context)
+
+    def access_result(self, f: Callable):
+        return f(self.v._pair[0], self._context)
+
+    def make_result_view(self) -> np.ndarray:
+        return self.access_result(lambda v, ctx: v.make_scalar_view(ctx))
+
+    def write_result_view(self, target: np.ndarray) -> None:
+        self.access_result(lambda v, ctx: v.write_scalar_view(ctx, target))
+
+
+class Simulation:
+    """The backend: ``SimulateBase + SimulateCreate + Simulate``."""
+
+    CliArgs = HipArgs
+    Concentration = HipConcentration
+    Error = GsError
+
+    def __init__(self, params: Parameters, args: Optional[HipArgs] = None):
+        self.params = params
+        self.context = HipContext(params, args)
+
+    @classmethod
+    def new(cls, params: Parameters, args: Optional[HipArgs] = None) -> "Simulation":
+        """``SimulateCreate::new(params, args)`` (compute/shared/src/lib.rs:42-45)."""
+        return cls(params, args)
+
+    def make_species(self, shape: Sequence[int]) -> Species:
+        """``SimulateBase::make_species`` (lib.rs:33-34)."""
+        return Species.new(self.context, shape)
+
+    def perform_steps(self, species: Species, steps: int) -> None:
+        """``Simulate::perform_steps`` (lib.rs:48-58): enqueue ``steps`` steps; on return the
+        input slots of ``species`` hold (handles to) the final state.  Asynchronous, like the
+        reference's GPU backends (compute/gpu/naive/src/lib.rs:99-131): a later download or
+        ``context.sync()`` waits."""
+        in_u, in_v, out_u, out_v = species.in_out()
+        slot = ctypes.c_int32(0)
+        lib = self.context._lib
+        capi.check(lib.gs_run(self.context.handle, in_u.handle, in_v.handle, out_u.handle,
+                              out_v.handle, int(steps), ctypes.byref(slot)))
+        if slot.value == 1:  # odd number of steps: the newest state sits in the output slot
+            species.u._pair.reverse()
+            species.v._pair.reverse()
+
+    def perform_step(self, species: Species) -> None:
+        """One ``gs_step`` then ``species.flip()`` -- the ``SimulateStep`` form (cpu.rs:21-42)."""
+        in_u, in_v, out_u, out_v = species.in_out()
+        capi.check(self.context._lib.gs_step(self.context.handle, in_u.handle, in_v.handle,
+                                             out_u.handle, out_v.handle))
+        species.flip()

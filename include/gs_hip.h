@@ -1,0 +1,183 @@
+/*
+ * gs_hip.h -- C ABI of the MI355X-native Gray-Scott compute backend (libgs_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of HadrienG2/grayscott: the per-timestep
+ * 9-point Laplacian + u*v^2 reaction update that every compute backend of the reference
+ * implements behind
+ *     SimulateBase / SimulateCreate / Simulate      compute/shared/src/lib.rs:19-58
+ *     Concentration / Species                       data/src/concentration/mod.rs:17-296
+ * Results follow the reference's *naive* backend (compute/naive/src/lib.rs:42-83) bit for
+ * bit, including its clipped-window boundary rule and FTZ-without-DAZ denormal handling.
+ *
+ * The reference is Rust; a backend crate binds these entry points through `extern "C"`
+ * (rust/compute_hip/src/ffi.rs, shown in INTEGRATION.md).  Plain pointers, sizes and
+ * integer status codes only: no C++ / torch / HIP types cross this boundary.
+ *
+ * Conventions
+ *   - Every function returns GS_OK (0) or a negative gs_status; gs_last_error() returns a
+ *     thread-local, human-readable message for the last failure on the calling thread.
+ *     No exceptions, aborts or panics cross the ABI.  (The reference's error contract:
+ *     `type Error: Error + From<C::Error> + Send + Sync`, compute/shared/src/lib.rs:31.)
+ *   - Handles are created and destroyed by the caller.  The library never keeps a host
+ *     pointer past the call that received it.
+ *   - Calls on one gs_ctx must be externally serialised (the reference takes
+ *     `&mut Species` in perform_steps); a context may be moved between threads: every
+ *     entry point selects its own device(s).
+ *   - gs_step / gs_run only enqueue work; gs_sync (or a download) waits for it.
+ *   - Shapes are [rows, cols] in scalar units, as in Concentration::shape()
+ *     (data/src/concentration/mod.rs:191-221).  Storage is row-major f32 (`Precision`,
+ *     data/src/lib.rs:11).
+ *
+ * Domain decomposition
+ *   A context owns `n_local` row slabs (one per entry of device_ids; ids may repeat) which
+ *   together cover the rows of this process; `world` processes (one per GPU when launched
+ *   under torchrun) cover the global grid in rank order.  Slabs keep one ghost row above
+ *   and below; after every step the ghost rows of the freshly written planes are refreshed
+ *   from the neighbouring slab: by a device-to-device copy inside a process, by RCCL
+ *   ncclSend/ncclRecv between processes, on a side stream overlapped with the interior
+ *   update.  The reference has no multi-device code; its in-process precedent is
+ *   SimulateCpu::split_grid (compute/shared/src/cpu.rs:111-154).
+ */
+#ifndef GS_HIP_H
+#define GS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+
+typedef enum gs_status {
+    GS_OK = 0,
+    GS_ERR_INVALID = -1,     /* bad argument / shape mismatch (the reference panics: mod.rs:291-295) */
+    GS_ERR_HIP = -2,         /* a HIP runtime call failed                                  */
+    GS_ERR_RCCL = -3,        /* librccl could not be loaded or an RCCL call failed         */
+    GS_ERR_NO_DEVICE = -4,   /* no usable gfx950 device                                    */
+    GS_ERR_UNSUPPORTED = -5, /* request outside what this build implements                 */
+    GS_ERR_NOMEM = -6
+} gs_status;
+
+/* Parameters (data/src/parameters.rs:13-33): stencil weights row-major + the five rates. */
+typedef struct gs_params {
+    float w[3][3];
+    float du;   /* diffusion_rate_u */
+    float dv;   /* diffusion_rate_v */
+    float feed; /* feed_rate        */
+    float kill; /* kill_rate        */
+    float dt;   /* time_step        */
+} gs_params;
+
+/* Arithmetic flavour of the step kernels.
+ *   GS_MATH_STRICT  every reference operation is a separately rounded f32 op and the
+ *                   kernels run with f32 denormal mode "flush results, keep inputs", which
+ *                   is what MXCSR.FTZ (DenormalsFlusher, compute/shared/src/lib.rs:161-180)
+ *                   does on the CPU: bit-identical to naive under FTZ, sub-normals included.
+ *   GS_MATH_FUSED   the eight tap updates per species use one FMA each (exact for the
+ *                   power-of-two Oono-Puri weights as long as the product is a normal
+ *                   number) and denormals are kept: bit-identical to naive wherever no
+ *                   intermediate is sub-normal, |diff| <= 1e-37 elsewhere.  Refused
+ *                   (GS_ERR_UNSUPPORTED) for weights that are not 0 or a power of two.    */
+typedef enum gs_math { GS_MATH_STRICT = 0, GS_MATH_FUSED = 1 } gs_math;
+
+/* Which step kernel gs_step launches. */
+typedef enum gs_kernel {
+    GS_KERNEL_AUTO = 0,    /* best measured variant for the shape                          */
+    GS_KERNEL_SIMPLE = 1,  /* one thread per cell, global loads only (cross-check kernel)  */
+    GS_KERNEL_STREAM = 2,  /* register sliding window, 16-B loads, DPP halo exchange       */
+    GS_KERNEL_LDS = 3      /* LDS-staged (tile + halo) window, multi-step capable          */
+} gs_kernel;
+
+/* Backend options: the C view of the Rust `CliArgs` (compute/shared/src/lib.rs:20-25 --
+ * every field has a default; zero-initialise and override). */
+typedef struct gs_options {
+    int32_t math;            /* gs_math; default STRICT                                    */
+    int32_t kernel;          /* gs_kernel; default AUTO                                    */
+    int32_t rows_per_block;  /* rows each wave marches over (0 = auto)                     */
+    int32_t fuse_steps;      /* steps fused per launch in gs_run where supported (0 = auto)*/
+    int32_t use_graph;       /* 1 = replay gs_run batches through a hipGraph (0 = off)     */
+    int32_t pitch_pad;       /* extra f32 of row pitch beyond the 64-float round-up        */
+    int32_t reserved[10];
+} gs_options;
+
+typedef struct gs_ctx gs_ctx;     /* devices, streams, row partition, RCCL communicator    */
+typedef struct gs_field gs_field; /* one f32 plane [rows, cols], slab-distributed           */
+
+/* Parameters::default() (parameters.rs:72-83) with the Oono-Puri weights (:116-122). */
+void gs_default_params(gs_params *out);
+void gs_default_options(gs_options *out);
+
+int32_t gs_abi_version(void);
+const char *gs_last_error(void);
+int32_t gs_device_count(int32_t *out);
+
+/* 128-byte RCCL unique id, created on rank 0 and handed to every rank out of band. */
+#define GS_UNIQUE_ID_BYTES 128
+int32_t gs_get_unique_id(void *out128);
+
+/* SimulateCreate::new(params, args) (compute/shared/src/lib.rs:42-45).
+ *   device_ids / n_local : local slabs, top to bottom (NULL / 0 = one slab on device 0)
+ *   rank, world          : this process's place in the row-wise chain (0, 1 = single process)
+ *   unique_id            : gs_get_unique_id() bytes of rank 0; required iff world > 1      */
+int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *opts,
+                      const int32_t *device_ids, int32_t n_local, int32_t rank, int32_t world,
+                      const void *unique_id);
+int32_t gs_ctx_destroy(gs_ctx *ctx);
+int32_t gs_ctx_set_params(gs_ctx *ctx, const gs_params *params);
+
+/* Concentration::default / zeros / ones (concentration/mod.rs:205-218) = create (+ fill).
+ * `rows`, `cols` are the GLOBAL shape; every process passes the same values. */
+int32_t gs_field_create(gs_ctx *ctx, gs_field **out, uint64_t rows, uint64_t cols);
+int32_t gs_field_destroy(gs_ctx *ctx, gs_field *f);
+int32_t gs_field_shape(const gs_field *f, uint64_t *rows, uint64_t *cols);
+/* Rows [row0, row1) of the global grid that this process stores. */
+int32_t gs_field_local_rows(const gs_field *f, uint64_t *row0, uint64_t *row1);
+/* Concentration::raw_shape (mod.rs:223-228): local rows incl. ghost rows, row pitch in f32. */
+int32_t gs_field_raw_shape(const gs_field *f, uint64_t *raw_rows, uint64_t *pitch);
+
+int32_t gs_field_fill(gs_ctx *ctx, gs_field *f, float value);
+/* Concentration::fill_slice (mod.rs:230-243): global half-open ranges; rows outside this
+ * process's slabs are skipped. */
+int32_t gs_field_fill_slice(gs_ctx *ctx, gs_field *f, uint64_t r0, uint64_t r1, uint64_t c0,
+                            uint64_t c1, float value);
+/* Concentration::finalize (mod.rs:245-253): make the plane usable as a step input, i.e.
+ * refresh ghost rows after fill / fill_slice / upload.  gs_step does it on demand. */
+int32_t gs_field_finalize(gs_ctx *ctx, gs_field *f);
+/* Dense row-major host <-> device copies of this process's rows (blocking).  `host` points
+ * at local row 0, i.e. global row `row0` of gs_field_local_rows.  download =
+ * Concentration::write_scalar_view (mod.rs:277-288). */
+int32_t gs_field_upload(gs_ctx *ctx, gs_field *f, const float *host);
+int32_t gs_field_download(gs_ctx *ctx, gs_field *f, float *host);
+/* Device address of local slab `slab`'s row 0 (for zero-copy consumers); *pitch in f32. */
+int32_t gs_field_device_ptr(const gs_field *f, int32_t slab, void **ptr, uint64_t *pitch,
+                            uint64_t *slab_row0, uint64_t *slab_rows, int32_t *device);
+
+/* One time step: reads (in_u, in_v), writes (out_u, out_v).  Asynchronous.  The caller
+ * flips its handles afterwards, as Species::flip does (concentration/mod.rs:88-92). */
+int32_t gs_step(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs_field *out_v);
+
+/* Simulate::perform_steps (compute/shared/src/lib.rs:48-58): `steps` steps ping-ponging
+ * between slot 0 (u0, v0: input on entry) and slot 1.  *result_slot receives the slot that
+ * holds the newest state (steps odd -> 1); the caller swaps its handles accordingly so that
+ * "the input concentrations contain the final results" (:51-52).  Asynchronous. */
+int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *v1,
+               uint64_t steps, int32_t *result_slot);
+
+/* Wait for everything enqueued on this context (all local devices and streams). */
+int32_t gs_sync(gs_ctx *ctx);
+
+/* Device-side stopwatch on the context's compute stream(s) (HIP events): start/stop
+ * bracket enqueued work; elapsed is the maximum over local slabs, in milliseconds. */
+int32_t gs_timer_start(gs_ctx *ctx);
+int32_t gs_timer_stop(gs_ctx *ctx, float *elapsed_ms);
+
+/* Introspection for tests and the bench: name of the kernel variant last launched and the
+ * number of kernel launches it took. */
+int32_t gs_ctx_info(const gs_ctx *ctx, char *kernel_name, size_t cap, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GS_HIP_H */

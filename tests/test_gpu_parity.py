@@ -1,0 +1,296 @@
+"""Parity tests proper: the HIP path, called through the C ABI (libgs_hip.so), against the CPU
+oracle on the same inputs -- BIT EXACT (memcmp) for the strict flavour, which is a stronger
+statement than north_star's tolerance of 1e-5 relative.  The fused flavour is held to
+bit-exactness wherever no sub-normal intermediate occurs and to |diff| <= 1e-37 elsewhere.
+
+All tests need a real MI355X:  python -m pytest tests -m gpu
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from grayscott_amd import GsError, HipArgs, Parameters, Simulation, capi
+from tests.helpers import (STRESS_SHAPES, assert_bits_equal, gpu_run, oracle_params,
+                           species_from_arrays, stress_fields)
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+REL_TOL = 1e-5  # north_star: "results within 1e-5 rel of the naive CPU reference"
+
+
+def args(**kw):
+    kw.setdefault("devices", [0])
+    return HipArgs(**kw)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built(built):
+    assert capi.device_count() >= 1, "no MI355X visible"
+
+
+# ---- small and ragged shapes, random data ---------------------------------------------------
+@pytest.mark.parametrize("kernel", [capi.GS_KERNEL_SIMPLE, capi.GS_KERNEL_STREAM])
+@pytest.mark.parametrize("shape", STRESS_SHAPES + [(5, 256), (9, 257), (33, 255), (6, 1024), (40, 1030)])
+def test_stress_shapes_bit_exact(shape, kernel):
+    for seed in (0, 1, 2):
+        u0, v0 = stress_fields(shape, seed)
+        for steps in (1, 7):
+            ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True)
+            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(kernel=kernel))
+            assert_bits_equal(got_u, ref_u, f"U {shape} seed {seed} steps {steps} {info[0]}")
+            assert_bits_equal(got_v, ref_v, f"V {shape} seed {seed} steps {steps} {info[0]}")
+
+
+@pytest.mark.parametrize("rpb", [1, 2, 3, 8, 64])
+def test_rows_per_block_does_not_change_results(rpb):
+    u0, v0 = stress_fields((77, 600), 3)
+    ref_u, ref_v = oracle.run(u0, v0, 5, ftz=True)
+    got_u, got_v, _ = gpu_run(u0, v0, 5, args=args(kernel=capi.GS_KERNEL_STREAM, rows_per_block=rpb))
+    assert_bits_equal(got_u, ref_u, f"U rpb {rpb}")
+    assert_bits_equal(got_v, ref_v, f"V rpb {rpb}")
+
+
+# ---- committed golden vectors (no oracle needed at run time) -------------------------------
+def test_golden_vectors():
+    for path in sorted(glob.glob(os.path.join(GOLDEN, "stress_*.npz"))):
+        g = np.load(path)
+        for steps in (1, 20):
+            got_u, got_v, _ = gpu_run(g["u0"], g["v0"], steps)
+            assert_bits_equal(got_u, g[f"u_{steps}"], f"{os.path.basename(path)} U {steps}")
+            assert_bits_equal(got_v, g[f"v_{steps}"], f"{os.path.basename(path)} V {steps}")
+    g = np.load(os.path.join(GOLDEN, "species_new_64x128.npz"))
+    sim = Simulation.new(Parameters(), args())
+    species = sim.make_species([64, 128])
+    done = 0
+    for steps in (1, 10, 100, 1000):
+        sim.perform_steps(species, steps - done)
+        done = steps
+        in_u, in_v, _, _ = species.in_out()
+        assert_bits_equal(in_u.make_scalar_view(sim.context), g[f"u_{steps}"], f"species_new U {steps}")
+        assert_bits_equal(in_v.make_scalar_view(sim.context), g[f"v_{steps}"], f"species_new V {steps}")
+
+
+def test_ftz_rule_matches_cpu_flush_to_zero():
+    """Strict flavour = MXCSR.FTZ semantics (flush results, keep inputs): V's sub-normal front."""
+    g = np.load(os.path.join(GOLDEN, "ftz_front_64x128.npz"))
+    u0, v0 = oracle.init_species(64, 128)
+    for steps in (30, 40):
+        got_u, got_v, _ = gpu_run(u0, v0, steps)
+        assert_bits_equal(got_v, g[f"v_{steps}"], f"FTZ V {steps}")
+        assert_bits_equal(got_u, g[f"u_{steps}"], f"FTZ U {steps}")
+        # and it is NOT the keep-denormals answer
+        assert np.count_nonzero(got_v.view(np.uint32) != g[f"v_{steps}_noftz"].view(np.uint32)) > 100
+
+
+# ---- BASELINE config 1: 1080 x 1920, Species::new, default feed/kill, 1000 steps -----------
+def test_config1_1080x1920_1000_steps():
+    rows, cols, steps = 1080, 1920, 1000
+    sim = Simulation.new(Parameters(), args())
+    species = sim.make_species([rows, cols])
+    assert species.shape() == (rows, cols)
+    sim.perform_steps(species, steps)
+    in_u, in_v, _, _ = species.in_out()
+    got_u, got_v = in_u.make_scalar_view(sim.context), in_v.make_scalar_view(sim.context)
+    u0, v0 = oracle.init_species(rows, cols)
+    ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True)
+    # the stated tolerance first (field-relative), then the stronger bit-exact claim
+    assert np.max(np.abs(got_u - ref_u)) <= REL_TOL * np.max(np.abs(ref_u))
+    assert np.max(np.abs(got_v - ref_v)) <= REL_TOL * np.max(np.abs(ref_v))
+    assert_bits_equal(got_u, ref_u, "config 1 U")
+    assert_bits_equal(got_v, ref_v, "config 1 V")
+    # SURVEY section 8c self-consistency sums
+    assert abs(got_u.sum(dtype=np.float64) - 2072039.383495) < 1e-5
+    assert abs(got_v.sum(dtype=np.float64) - 354.492044) < 1e-5
+
+
+# ---- fused flavour -----------------------------------------------------------------------------
+def test_fused_flavour():
+    # no sub-normals anywhere (few steps, fields O(1)): identical bits
+    u0, v0 = stress_fields((250, 130), 1)
+    ref_u, ref_v = oracle.run(u0, v0, 20, ftz=True)
+    got_u, got_v, info = gpu_run(u0, v0, 20, args=args(math=capi.GS_MATH_FUSED))
+    assert "fused" in info[0]
+    assert_bits_equal(got_u, ref_u, "fused U")
+    assert_bits_equal(got_v, ref_v, "fused V")
+    # sub-normal front present: U still identical, V within 1e-37 absolute
+    u0, v0 = oracle.init_species(64, 128)
+    ref_u, ref_v = oracle.run(u0, v0, 100, ftz=True)
+    got_u, got_v, _ = gpu_run(u0, v0, 100, args=args(math=capi.GS_MATH_FUSED))
+    assert_bits_equal(got_u, ref_u, "fused U with sub-normal V front")
+    assert np.max(np.abs(got_v.astype(np.float64) - ref_v.astype(np.float64))) <= 1e-37
+    assert np.max(np.abs(got_v - ref_v)) <= REL_TOL * np.max(np.abs(ref_v))
+
+
+def test_fused_refuses_non_power_of_two_weights():
+    pk = ((1 / 6, 4 / 6, 1 / 6), (4 / 6, 0.0, 4 / 6), (1 / 6, 4 / 6, 1 / 6))
+    with pytest.raises(GsError) as e:
+        Simulation.new(Parameters(weights=pk), args(math=capi.GS_MATH_FUSED))
+    assert e.value.code == capi.GS_ERR_UNSUPPORTED
+
+
+# ---- non-default parameters (CLI overrides -k -f -t, ui/src/lib.rs:51-63) and weights ------
+@pytest.mark.parametrize("kernel", [capi.GS_KERNEL_SIMPLE, capi.GS_KERNEL_STREAM])
+def test_non_default_parameters(kernel):
+    pk = ((1 / 6, 4 / 6, 1 / 6), (4 / 6, 0.0, 4 / 6), (1 / 6, 4 / 6, 1 / 6))
+    for p in (Parameters(feed_rate=0.03, kill_rate=0.06, time_step=0.5),
+              Parameters(weights=pk, time_step=0.75),
+              Parameters(weights=((0, 1, 0), (1, 0, 1), (0, 1, 0)), diffusion_rate_u=0.2)):
+        u0, v0 = stress_fields((37, 300), 4)
+        ref_u, ref_v = oracle.run(u0, v0, 9, oracle_params(p), ftz=True)
+        got_u, got_v, _ = gpu_run(u0, v0, 9, params=p, args=args(kernel=kernel))
+        assert_bits_equal(got_u, ref_u, f"U {p}")
+        assert_bits_equal(got_v, ref_v, f"V {p}")
+
+
+# ---- the Species / Simulate contract -----------------------------------------------------------
+def test_species_new_and_flip_contract():
+    sim = Simulation.new(Parameters(), args())
+    species = sim.make_species([64, 128])
+    in_u, in_v, out_u, out_v = species.in_out()
+    u0, v0 = oracle.init_species(64, 128)
+    assert_bits_equal(in_u.make_scalar_view(sim.context), u0, "Species::new U")
+    assert_bits_equal(in_v.make_scalar_view(sim.context), v0, "Species::new V")
+    assert in_u.raw_shape() == (66, 128)  # one slab: rows + 2 ghost rows, pitch 128
+    # perform_step + flip == perform_steps(1); results land in the input slot either way
+    sim.perform_step(species)
+    a = species.make_result_view()
+    sim2 = Simulation.new(Parameters(), args())
+    sp2 = sim2.make_species([64, 128])
+    sim2.perform_steps(sp2, 1)
+    b = sp2.make_result_view()
+    ref_u, ref_v = oracle.run(u0, v0, 1)
+    assert_bits_equal(a, ref_v, "perform_step result view")
+    assert_bits_equal(b, ref_v, "perform_steps(1) result view")
+    # steps = 0 is a no-op; even and odd counts both leave the result in the input slot
+    sim2.perform_steps(sp2, 0)
+    assert_bits_equal(sp2.make_result_view(), ref_v, "perform_steps(0)")
+    sim2.perform_steps(sp2, 2)
+    ref3 = oracle.run(u0, v0, 3)
+    assert_bits_equal(sp2.make_result_view(), ref3[1], "perform_steps(1)+(2)")
+    target = np.empty((64, 128), np.float32)
+    sp2.write_result_view(target)
+    assert_bits_equal(target, ref3[1], "write_result_view")
+    with pytest.raises(AssertionError):  # validate_write panics on shape mismatch (mod.rs:291-295)
+        sp2.write_result_view(np.empty((64, 127), np.float32))
+
+
+def test_error_behaviour():
+    sim = Simulation.new(Parameters(), args())
+    ctx = sim.context
+    from grayscott_amd import HipConcentration
+
+    a = HipConcentration(ctx, (8, 8))
+    b = HipConcentration(ctx, (8, 9))
+    lib = ctx._lib
+    assert lib.gs_step(ctx.handle, a.handle, a.handle, a.handle, a.handle) == capi.GS_ERR_INVALID
+    assert lib.gs_step(ctx.handle, a.handle, b.handle, a.handle, b.handle) == capi.GS_ERR_INVALID
+    with pytest.raises(GsError):
+        a.fill_slice(ctx, [range(0, 9), range(0, 8)], 1.0)  # out of range, as ndarray slicing panics
+    with pytest.raises(GsError):
+        HipConcentration(ctx, (0, 8))
+    with pytest.raises(GsError):
+        Simulation.new(Parameters(), HipArgs(devices=[99]))
+    a.fill_slice(ctx, [range(2, 2), range(0, 8)], 5.0)  # empty range is fine
+    assert float(a.make_scalar_view(ctx).sum()) == 0.0
+
+
+# ---- in-process row slabs with ghost rows (the multi-GPU data path on one GPU) --------------
+@pytest.mark.parametrize("nslabs", [2, 3, 5])
+def test_row_slabs_bit_identical_to_single(nslabs):
+    for shape, steps in (((64, 128), 50), ((37, 300), 12), ((nslabs, 9), 4), ((250, 1030), 6)):
+        u0, v0 = stress_fields(shape, 7)
+        ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True)
+        got_u, got_v, _ = gpu_run(u0, v0, steps, args=args(devices=[0] * nslabs))
+        assert_bits_equal(got_u, ref_u, f"U {nslabs} slabs {shape}")
+        assert_bits_equal(got_v, ref_v, f"V {nslabs} slabs {shape}")
+
+
+def test_row_slabs_species_new_and_stepwise():
+    sim = Simulation.new(Parameters(), args(devices=[0, 0, 0, 0]))
+    species = sim.make_species([128, 256])
+    assert species.raw_shape() == (128 + 8, 256)
+    for _ in range(30):
+        sim.perform_step(species)
+    sim.perform_steps(species, 31)
+    u0, v0 = oracle.init_species(128, 256)
+    ref_u, ref_v = oracle.run(u0, v0, 61)
+    in_u, in_v, _, _ = species.in_out()
+    assert_bits_equal(in_u.make_scalar_view(sim.context), ref_u, "4 slabs U")
+    assert_bits_equal(in_v.make_scalar_view(sim.context), ref_v, "4 slabs V")
+    with pytest.raises(GsError):
+        sim.make_species([3, 16])  # fewer rows than slabs
+
+
+# ---- large grids: size-independent properties + GPU-vs-GPU equivalence chain ----------------
+def test_large_grid_properties_4096():
+    """4096 x 4096 (BASELINE config 2): (a) stream kernel == simple kernel bit for bit,
+    (b) the far field is an exact fixed point (U=1, V=0), (c) a band of rows around the seed
+    equals the oracle run on a cropped domain whose edges the signal has not reached."""
+    rows = cols = 4096
+    steps = 24
+    out = {}
+    for kernel in (capi.GS_KERNEL_SIMPLE, capi.GS_KERNEL_STREAM):
+        sim = Simulation.new(Parameters(), args(kernel=kernel))
+        sp = sim.make_species([rows, cols])
+        sim.perform_steps(sp, steps)
+        in_u, in_v, _, _ = sp.in_out()
+        out[kernel] = (in_u.make_scalar_view(sim.context), in_v.make_scalar_view(sim.context))
+        sim.context.close()
+    su, sv = out[capi.GS_KERNEL_SIMPLE]
+    tu, tv = out[capi.GS_KERNEL_STREAM]
+    assert_bits_equal(tu, su, "stream vs simple U 4096^2")
+    assert_bits_equal(tv, sv, "stream vs simple V 4096^2")
+    (r0, r1), (c0, c1) = oracle.seed_ranges(rows, cols)
+    m = steps + 2
+    far = np.ones((rows, cols), bool)
+    far[r0 - m:r1 + m, c0 - m:c1 + m] = False
+    assert (tu[far] == 1.0).all() and (tv[far] == 0.0).all()
+    # crop: the influence cone of the seed after `steps` steps stays inside [r0-m, r1+m) x [c0-m, c1+m);
+    # outside it the state is the fixed point, so a crop with a 2m margin evolves identically
+    R0, R1, C0, C1 = r0 - 2 * m, r1 + 2 * m, c0 - 2 * m, c1 + 2 * m
+    u0, v0 = oracle.init_species(rows, cols)
+    cu, cv = oracle.run(u0[R0:R1, C0:C1], v0[R0:R1, C0:C1], steps)
+    inner = (slice(m, R1 - R0 - m), slice(m, C1 - C0 - m))
+    assert_bits_equal(tu[R0:R1, C0:C1][inner], cu[inner], "crop U")
+    assert_bits_equal(tv[R0:R1, C0:C1][inner], cv[inner], "crop V")
+
+
+def test_headline_grid_16384_equivalence_chain():
+    """16384 x 16384 (BASELINE config 3 shape): random-ish data everywhere, 3 steps,
+    production kernel vs cross-check kernel vs 2 in-process slabs: identical bits.
+    (The oracle cannot run this size in test time; the chain oracle == simple kernel ==
+    stream kernel is closed on the smaller sizes above.)"""
+    rows = cols = 16384
+    rng = np.random.default_rng(11)
+    base_u = rng.random((256, cols), dtype=np.float32)
+    base_v = (rng.random((256, cols), dtype=np.float32) * np.float32(0.5)).astype(np.float32)
+    u0 = np.tile(base_u, (rows // 256, 1))
+    v0 = np.tile(base_v, (rows // 256, 1))
+    u0[::7] = u0[::7][:, ::-1]  # break the vertical periodicity
+    results = []
+    for kw in (dict(kernel=capi.GS_KERNEL_SIMPLE), dict(kernel=capi.GS_KERNEL_STREAM),
+               dict(kernel=capi.GS_KERNEL_STREAM, devices=[0, 0])):
+        sim = Simulation.new(Parameters(), args(**kw))
+        sp = species_from_arrays(sim, u0, v0)
+        sim.perform_steps(sp, 3)
+        in_u, in_v, _, _ = sp.in_out()
+        results.append((in_u.make_scalar_view(sim.context), in_v.make_scalar_view(sim.context)))
+        for c in sp.u._pair + sp.v._pair:
+            c.destroy()
+        sim.context.close()
+    for k in (1, 2):
+        for f, name in ((0, "U"), (1, "V")):
+            same = np.array_equal(results[k][f].view(np.uint32), results[0][f].view(np.uint32))
+            assert same, f"{name} variant {k} differs from the cross-check kernel"
+    # oracle on the top-left corner block (exact for cells whose 3-step cone stays inside it)
+    n = 160
+    cu, cv = oracle.run(u0[:n, :n], v0[:n, :n], 3)
+    assert_bits_equal(results[1][0][:n - 3, :n - 3], cu[:n - 3, :n - 3], "corner U")
+    assert_bits_equal(results[1][1][:n - 3, :n - 3], cv[:n - 3, :n - 3], "corner V")
+    # and the bottom-right corner (clipped-window rule on the far edges)
+    cu, cv = oracle.run(u0[-n:, -n:], v0[-n:, -n:], 3)
+    assert_bits_equal(results[1][0][-n + 3:, -n + 3:], cu[3:, 3:], "far corner U")
+    assert_bits_equal(results[1][1][-n + 3:, -n + 3:], cv[3:, 3:], "far corner V")
