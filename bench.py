@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the Gray-Scott step path on MI355X (contract: see the task statement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one simulation time step of the whole grid (the reference's own throughput
+unit is cells x steps, compute/shared/src/benchmark.rs:55-59; its "compute" workload is
+perform_steps only, :77-83).  Inputs are resident in HBM before the timed region starts.
+
+N = 1 : BASELINE.json's headline workload, 16384 x 16384 f32 (config 3), Species::new init,
+        default feed/kill.  Rank 0 also times the CPU port of the reference's
+        parallel(block(autovec)) backend on the host cores on a bounded sample.
+N > 1 : launched by torchrun, one process per GPU; weak scaling with 2^28 cells per GPU:
+        rows = 16384 * N over 16384 columns (N = 8: 65536 x 32768, BASELINE config 5), row
+        slabs with ghost-row exchange through RCCL send/recv inside libgs_hip.so.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_CELL_STEP = 16          # read U,V + write U,V, 4 B each
+HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip table)
+HBM_COPY_CEILING_GBS = 6290.0     # measured float4-copy ceiling, same table
+
+
+def grid_for(n_gpus: int):
+    if n_gpus == 8:
+        return 65536, 32768       # BASELINE config 5
+    return 16384 * n_gpus, 16384  # config 3 (N=1), config 4 shape (N=2), same cells per GPU
+
+
+def cpu_baseline(target_seconds: float = 15.0):
+    """Times the CPU port (oracle/gs_cpu_parallel.c) of the reference's parallel backend on a
+    bounded sample of the SAME workload: 16384 x 16384, Species::new init, a few steps."""
+    from oracle import cpu_parallel
+
+    rows, cols = 16384, 16384
+    threads = os.cpu_count() or 1
+    sim = cpu_parallel.ParallelSimulation(rows, cols, num_threads=threads, ftz=True)
+    sim.perform_steps(1)                                  # touch pages / warm the thread team
+    t0 = time.perf_counter()
+    sim.perform_steps(1)
+    one = time.perf_counter() - t0
+    n = max(2, min(200, int(target_seconds / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    sim.perform_steps(n)
+    dt = time.perf_counter() - t0
+    info = {
+        "value": rows * cols * n / dt / 1e6,
+        "unit": "Mcells×steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{rows}x{cols} f32, Species::new init, {n} steps of the parallel(block(autovec)) "
+                  f"port (oracle/gs_cpu_parallel.c), SIMD width {cpu_parallel.simd_width()}, FTZ on, "
+                  f"L1/L2 block {sim.l1_block_size}/{sim.l2_block_size} B, {dt:.1f} s",
+    }
+    sim.close()
+    return info
+
+
+def measured_traffic(kernel_name: str):
+    """HBM bytes per launch from rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/profile_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs); None if absent."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            data = json.load(f)
+        return data.get(kernel_name, data.get("default"))
+    except (OSError, ValueError):
+        return None
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--rows", type=int, default=0, help="override the grid (diagnostics only)")
+    ap.add_argument("--cols", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from grayscott_amd import HipArgs, Parameters, Simulation, capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus N > 1 must be launched with torch.distributed.run "
+                  "(one process per GPU)", file=sys.stderr)
+            return 2
+        args.gpus = world
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+
+    unique_id = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+        buf = torch.zeros(capi.GS_UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(capi.get_unique_id()), dtype=torch.uint8))
+        dist.broadcast(buf, src=0)
+        unique_id = bytes(buf.cpu().numpy().tobytes())
+
+    rows, cols = grid_for(args.gpus)
+    if args.rows and args.cols:
+        rows, cols = args.rows, args.cols
+    hip_args = HipArgs(devices=[local_rank], rank=rank, world=world, unique_id=unique_id)
+    sim = Simulation.new(Parameters(), hip_args)
+    species = sim.make_species([rows, cols])        # Species::new on the device, HBM-resident
+    ctx = sim.context
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    sim.perform_steps(species, args.warmup)
+    ctx.sync()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_start()                               # HIP events on the library's own stream
+    sim.perform_steps(species, args.steps)
+    event_ms = ctx.timer_stop()
+    ctx.sync()
+    torch.cuda.synchronize()
+    barrier()
+    wall = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([wall, event_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, event_ms = float(t[0]), float(t[1])
+
+    kernel_name, _ = ctx.info()
+    cells = rows * cols
+    value = cells * args.steps / wall / 1e6
+    # roofline of the dominant kernel: algorithmic bytes per launch / average launch duration.
+    # One launch = one time step of one GPU's slab (cells / N cells).
+    launch_ms = event_ms / args.steps
+    per_launch_bytes = BYTES_PER_CELL_STEP * cells / args.gpus
+    achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9
+    result = {
+        "metric": "Mcells×steps/s, 16384² f32 grid per GPU (Gray-Scott step, naive-rule parity)",
+        "value": value,
+        "unit": "Mcells×steps/s",
+        "n_gpus": args.gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{rows}x{cols} f32 (rows x cols), Species::new init, default feed/kill, "
+                        f"double-buffered U/V in HBM",
+            "cells_per_gpu": cells // args.gpus,
+            "kernel": kernel_name,
+            "partition": "single GPU" if args.gpus == 1 else
+                         f"{args.gpus} row slabs, RCCL send/recv ghost rows",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
+            "launch_ms": launch_ms,
+            "algorithmic_bytes_per_launch": per_launch_bytes,
+            "traffic": measured_traffic(kernel_name),
+        },
+    }
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(result, ensure_ascii=False))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -464,6 +464,7 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
 {
     if (!ctx) return GS_OK;
     for (auto &sl : ctx->slabs) {
+        if (!sl.compute && !sl.halo) continue; // never initialised (creation failed early)
         if (hipSetDevice(sl.device) != hipSuccess) continue;
         if (sl.halo) (void)hipStreamSynchronize(sl.halo);
         if (sl.compute) (void)hipStreamSynchronize(sl.compute);
@@ -472,6 +473,7 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
         if (Rccl *R = rccl()) R->CommDestroy(ctx->comm);
     }
     for (auto &sl : ctx->slabs) {
+        if (!sl.compute && !sl.halo) continue;
         if (hipSetDevice(sl.device) != hipSuccess) continue;
         for (int k = 0; k < 2; ++k) {
             if (sl.done[k]) (void)hipEventDestroy(sl.done[k]);
@@ -482,6 +484,7 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
         if (sl.halo) (void)hipStreamDestroy(sl.halo);
         if (sl.compute) (void)hipStreamDestroy(sl.compute);
     }
+    (void)hipGetLastError(); // teardown failures must not leak into later calls' status
     delete ctx;
     return GS_OK;
 }

@@ -317,8 +317,10 @@ hipError_t GS_SUFFIX(gs_launch_simple)(const GsStepArgs &a, hipStream_t s, const
     const long bpr = (a.cols + 255) >> 8;
     const long blocks = nrows * bpr;
     if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL(GS_SUFFIX(gs_step_simple_k), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    return hipGetLastError();
+    GsStepArgs args = a;
+    void *kargs[] = {&args};
+    return hipLaunchKernel(reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_simple_k)),
+                           dim3((unsigned)blocks), dim3(256), kargs, 0, s);
 }
 
 hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const char **name)
@@ -331,6 +333,8 @@ hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const
     const long strips = (a.cols + 255) >> 8;
     const long blocks = (chunks * strips + 3) / 4;
     if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL(GS_SUFFIX(gs_step_stream_k)<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-    return hipGetLastError();
+    GsStepArgs args = a;
+    void *kargs[] = {&args};
+    return hipLaunchKernel(reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_stream_k)<2>),
+                           dim3((unsigned)blocks), dim3(256), kargs, 0, s);
 }

@@ -24,8 +24,9 @@ hipError_t gs_launch_fill_rect(float *row0, int32_t pitch, int32_t r0, int32_t r
     for (int32_t b0 = r0; b0 < r1; b0 += 32768) {
         const int32_t b1 = (r1 - b0 > 32768) ? b0 + 32768 : r1;
         dim3 grid((unsigned)((c1 - c0 + 255) / 256), (unsigned)(b1 - b0));
-        hipLaunchKernelGGL(gs_fill_rect_k, grid, dim3(256), 0, s, row0, pitch, b0, c0, c1, value);
-        hipError_t e = hipGetLastError();
+        void *kargs[] = {&row0, &pitch, &b0, &c0, &c1, &value};
+        hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(&gs_fill_rect_k), grid, dim3(256),
+                                       kargs, 0, s);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -1,0 +1,214 @@
+//! MI355X (gfx950) HIP implementation of Gray-Scott simulation
+//!
+//! Thin shim over libgs_hip.so (hand-written HIP kernels behind a C ABI).  Storage lives in
+//! HBM as plain row-major f32 planes; `perform_steps` enqueues all steps asynchronously and
+//! flips the Rust-side handles per step, like the Vulkan backends re-derive their descriptor
+//! set per step (compute/gpu/naive/src/lib.rs:117-124).  Results match `compute_naive` bit
+//! for bit (clipped-window boundary rule, FTZ-without-DAZ denormal handling).
+
+mod ffi;
+
+use clap::Args;
+use compute::{Simulate, SimulateBase, SimulateCreate};
+use data::{
+    concentration::{Concentration, Species},
+    parameters::Parameters,
+    Precision,
+};
+use ndarray::{Array2, ArrayView2, ArrayViewMut2};
+use std::{ffi::CStr, ops::Range, ptr, rc::Rc};
+use thiserror::Error;
+
+/// Errors reported by libgs_hip.so (status code + gs_last_error() text)
+#[derive(Clone, Debug, Error)]
+#[error("gs_hip error {code}: {message}")]
+pub struct HipError {
+    pub code: i32,
+    pub message: String,
+}
+
+fn check(code: i32) -> Result<(), HipError> {
+    if code == ffi::GS_OK {
+        return Ok(());
+    }
+    // SAFETY: gs_last_error returns a NUL-terminated thread-local string owned by the library
+    let message = unsafe { CStr::from_ptr(ffi::gs_last_error()) }
+        .to_string_lossy()
+        .into_owned();
+    Err(HipError { code, message })
+}
+
+/// CLI parameters of the HIP backend (all defaulted, all settable from the environment, as
+/// compute/shared/src/lib.rs:20-25 requires)
+#[derive(Args, Clone, Debug)]
+pub struct HipArgs {
+    /// HIP device that runs the simulation
+    #[arg(long, env = "GS_HIP_DEVICE", default_value_t = 0)]
+    pub hip_device: i32,
+
+    /// Arithmetic flavour: 0 = strict (bit-identical to compute_naive), 1 = fused taps
+    #[arg(long, env = "GS_HIP_MATH", default_value_t = 0)]
+    pub hip_math: i32,
+
+    /// Rows each wavefront marches over (0 = automatic)
+    #[arg(long, env = "GS_HIP_ROWS_PER_BLOCK", default_value_t = 0)]
+    pub hip_rows_per_block: i32,
+}
+
+/// Owner of the `gs_ctx` (devices, streams); shared by the simulation and its species
+pub struct HipContextInner(*mut ffi::gs_ctx);
+//
+impl Drop for HipContextInner {
+    fn drop(&mut self) {
+        // SAFETY: created by gs_ctx_create, destroyed exactly once
+        unsafe { ffi::gs_ctx_destroy(self.0) };
+    }
+}
+/// `Concentration::Context` of [`HipConcentration`]
+pub type HipContext = Rc<HipContextInner>;
+
+/// One species plane in HBM
+pub struct HipConcentration {
+    context: HipContext,
+    field: *mut ffi::gs_field,
+    shape: [usize; 2],
+    /// Host mirror, lazily allocated by make_scalar_view (cf. simd/mod.rs:330-345)
+    scalar: Array2<Precision>,
+}
+//
+impl HipConcentration {
+    fn create(context: &mut HipContext, shape: [usize; 2], fill: Option<Precision>) -> Result<Self, HipError> {
+        let mut field = ptr::null_mut();
+        // SAFETY: plain FFI call, out pointer is valid
+        check(unsafe { ffi::gs_field_create(context.0, &mut field, shape[0] as u64, shape[1] as u64) })?;
+        if let Some(value) = fill {
+            check(unsafe { ffi::gs_field_fill(context.0, field, value) })?;
+        }
+        Ok(Self { context: context.clone(), field, shape, scalar: Array2::default([0, 0]) })
+    }
+}
+//
+impl Drop for HipConcentration {
+    fn drop(&mut self) {
+        // SAFETY: the context outlives the field through the Rc
+        unsafe { ffi::gs_field_destroy(self.context.0, self.field) };
+    }
+}
+//
+impl Concentration for HipConcentration {
+    type Context = HipContext;
+    type Error = HipError;
+
+    fn default(context: &mut HipContext, shape: [usize; 2]) -> Result<Self, HipError> {
+        Self::create(context, shape, None) // planes are created zero-filled
+    }
+    fn zeros(context: &mut HipContext, shape: [usize; 2]) -> Result<Self, HipError> {
+        Self::create(context, shape, None)
+    }
+    fn ones(context: &mut HipContext, shape: [usize; 2]) -> Result<Self, HipError> {
+        Self::create(context, shape, Some(1.0))
+    }
+    fn shape(&self) -> [usize; 2] {
+        self.shape
+    }
+    fn raw_shape(&self) -> [usize; 2] {
+        let (mut rows, mut pitch) = (0u64, 0u64);
+        // SAFETY: out pointers are valid; the call cannot fail on a live field
+        unsafe { ffi::gs_field_raw_shape(self.field, &mut rows, &mut pitch) };
+        [rows as usize, pitch as usize]
+    }
+    fn fill_slice(
+        &mut self,
+        context: &mut HipContext,
+        [rows, cols]: [Range<usize>; 2],
+        value: Precision,
+    ) -> Result<(), HipError> {
+        check(unsafe {
+            ffi::gs_field_fill_slice(
+                context.0, self.field, rows.start as u64, rows.end as u64, cols.start as u64,
+                cols.end as u64, value,
+            )
+        })
+    }
+    fn finalize(&mut self, context: &mut HipContext) -> Result<(), HipError> {
+        check(unsafe { ffi::gs_field_finalize(context.0, self.field) })
+    }
+
+    type ScalarView<'a> = ArrayView2<'a, Precision>;
+
+    fn make_scalar_view(&mut self, context: &mut HipContext) -> Result<ArrayView2<'_, Precision>, HipError> {
+        if self.scalar.is_empty() {
+            self.scalar = Array2::default(self.shape);
+        }
+        let ptr = self.scalar.as_mut_ptr();
+        check(unsafe { ffi::gs_field_download(context.0, self.field, ptr) })?; // syncs
+        Ok(self.scalar.view())
+    }
+    fn write_scalar_view(
+        &mut self,
+        context: &mut HipContext,
+        mut target: ArrayViewMut2<Precision>,
+    ) -> Result<(), HipError> {
+        Self::validate_write(self, &target);
+        match target.as_slice_mut() {
+            // dense row-major target (what `simulate` passes): download straight into it
+            Some(slice) => check(unsafe { ffi::gs_field_download(context.0, self.field, slice.as_mut_ptr()) }),
+            None => {
+                let view = self.make_scalar_view(context)?;
+                target.assign(&view);
+                Ok(())
+            }
+        }
+    }
+}
+
+/// Gray-Scott reaction simulation
+pub struct Simulation {
+    context: HipContext,
+}
+//
+impl SimulateBase for Simulation {
+    type CliArgs = HipArgs;
+    type Concentration = HipConcentration;
+    type Error = HipError;
+
+    fn make_species(&self, shape: [usize; 2]) -> Result<Species<HipConcentration>, HipError> {
+        Species::new(self.context.clone(), shape)
+    }
+}
+//
+impl SimulateCreate for Simulation {
+    fn new(params: Parameters, args: HipArgs) -> Result<Self, HipError> {
+        let weights = params.weights().0;
+        let c_params = ffi::gs_params {
+            w: weights,
+            du: params.diffusion_rate_u,
+            dv: params.diffusion_rate_v,
+            feed: params.feed_rate,
+            kill: params.kill_rate,
+            dt: params.time_step,
+        };
+        let mut opts = ffi::gs_options::default();
+        // SAFETY: fills a plain struct
+        unsafe { ffi::gs_default_options(&mut opts) };
+        opts.math = args.hip_math;
+        opts.rows_per_block = args.hip_rows_per_block;
+        let mut ctx = ptr::null_mut();
+        check(unsafe {
+            ffi::gs_ctx_create(&mut ctx, &c_params, &opts, &args.hip_device, 1, 0, 1, ptr::null())
+        })?;
+        Ok(Self { context: Rc::new(HipContextInner(ctx)) })
+    }
+}
+//
+impl Simulate for Simulation {
+    fn perform_steps(&self, species: &mut Species<HipConcentration>, steps: usize) -> Result<(), HipError> {
+        for _ in 0..steps {
+            let (in_u, in_v, out_u, out_v) = species.in_out();
+            // asynchronous: only enqueues the kernel(s) of this step
+            check(unsafe { ffi::gs_step(self.context.0, in_u.field, in_v.field, out_u.field, out_v.field) })?;
+            species.flip()?; // finalize() is a no-op on freshly stepped planes
+        }
+        Ok(())
+    }
+}

@@ -1,0 +1,43 @@
+// Exercises include/grayscott_hip.hpp (the C++ mirror of the reference's backend interface)
+// the way the reference's `simulate` binary drives a backend (simulate/src/main.rs:56-59,
+// 113-115): Simulation::new -> make_species -> perform_steps -> write_result_view.
+// Usage: host_mirror ROWS COLS STEPS OUT.bin   (writes U then V as raw f32)
+// Built and run by tests/test_cpp_host_mirror.py; plain g++, links libgs_hip.so.
+#include "grayscott_hip.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+
+int main(int argc, char **argv)
+{
+    if (argc != 5) {
+        std::fprintf(stderr, "usage: %s rows cols steps out.bin\n", argv[0]);
+        return 2;
+    }
+    const std::size_t rows = std::strtoull(argv[1], nullptr, 10), cols = std::strtoull(argv[2], nullptr, 10);
+    const std::size_t steps = std::strtoull(argv[3], nullptr, 10);
+    try {
+        gs::Simulation sim = gs::Simulation::new_(gs::Parameters());
+        gs::Species species = sim.make_species({rows, cols});
+        sim.perform_steps(species, steps);
+        std::vector<float> v(rows * cols);
+        species.write_result_view(v.data(), {rows, cols});
+        std::vector<float> u = species.u().in().make_scalar_view(species.context());
+        bool threw = false;
+        try {
+            species.write_result_view(v.data(), {rows, cols + 1}); // must be rejected
+        } catch (const std::logic_error &) {
+            threw = true;
+        }
+        if (!threw) return 3;
+        std::FILE *f = std::fopen(argv[4], "wb");
+        if (!f) return 4;
+        std::fwrite(u.data(), sizeof(float), u.size(), f);
+        std::fwrite(v.data(), sizeof(float), v.size(), f);
+        std::fclose(f);
+    } catch (const gs::HipError &e) {
+        std::fprintf(stderr, "HipError: %s\n", e.what());
+        return 10 - e.code; // GS_ERR_NO_DEVICE (-4) -> 14
+    }
+    return 0;
+}

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Profiles bench.py on the GPU box with rocprofv3 (run through gpurun):
+#   1. --kernel-trace --stats          per-kernel time (average launch duration)
+#   2. --pmc FETCH_SIZE                HBM read traffic   (its own pass: TCC has 4 slots,
+#   3. --pmc WRITE_SIZE                HBM write traffic   FETCH_SIZE costs 3, WRITE_SIZE 2)
+# PMC passes use --kernel-trace only (no sys/hip/hsa tracing), as the pool requires.
+# Raw CSVs land under gpurun_out/prof_$TAG/; tools/summarize_profile.py turns them into the
+# summaries committed under profiles/.
+set -eo pipefail
+TAG=${1:-r01}
+STEPS=${2:-200}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+EXTRA=${GS_BENCH_EXTRA:-}
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
+    python3 "$ROOT/bench.py" --steps "$STEPS" --warmup 20 --no-cpu-baseline $EXTRA > "$OUT/bench_stats.json" 2> "$OUT/stats.log"
+tail -1 "$OUT/bench_stats.json"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o bench -- \
+    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline $EXTRA > "$OUT/bench_fetch.json" 2> "$OUT/fetch.log"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o bench -- \
+    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline $EXTRA > "$OUT/bench_write.json" 2> "$OUT/write.log"
+find "$OUT" -name '*.csv' | head -20

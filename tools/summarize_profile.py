@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Turns the raw rocprofv3 CSVs of tools/profile_gpu.sh (gpurun_out/prof_<tag>/) into the
+summaries committed under profiles/:
+
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
+  profiles/<tag>_summary.md         per-kernel time + HBM traffic per launch of the step kernel
+  profiles/traffic.json             {"<bench kernel label>": bytes per launch, ...} read by bench.py
+
+HBM bytes per launch follow MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE come from
+separate --pmc passes, both are in KiB, and on gfx950 FETCH_SIZE reports exactly half of the
+bytes of wide coalesced (16 B/lane) streaming reads, so reads = 2 * FETCH_SIZE * 1024 while
+WRITE_SIZE * 1024 is exact for 16 B/lane streaming stores.
+"""
+import csv
+import json
+import os
+import shutil
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counter_values(path, needle, counter):
+    vals = []
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if needle in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                vals.append(float(row["Counter_Value"]))
+    return vals
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    needle = sys.argv[2] if len(sys.argv) > 2 else "gs_step_stream_k"
+    label = sys.argv[3] if len(sys.argv) > 3 else "default"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = os.path.join(src, "stats", "bench_kernel_stats.csv")
+    shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    rows = list(csv.DictReader(open(stats)))
+    fetch = counter_values(os.path.join(src, "fetch", "bench_counter_collection.csv"), needle, "FETCH_SIZE")
+    write = counter_values(os.path.join(src, "write", "bench_counter_collection.csv"), needle, "WRITE_SIZE")
+    bench = json.loads(open(os.path.join(src, "bench_stats.json")).read().strip().splitlines()[-1])
+    fetch_kib = statistics.median(fetch)
+    write_kib = statistics.median(write)
+    read_bytes = 2.0 * fetch_kib * 1024.0
+    write_bytes = write_kib * 1024.0
+    total = read_bytes + write_bytes
+    algo = bench["roofline"]["algorithmic_bytes_per_launch"]
+    kern = next(r for r in rows if needle in r["Name"])
+    avg_ms = float(kern["AverageNs"]) / 1e6
+    lines = [
+        f"# rocprofv3 summary `{tag}` — `{bench['config']['workload']}`",
+        "",
+        f"Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {bench['steps']} --warmup {bench['warmup']} --no-cpu-baseline`"
+        " (PMC passes: `--kernel-trace --pmc FETCH_SIZE` and `--kernel-trace --pmc WRITE_SIZE`, separate runs).",
+        "",
+        "| kernel | calls | avg ms | min ms | max ms | % of GPU time |",
+        "|---|---|---|---|---|---|",
+    ]
+    for r in rows:
+        lines.append(f"| `{r['Name']}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.4f} | {float(r['MinNs'])/1e6:.4f} |"
+                     f" {float(r['MaxNs'])/1e6:.4f} | {float(r['Percentage']):.2f} |")
+    lines += [
+        "",
+        f"Step kernel `{needle}` (bench label `{bench['config']['kernel']}`), per launch:",
+        "",
+        f"* average duration under the profiler: **{avg_ms:.4f} ms**; `bench.py`'s own HIP-event figure in the same run: "
+        f"{bench['roofline']['launch_ms']:.4f} ms (un-profiled runs are faster: profiling lowers clocks)",
+        f"* algorithmic bytes: {algo/2**30:.3f} GiB (16 B x {bench['config']['cells_per_gpu']} cells x steps per launch)",
+        f"* FETCH_SIZE median {fetch_kib:.0f} KiB -> reads = 2 x FETCH_SIZE = **{read_bytes/2**30:.3f} GiB** (gfx950 half-count correction)",
+        f"* WRITE_SIZE median {write_kib:.0f} KiB -> writes = **{write_bytes/2**30:.3f} GiB**",
+        f"* HBM traffic = **{total/2**30:.3f} GiB = {total/algo:.3f} x algorithmic**",
+        f"* algorithmic rate under the profiler: {algo/avg_ms/1e6:.0f} GB/s; HBM-side rate {total/avg_ms/1e6:.0f} GB/s",
+        "",
+    ]
+    open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))
+    tpath = os.path.join(dst, "traffic.json")
+    try:
+        traffic = json.load(open(tpath))
+    except (OSError, ValueError):
+        traffic = {}
+    traffic[bench["config"]["kernel"]] = total
+    traffic[label] = total
+    traffic["_source"] = f"profiles/{tag}_summary.md"
+    json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
