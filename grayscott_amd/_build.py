@@ -25,6 +25,8 @@ ARCH = "gfx950"
 
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
           "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# Experiment hook (tools/sweep runs): extra hipcc flags for the kernel translation units.
+EXTRA = os.environ.get("GS_HIP_EXTRA_FLAGS", "").split()
 
 UNITS = [
     # (source, object, extra flags)
@@ -65,7 +67,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cc = hipcc()
     procs = []
     for src, obj, extra in UNITS:
-        flags = list(COMMON)
+        flags = list(COMMON) + (EXTRA if src.endswith(".hip") else [])
         cmd = [cc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(BUILD, obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

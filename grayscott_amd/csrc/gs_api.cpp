@@ -149,7 +149,7 @@ struct gs_ctx {
 };
 
 struct FieldSlab {
-    float *alloc = nullptr; // hipMalloc'ed block: guard | ghost | rows | ghost | guard
+    float *alloc = nullptr; // hipMalloc'ed block: guard | 4 ghost rows | rows | 4 ghost rows | guard
     float *row0 = nullptr;  // local row 0, column 0
     uint64_t g_row0 = 0;    // global index of local row 0
     int32_t rows = 0;
@@ -160,12 +160,13 @@ struct gs_field {
     uint64_t rows = 0, cols = 0;
     int32_t pitch = 0;
     std::vector<FieldSlab> s;
-    bool ghosts_dirty = true;
+    int ghost_depth = 0; // ghost rows currently holding the neighbours' data (0 = stale)
 };
 
 namespace {
 
 constexpr int kGuardFloats = 64; // 256 B in front of / behind every plane
+constexpr int kGhostRows = 4;    // ghost rows kept above and below every slab (= max fused steps)
 
 bool is_pow2_or_zero(float w)
 {
@@ -220,10 +221,10 @@ int32_t copy_row(gs_ctx *ctx, int src_slab, const float *src, int dst_slab, floa
     return GS_OK;
 }
 
-// Push the boundary rows of `planes` to the ghost rows of the neighbouring slabs, from
-// local slab i, on `stream`.  Rows travel whole (pitch floats) so U and V need one message
-// each per direction.
-int32_t push_halo(gs_ctx *ctx, gs_field *const *planes, int nplanes, int i, hipStream_t stream)
+// Push the `depth` boundary rows of `planes` to the ghost rows of the neighbouring slabs,
+// from local slab i, on `stream`.  Rows travel whole (pitch floats) and the `depth` rows of a
+// side are contiguous, so every plane needs one message per direction.
+int32_t push_halo(gs_ctx *ctx, gs_field *const *planes, int nplanes, int i, hipStream_t stream, int depth)
 {
     const int n_local = (int)ctx->slabs.size();
     const int k = ctx->global_index(i), S = ctx->total_slabs();
@@ -232,16 +233,15 @@ int32_t push_halo(gs_ctx *ctx, gs_field *const *planes, int nplanes, int i, hipS
     for (int f = 0; f < nplanes; ++f) {
         gs_field *pl = planes[f];
         const FieldSlab &me = pl->s[i];
-        const size_t bytes = (size_t)pl->cols * sizeof(float);
-        if (i > 0) { // my first row -> bottom ghost of the slab above
+        const size_t bytes = (size_t)depth * pl->pitch * sizeof(float);
+        if (i > 0) { // my first rows -> bottom ghost rows of the slab above
             const FieldSlab &nb = pl->s[i - 1];
-            GS_TRY(copy_row(ctx, i, me.row0, i - 1, nb.row0 + (ptrdiff_t)nb.rows * pl->pitch, bytes,
-                            stream));
+            GS_TRY(copy_row(ctx, i, me.row0, i - 1, nb.row0 + (ptrdiff_t)nb.rows * pl->pitch, bytes, stream));
         }
-        if (i < n_local - 1) { // my last row -> top ghost of the slab below
+        if (i < n_local - 1) { // my last rows -> top ghost rows of the slab below
             const FieldSlab &nb = pl->s[i + 1];
-            GS_TRY(copy_row(ctx, i, me.row0 + (ptrdiff_t)(me.rows - 1) * pl->pitch, i + 1,
-                            nb.row0 - pl->pitch, bytes, stream));
+            GS_TRY(copy_row(ctx, i, me.row0 + (ptrdiff_t)(me.rows - depth) * pl->pitch, i + 1,
+                            nb.row0 - (ptrdiff_t)depth * pl->pitch, bytes, stream));
         }
     }
     if (up_remote || down_remote) {
@@ -251,21 +251,29 @@ int32_t push_halo(gs_ctx *ctx, gs_field *const *planes, int nplanes, int i, hipS
         for (int f = 0; f < nplanes; ++f) {
             gs_field *pl = planes[f];
             const FieldSlab &me = pl->s[i];
-            const size_t n = (size_t)pl->cols;
+            const size_t n = (size_t)depth * pl->pitch;
             if (up_remote) {
                 GS_NCCL(R, R->Send(me.row0, n, ncclFloat, ctx->rank - 1, ctx->comm, stream));
-                GS_NCCL(R, R->Recv(me.row0 - pl->pitch, n, ncclFloat, ctx->rank - 1, ctx->comm, stream));
+                GS_NCCL(R, R->Recv(me.row0 - (ptrdiff_t)depth * pl->pitch, n, ncclFloat, ctx->rank - 1, ctx->comm,
+                                   stream));
             }
             if (down_remote) {
-                GS_NCCL(R, R->Send(me.row0 + (ptrdiff_t)(me.rows - 1) * pl->pitch, n, ncclFloat,
-                                   ctx->rank + 1, ctx->comm, stream));
-                GS_NCCL(R, R->Recv(me.row0 + (ptrdiff_t)me.rows * pl->pitch, n, ncclFloat, ctx->rank + 1,
+                GS_NCCL(R, R->Send(me.row0 + (ptrdiff_t)(me.rows - depth) * pl->pitch, n, ncclFloat, ctx->rank + 1,
                                    ctx->comm, stream));
+                GS_NCCL(R, R->Recv(me.row0 + (ptrdiff_t)me.rows * pl->pitch, n, ncclFloat, ctx->rank + 1, ctx->comm,
+                                   stream));
             }
         }
         GS_NCCL(R, R->GroupEnd());
     }
     return GS_OK;
+}
+
+// Smallest slab of the row partition of `f` (every process computes the same value).
+int min_slab_rows(const gs_ctx *ctx, const gs_field *f)
+{
+    return (int)(f->rows / (uint64_t)ctx->total_slabs() < 0x7fffffffull ? f->rows / (uint64_t)ctx->total_slabs()
+                                                                          : 0x7fffffffull);
 }
 
 // Bring the ghost rows of one plane up to date (after fill / fill_slice / upload).
@@ -274,34 +282,44 @@ int32_t refresh_ghosts(gs_ctx *ctx, gs_field *f)
     if (ctx->total_slabs() > 1) {
         GS_TRY(sync_all(ctx));
         gs_field *planes[1] = {f};
+        const int depth = min_slab_rows(ctx, f) < kGhostRows ? min_slab_rows(ctx, f) : kGhostRows;
         for (int i = 0; i < (int)ctx->slabs.size(); ++i) {
             GS_HIP(hipSetDevice(ctx->slabs[i].device));
-            GS_TRY(push_halo(ctx, planes, 1, i, ctx->slabs[i].halo));
+            GS_TRY(push_halo(ctx, planes, 1, i, ctx->slabs[i].halo, depth));
         }
         GS_TRY(sync_all(ctx));
     }
-    f->ghosts_dirty = false;
+    f->ghost_depth = kGhostRows;
     return GS_OK;
 }
 
-int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols)
+// Rows each wave marches over.  Measured at 16384^2 (profiles/r01_sweeps.md): short units win --
+// 16 rows for single steps, 64 for 4 fused steps (redundant rows 2K/rpu vs tail effects).
+int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse)
 {
     if (ctx->o.rows_per_block > 0) return ctx->o.rows_per_block;
-    const long strips = (cols + 255) / 256;
-    long rpu = ((long)rows * strips + 8191) / 8192; // aim for >= 8192 waves in flight
-    if (rpu < 8) rpu = 8;
-    if (rpu > 32) rpu = 32;
+    const long strips = (cols + 247) / 248;
+    const long want = fuse > 1 ? 16L * fuse : 16;
+    long rpu = ((long)rows * strips + 16383) / 16384; // keep >= 16384 waves per launch when possible
+    if (rpu > want) rpu = want;
+    if (rpu < 2L * fuse) rpu = 2L * fuse;
+    if (rpu < 4) rpu = 4;
     return (int32_t)rpu;
 }
 
-int32_t launch_rows(gs_ctx *ctx, const GsStepArgs &a, hipStream_t stream)
+int32_t launch_rows(gs_ctx *ctx, const GsStepArgs &a, hipStream_t stream, int fuse = 1)
 {
     int32_t kernel = ctx->o.kernel;
-    if (kernel == GS_KERNEL_AUTO) kernel = GS_KERNEL_STREAM;
+    if (kernel == GS_KERNEL_AUTO) kernel = fuse > 1 ? GS_KERNEL_TB : GS_KERNEL_STREAM;
+    if (fuse > 1 && kernel != GS_KERNEL_TB)
+        return fail(GS_ERR_UNSUPPORTED, "only the temporally blocked kernel fuses steps");
     const bool fused = ctx->o.math == GS_MATH_FUSED;
     const char *name = nullptr;
     hipError_t e;
     switch (kernel) {
+    case GS_KERNEL_TB:
+        e = fused ? gs_launch_tb_fused(a, fuse, stream, &name) : gs_launch_tb_strict(a, fuse, stream, &name);
+        break;
     case GS_KERNEL_SIMPLE:
         e = fused ? gs_launch_simple_fused(a, stream, &name) : gs_launch_simple_strict(a, stream, &name);
         break;
@@ -318,7 +336,7 @@ int32_t launch_rows(gs_ctx *ctx, const GsStepArgs &a, hipStream_t stream)
 }
 
 GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in_v,
-                     const gs_field *out_u, const gs_field *out_v, int i)
+                     const gs_field *out_u, const gs_field *out_v, int i, int fuse)
 {
     GsStepArgs a;
     std::memset(&a, 0, sizeof a);
@@ -332,7 +350,8 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
     const int k = ctx->global_index(i);
     a.top_present = k > 0;
     a.bottom_present = k < ctx->total_slabs() - 1;
-    a.rows_per_unit = pick_rows_per_unit(ctx, a.rows, a.cols);
+    a.ghost = kGhostRows;
+    a.rows_per_unit = pick_rows_per_unit(ctx, a.rows, a.cols, fuse);
     std::memcpy(a.w, ctx->p.w, sizeof a.w);
     a.du = ctx->p.du;
     a.dv = ctx->p.dv;
@@ -344,50 +363,61 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
     return a;
 }
 
-int32_t step_impl(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs_field *out_v)
+// Advances the state by `fuse` time steps with ONE pass over the planes.  On a chain of slabs
+// the ghost rows are `fuse` deep for that pass: the boundary kernel updates the first and last
+// `fuse` rows, which are then pushed to the neighbours while the interior kernel runs.
+int32_t step_impl(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs_field *out_v,
+                  int fuse = 1)
 {
     const int n_local = (int)ctx->slabs.size();
     const int S = ctx->total_slabs();
     if (S == 1) {
         SlabRt &sl = ctx->slabs[0];
         GS_HIP(hipSetDevice(sl.device));
-        GsStepArgs a = make_args(ctx, in_u, in_v, out_u, out_v, 0);
+        GsStepArgs a = make_args(ctx, in_u, in_v, out_u, out_v, 0, fuse);
         a.ra0 = 0;
         a.ra1 = a.rows;
-        GS_TRY(launch_rows(ctx, a, sl.compute));
+        GS_TRY(launch_rows(ctx, a, sl.compute, fuse));
     } else {
+        if (fuse > kGhostRows || fuse > min_slab_rows(ctx, in_u))
+            return fail(GS_ERR_INVALID, "cannot fuse %d steps over slabs of %d rows", fuse, min_slab_rows(ctx, in_u));
+        // The input planes need `fuse` valid ghost rows (after fill / upload, or after a pass that
+        // fused fewer steps, they are refreshed from the neighbours first: a blocking exchange).
+        if (in_u->ghost_depth < fuse) GS_TRY(refresh_ghosts(ctx, in_u));
+        if (in_v->ghost_depth < fuse) GS_TRY(refresh_ghosts(ctx, in_v));
         const int p = (int)(ctx->step_no & 1), q = p ^ 1;
         gs_field *outs[2] = {out_u, out_v};
         for (int i = 0; i < n_local; ++i) {
             SlabRt &sl = ctx->slabs[i];
             GS_HIP(hipSetDevice(sl.device));
-            GsStepArgs a = make_args(ctx, in_u, in_v, out_u, out_v, i);
+            GsStepArgs a = make_args(ctx, in_u, in_v, out_u, out_v, i, fuse);
+            const int n = a.rows;
             // halo stream: boundary rows, then the exchange
             GS_HIP(hipStreamWaitEvent(sl.halo, sl.done[q], 0));
             if (i > 0) GS_HIP(hipStreamWaitEvent(sl.halo, ctx->slabs[i - 1].halod[q], 0));
             if (i < n_local - 1) GS_HIP(hipStreamWaitEvent(sl.halo, ctx->slabs[i + 1].halod[q], 0));
             GsStepArgs b = a;
             b.ra0 = 0;
-            b.ra1 = 1;
-            b.rb0 = a.rows > 1 ? a.rows - 1 : 0;
-            b.rb1 = a.rows > 1 ? a.rows : 0;
-            b.rows_per_unit = 1;
-            GS_TRY(launch_rows(ctx, b, sl.halo));
-            GS_TRY(push_halo(ctx, outs, 2, i, sl.halo));
+            b.ra1 = n <= 2 * fuse ? n : fuse;
+            b.rb0 = n <= 2 * fuse ? 0 : n - fuse;
+            b.rb1 = n <= 2 * fuse ? 0 : n;
+            b.rows_per_unit = fuse; // one unit per boundary band and strip
+            GS_TRY(launch_rows(ctx, b, sl.halo, fuse));
+            GS_TRY(push_halo(ctx, outs, 2, i, sl.halo, fuse));
             GS_HIP(hipEventRecord(sl.halod[p], sl.halo));
             // compute stream: interior rows
             GS_HIP(hipStreamWaitEvent(sl.compute, sl.halod[q], 0));
-            if (a.rows > 2) {
-                a.ra0 = 1;
-                a.ra1 = a.rows - 1;
-                GS_TRY(launch_rows(ctx, a, sl.compute));
+            if (n > 2 * fuse) {
+                a.ra0 = fuse;
+                a.ra1 = n - fuse;
+                GS_TRY(launch_rows(ctx, a, sl.compute, fuse));
             }
             GS_HIP(hipEventRecord(sl.done[p], sl.compute));
         }
     }
     ctx->step_no++;
-    out_u->ghosts_dirty = false;
-    out_v->ghosts_dirty = false;
+    out_u->ghost_depth = fuse;
+    out_v->ghost_depth = fuse;
     return GS_OK;
 }
 
@@ -400,8 +430,6 @@ int32_t check_step_fields(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field 
     GS_TRY(same_shape(in_u, out_v));
     if (in_u == out_u || in_v == out_v || in_u == in_v || out_u == out_v || in_u == out_v || in_v == out_u)
         return fail(GS_ERR_INVALID, "the four planes of a step must be distinct");
-    if (in_u->ghosts_dirty) GS_TRY(refresh_ghosts(ctx, in_u));
-    if (in_v->ghosts_dirty) GS_TRY(refresh_ghosts(ctx, in_v));
     return GS_OK;
 }
 
@@ -620,14 +648,14 @@ int32_t gs_field_create(gs_ctx *ctx, gs_field **out, uint64_t rows, uint64_t col
     for (size_t i = 0; i < ctx->slabs.size(); ++i) {
         const uint64_t k = (uint64_t)ctx->global_index((int)i);
         const uint64_t r0 = k * rows / S, r1 = (k + 1) * rows / S;
-        if (r1 - r0 > 0x7ffffff0ull || (r1 - r0 + 2) * pitch > 0x7ffffff0ull * 4ull) {
+        if (r1 - r0 > 0x7ffffff0ull || (r1 - r0 + 2 * kGhostRows) * pitch > 0x7ffffff0ull * 4ull) {
             gs_field_destroy(ctx, f);
             return fail(GS_ERR_UNSUPPORTED, "slab too large for 32-bit row indexing");
         }
         FieldSlab &fs = f->s[i];
         fs.g_row0 = r0;
         fs.rows = (int32_t)(r1 - r0);
-        const size_t n = (size_t)(fs.rows + 2) * pitch + 2 * kGuardFloats;
+        const size_t n = (size_t)(fs.rows + 2 * kGhostRows) * pitch + 2 * kGuardFloats;
         hipError_t e = hipSetDevice(ctx->slabs[i].device);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&fs.alloc), n * sizeof(float));
         // Concentration::default() is zero-filled in the reference (ndarray default); ghost
@@ -638,11 +666,11 @@ int32_t gs_field_create(gs_ctx *ctx, gs_field **out, uint64_t rows, uint64_t col
             return fail(e == hipErrorOutOfMemory ? GS_ERR_NOMEM : GS_ERR_HIP, "plane allocation failed: %s",
                         hipGetErrorString(e));
         }
-        fs.row0 = fs.alloc + kGuardFloats + pitch;
+        fs.row0 = fs.alloc + kGuardFloats + (size_t)kGhostRows * pitch;
     }
     int32_t st = sync_all(ctx);
     if (st != GS_OK) { gs_field_destroy(ctx, f); return st; }
-    f->ghosts_dirty = false; // all zeros, ghosts included
+    f->ghost_depth = kGhostRows; // all zeros, ghosts included
     *out = f;
     return GS_OK;
 }
@@ -667,7 +695,7 @@ int32_t gs_field_raw_shape(const gs_field *f, uint64_t *raw_rows, uint64_t *pitc
 {
     if (!f) return fail(GS_ERR_INVALID, "null field");
     uint64_t n = 0;
-    for (auto &fs : f->s) n += (uint64_t)fs.rows + 2;
+    for (auto &fs : f->s) n += (uint64_t)fs.rows + 2 * kGhostRows;
     if (raw_rows) *raw_rows = n;
     if (pitch) *pitch = (uint64_t)f->pitch;
     return GS_OK;
@@ -694,7 +722,7 @@ int32_t gs_field_fill_slice(gs_ctx *ctx, gs_field *f, uint64_t r0, uint64_t r1, 
         if (e != hipSuccess) return fail(GS_ERR_HIP, "fill launch failed: %s", hipGetErrorString(e));
     }
     GS_TRY(sync_all(ctx));
-    f->ghosts_dirty = true;
+    f->ghost_depth = 0;
     return GS_OK;
 }
 
@@ -707,7 +735,7 @@ int32_t gs_field_fill(gs_ctx *ctx, gs_field *f, float value)
 int32_t gs_field_finalize(gs_ctx *ctx, gs_field *f)
 {
     if (!ctx || !f || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad handle");
-    if (f->ghosts_dirty) GS_TRY(refresh_ghosts(ctx, f));
+    if (f->ghost_depth == 0) GS_TRY(refresh_ghosts(ctx, f)); // deeper needs are met lazily by gs_step / gs_run
     return GS_OK;
 }
 
@@ -723,7 +751,7 @@ int32_t gs_field_upload(gs_ctx *ctx, gs_field *f, const float *host)
                            (size_t)f->cols * sizeof(float), (size_t)f->cols * sizeof(float), (size_t)fs.rows,
                            hipMemcpyHostToDevice));
     }
-    f->ghosts_dirty = true;
+    f->ghost_depth = 0;
     return GS_OK;
 }
 
@@ -766,9 +794,22 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     GS_TRY(check_step_fields(ctx, u0, v0, u1, v1));
     gs_field *u[2] = {u0, u1}, *v[2] = {v0, v1};
     int in = 0;
-    for (uint64_t n = 0; n < steps; ++n) {
-        GS_TRY(step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in]));
+    // Temporal blocking: `fuse` steps per pass over HBM (default 4, the measured optimum);
+    // bounded by the ghost depth and by the smallest slab of the partition.
+    int fuse = 1;
+    if (ctx->o.kernel == GS_KERNEL_AUTO || ctx->o.kernel == GS_KERNEL_TB) {
+        fuse = ctx->o.fuse_steps > 0 ? ctx->o.fuse_steps : kGhostRows;
+        if (fuse > kGhostRows) fuse = kGhostRows;
+        if (ctx->total_slabs() > 1 && fuse > min_slab_rows(ctx, u0)) fuse = min_slab_rows(ctx, u0);
+        if (fuse < 1) fuse = 1;
+    }
+    // The short pass (steps % fuse) goes first so that a run ends on a full-depth ghost exchange
+    // and the next run can start without a blocking refresh.
+    for (uint64_t n = 0; n < steps;) {
+        const int k = (n == 0 && steps % (uint64_t)fuse) ? (int)(steps % (uint64_t)fuse) : fuse;
+        GS_TRY(step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], k));
         in = 1 - in;
+        n += (uint64_t)k;
     }
     if (result_slot) *result_slot = in;
     return GS_OK;

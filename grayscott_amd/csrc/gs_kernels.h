@@ -1,7 +1,7 @@
 // gs_kernels.h -- host/device contract between gs_api.cpp and the gfx950 kernels.
 //
 // One "plane" is a row-major f32 array of one species in one slot for one row slab:
-//   element (r, c) of the slab, r in [-1, rows] (row -1 / row `rows` = ghost rows),
+//   element (r, c) of the slab, r in [-ghost, rows + ghost) (rows outside [0, rows) = ghost rows),
 //   c in [0, pitch), lives at  base + r * pitch + c ;  pitch % 64 == 0 (256-B rows).
 // Columns [cols, pitch) are padding: readable, writable, never used as neighbours.
 #pragma once
@@ -19,7 +19,8 @@ struct GsStepArgs {
     // 1 when the ghost row above / below holds a neighbouring slab's row (slab seam),
     // 0 when that side is a global edge (naive's clipped window applies there).
     int32_t top_present, bottom_present;
-    int32_t rows_per_unit; // rows one wave marches over (stream kernel)
+    int32_t ghost;         // ghost rows stored above / below the slab (>= fused steps on seams)
+    int32_t rows_per_unit; // rows one wave marches over
     float w[3][3];         // stencil weights, row-major (parameters.rs:87-88)
     float du, dv, feed, feed_plus_kill, dt;
 };
@@ -28,7 +29,8 @@ struct GsStepArgs {
 // returns the hipError_t of the launch.  `name` receives a static kernel-variant label.
 #define GS_DECLARE_LAUNCHERS(SUFFIX)                                                           \
     hipError_t gs_launch_simple_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name); \
-    hipError_t gs_launch_stream_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name);
+    hipError_t gs_launch_stream_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name); \
+    hipError_t gs_launch_tb_##SUFFIX(const GsStepArgs &a, int k, hipStream_t s, const char **name);
 
 GS_DECLARE_LAUNCHERS(strict)
 GS_DECLARE_LAUNCHERS(fused)

@@ -278,7 +278,9 @@ template <int G>
 __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_stream_k)(GsStepArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // readfirstlane tells the compiler the wave index is wave-uniform: everything derived
+    // from it (unit, row range, edge flags) then lives in SGPRs and branches are scalar.
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int strips = (a.cols + 255) >> 8;
     const int unit = blockIdx.x * 4 + wave;
     const int chunk = unit / strips;
@@ -305,6 +307,159 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_stream_k)(GsStepArgs a)
         march<G, true>(a, ur0, ur1, c0, lane);
     else
         march<G, false>(a, ur0, ur1, c0, lane);
+}
+
+// ------------------------------------------------------------------------------------
+// Temporal blocking: K time steps per launch (one HBM read + one HBM write per K steps).
+//
+// Same per-cell arithmetic, so the results are bit-identical to K single-step launches.
+// A wave loads a 256-column window [248*s - 4, 248*s + 252) of its strip and marches down
+// the rows with a software pipeline of K time levels, each keeping a 3-row window in
+// registers: per "tick" it takes one new level-0 row from the prefetch queue, computes one
+// row of level 1 from the level-0 window, one row of level 2 from the level-1 window, ...
+// and stores one row of level K.  Lanes 0 and 63 are sacrificial: their outermost columns
+// lose one column of validity per level (no neighbour to read), so after K <= 4 levels
+// lanes 1..62 (248 columns) still hold exact values.  No halo loads, no LDS, no barriers;
+// redundant work is 8/256 of the columns plus 2K rows per unit.
+//   HBM traffic per launch ~ 16 B per cell (+ ~3 % column overlap, + 2K/rows_per_unit rows),
+//   algorithmic traffic 16 B * K per cell: the kernel moves from HBM-bound (K = 1, 2)
+//   towards VALU-bound (K = 4).
+// ------------------------------------------------------------------------------------
+constexpr int kTbCols = 248; // output columns per wave
+
+// Measured on MI355X while tuning this kernel (tools/ubench/valu_rate.hip, sweeps under
+// profiles/): packed v_pk_{add,mul}_f32 have the same lane throughput as scalar VALU ops
+// (so (u,v)-pair arithmetic buys nothing), DPP moves cost ~1.5 scalar ops (so neighbour
+// columns are fetched once per row and kept, not re-read at each use), v_cndmask is ~8x a
+// scalar op (kept out of the interior path), and 2 or 4 waves per SIMD issue at full rate
+// while 3 do not.  The kernel is VALU-issue bound for K >= 3.
+struct RowQ { // a level-0 row as fetched (no halo columns: sacrificial lanes instead)
+    float4 u, v;
+};
+
+__device__ __forceinline__ RowW widen_tb(const float4 &u, const float4 &v)
+{
+    RowW w;
+    w.u[1] = u.x; w.u[2] = u.y; w.u[3] = u.z; w.u[4] = u.w;
+    w.v[1] = v.x; w.v[2] = v.y; w.v[3] = v.z; w.v[4] = v.w;
+    w.u[0] = from_prev_lane(u.w, u.w); // lanes 0 / 63 keep a don't-care value
+    w.u[5] = from_next_lane(u.x, u.x);
+    w.v[0] = from_prev_lane(v.w, v.w);
+    w.v[5] = from_next_lane(v.x, v.x);
+    return w;
+}
+
+template <int K, bool EDGE>
+__device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, int strip, int lane)
+{
+    const int c = strip * kTbCols - 4 + lane * 4; // first column of this lane (may be -4)
+    const bool load_ok = !EDGE || (c >= 0 && c < a.pitch);
+    const bool store_ok = (lane >= 1) && (lane <= 62) && (!EDGE || c < a.pitch);
+    const ptrdiff_t pitch = a.pitch;
+    const float *bu = a.in_u + c, *bv = a.in_v + c;
+
+    // Level-0 rows needed: [ur0 - K, ur1 + K) clipped to the rows that exist: the slab's own
+    // rows plus, on a slab seam, `ghost` rows of the neighbouring slab.
+    const int row_lo = max(ur0 - K, a.top_present ? -a.ghost : 0);
+    const int row_hi = min(ur1 + K - 1, a.bottom_present ? a.rows + a.ghost - 1 : a.rows - 1);
+    auto fetch = [&](int row) {
+        RowQ r;
+        const int rr = min(max(row, row_lo), row_hi);
+        if (load_ok) {
+            r.u = *reinterpret_cast<const float4 *>(bu + (ptrdiff_t)rr * pitch);
+            r.v = *reinterpret_cast<const float4 *>(bv + (ptrdiff_t)rr * pitch);
+        } else {
+            r.u = make_float4(0.f, 0.f, 0.f, 0.f);
+            r.v = r.u;
+        }
+        return r;
+    };
+
+    bool la[4], ra[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        la[k] = EDGE && (c + k == 0);
+        ra[k] = EDGE && (c + k + 1 >= a.cols);
+    }
+
+    RowW w[K][3]; // w[j][slot]: level-j rows, newest in slot (tick % 3)
+    RowQ q[3];    // prefetch queue of level-0 rows, 3 ticks deep
+    const int first = ur0 - K; // level-0 row of tick 0
+    const int nticks = (ur1 - ur0) + 2 * K;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) q[i] = fetch(first + i);
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+            for (int e = 0; e < 6; ++e) { w[j][sl].u[e] = 0.f; w[j][sl].v[e] = 0.f; }
+
+    for (int t = 0; t < nticks; t += 3) {
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int tick = t + s3;
+            if (tick < nticks) {
+                const int l0 = first + tick; // level-0 row entering the pipeline
+                w[0][s3] = widen_tb(q[s3].u, q[s3].v);
+                q[s3] = fetch(l0 + 3);
+#pragma unroll
+                for (int j = 1; j <= K; ++j) {
+                    const int row = l0 - j; // level-j row produced in this tick
+                    // needed for this unit's outputs, and a row of the global grid?
+                    const bool need = (row >= ur0 - (K - j)) && (row < ur1 + (K - j)) &&
+                                      (!EDGE || ((row >= 0 || a.top_present) && (row < a.rows || a.bottom_present)));
+                    if (need) {
+                        const RowW &m = w[j - 1][(s3 + 1) % 3]; // row - 1
+                        const RowW &z = w[j - 1][(s3 + 2) % 3]; // row
+                        const RowW &p = w[j - 1][s3];           // row + 1
+                        const bool mrow = !EDGE || (row > 0) || a.top_present;
+                        const bool prow = !EDGE || (row + 1 < a.rows) || a.bottom_present;
+                        float4 nu, nv;
+                        cell<EDGE>(a, m, z, p, 1, mrow, prow, la[0], ra[0], nu.x, nv.x);
+                        cell<EDGE>(a, m, z, p, 2, mrow, prow, la[1], ra[1], nu.y, nv.y);
+                        cell<EDGE>(a, m, z, p, 3, mrow, prow, la[2], ra[2], nu.z, nv.z);
+                        cell<EDGE>(a, m, z, p, 4, mrow, prow, la[3], ra[3], nu.w, nv.w);
+                        if (j < K) {
+                            w[j < K ? j : 0][s3] = widen_tb(nu, nv);
+                        } else if (store_ok) {
+                            *reinterpret_cast<float4 *>(a.out_u + (ptrdiff_t)row * pitch + c) = nu;
+                            *reinterpret_cast<float4 *>(a.out_v + (ptrdiff_t)row * pitch + c) = nv;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, see above
+    const int strips = (a.cols + kTbCols - 1) / kTbCols;
+    const int unit = blockIdx.x * 4 + wave;
+    const int chunk = unit / strips;
+    const int strip = unit - chunk * strips;
+    const int rpu = a.rows_per_unit;
+    const int chunks_a = (a.ra1 - a.ra0 + rpu - 1) / rpu;
+    const int chunks_b = (a.rb1 - a.rb0 + rpu - 1) / rpu;
+    if (chunk >= chunks_a + chunks_b) return; // wave-uniform
+    int ur0, ur1;
+    if (chunk < chunks_a) {
+        ur0 = a.ra0 + chunk * rpu;
+        ur1 = min(ur0 + rpu, a.ra1);
+    } else {
+        ur0 = a.rb0 + (chunk - chunks_a) * rpu;
+        ur1 = min(ur0 + rpu, a.rb1);
+    }
+    const bool edge = (strip == 0) || ((strip + 1) * kTbCols + 4 >= a.cols) ||
+                      (ur0 - K < 0 && !a.top_present) || (ur1 + K > a.rows && !a.bottom_present);
+    if (edge)
+        tb_march<K, true>(a, ur0, ur1, strip, lane);
+    else
+        tb_march<K, false>(a, ur0, ur1, strip, lane);
 }
 
 } // namespace
@@ -337,4 +492,30 @@ hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const
     void *kargs[] = {&args};
     return hipLaunchKernel(reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_stream_k)<2>),
                            dim3((unsigned)blocks), dim3(256), kargs, 0, s);
+}
+
+// K fused steps over the row ranges of GsStepArgs; on slab seams the ghost rows must be K deep.
+hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, const char **name)
+{
+    static const char *const names[4] = {"tb-k1/" GS_MATH_NAME, "tb-k2/" GS_MATH_NAME,
+                                         "tb-k3/" GS_MATH_NAME, "tb-k4/" GS_MATH_NAME};
+    if (k < 1 || k > 4 || a.cols <= 0 || a.rows_per_unit <= 0) return hipErrorInvalidValue;
+    if (name) *name = names[k - 1];
+    const long rpu = a.rows_per_unit;
+    const long chunks = ((long)(a.ra1 - a.ra0) + rpu - 1) / rpu + ((long)(a.rb1 - a.rb0) + rpu - 1) / rpu;
+    if (chunks <= 0) return hipSuccess;
+    if (k > a.ghost && (a.top_present || a.bottom_present)) return hipErrorInvalidValue;
+    const long strips = (a.cols + kTbCols - 1) / kTbCols;
+    const long blocks = (chunks * strips + 3) / 4;
+    if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
+    GsStepArgs args = a;
+    void *kargs[] = {&args};
+    const void *fn = nullptr;
+    switch (k) {
+    case 1: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<1>); break;
+    case 2: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<2>); break;
+    case 3: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<3>); break;
+    default: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4>); break;
+    }
+    return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), kargs, 0, s);
 }

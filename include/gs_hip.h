@@ -87,7 +87,7 @@ typedef enum gs_kernel {
     GS_KERNEL_AUTO = 0,    /* best measured variant for the shape                          */
     GS_KERNEL_SIMPLE = 1,  /* one thread per cell, global loads only (cross-check kernel)  */
     GS_KERNEL_STREAM = 2,  /* register sliding window, 16-B loads, DPP halo exchange       */
-    GS_KERNEL_LDS = 3      /* LDS-staged (tile + halo) window, multi-step capable          */
+    GS_KERNEL_TB = 3       /* temporally blocked streaming kernel: fuse_steps steps / launch */
 } gs_kernel;
 
 /* Backend options: the C view of the Rust `CliArgs` (compute/shared/src/lib.rs:20-25 --
@@ -96,7 +96,7 @@ typedef struct gs_options {
     int32_t math;            /* gs_math; default STRICT                                    */
     int32_t kernel;          /* gs_kernel; default AUTO                                    */
     int32_t rows_per_block;  /* rows each wave marches over (0 = auto)                     */
-    int32_t fuse_steps;      /* steps fused per launch in gs_run where supported (0 = auto)*/
+    int32_t fuse_steps;      /* steps fused per launch in gs_run (1..4; 0 = auto); single slab */
     int32_t use_graph;       /* 1 = replay gs_run batches through a hipGraph (0 = off)     */
     int32_t pitch_pad;       /* extra f32 of row pitch beyond the 64-float round-up        */
     int32_t reserved[10];

@@ -131,6 +131,49 @@ def test_fused_refuses_non_power_of_two_weights():
     assert e.value.code == capi.GS_ERR_UNSUPPORTED
 
 
+# ---- temporal blocking: K fused steps per launch are bit-identical to K single steps ---------
+@pytest.mark.parametrize("fuse", [1, 2, 3, 4])
+def test_temporal_blocking_bit_exact(fuse):
+    for shape in [(1, 1), (1, 7), (7, 1), (2, 2), (3, 5), (17, 33), (64, 128), (250, 130), (9, 247), (9, 248),
+                  (9, 249), (30, 252), (30, 253), (41, 500), (12, 1030)]:
+        u0, v0 = stress_fields(shape, 2)
+        for steps in (1, 4, 7):
+            ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True)
+            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(kernel=capi.GS_KERNEL_TB, fuse_steps=fuse,
+                                                                  rows_per_block=5))
+            assert info[0].startswith("tb-k"), info
+            assert_bits_equal(got_u, ref_u, f"TB{fuse} U {shape} steps {steps}")
+            assert_bits_equal(got_v, ref_v, f"TB{fuse} V {shape} steps {steps}")
+
+
+@pytest.mark.parametrize("fuse,math", [(2, 0), (4, 0), (4, 1)])
+def test_temporal_blocking_species_new_1000_steps(fuse, math):
+    g = np.load(os.path.join(GOLDEN, "species_new_64x128.npz"))
+    sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_TB, fuse_steps=fuse, math=math))
+    species = sim.make_species([64, 128])
+    sim.perform_steps(species, 1000)
+    in_u, in_v, _, _ = species.in_out()
+    got_u, got_v = in_u.make_scalar_view(sim.context), in_v.make_scalar_view(sim.context)
+    if math == 0:
+        assert_bits_equal(got_u, g["u_1000"], "TB U 1000")
+        assert_bits_equal(got_v, g["v_1000"], "TB V 1000")
+    else:
+        assert np.max(np.abs(got_u - g["u_1000"])) <= REL_TOL * np.max(np.abs(g["u_1000"]))
+        assert np.max(np.abs(got_v - g["v_1000"])) <= REL_TOL * np.max(np.abs(g["v_1000"]))
+
+
+def test_temporal_blocking_large_grid_vs_stream():
+    rows, cols, steps = 2048, 4096, 13  # 13 = 3 launches of 4 + 1 of 1
+    rng = np.random.default_rng(5)
+    u0 = rng.random((rows, cols), dtype=np.float32)
+    v0 = (rng.random((rows, cols), dtype=np.float32) * np.float32(0.5)).astype(np.float32)
+    ref = gpu_run(u0, v0, steps, args=args(kernel=capi.GS_KERNEL_STREAM))
+    for fuse in (2, 3, 4):
+        got = gpu_run(u0, v0, steps, args=args(kernel=capi.GS_KERNEL_TB, fuse_steps=fuse))
+        assert_bits_equal(got[0], ref[0], f"TB{fuse} vs stream U")
+        assert_bits_equal(got[1], ref[1], f"TB{fuse} vs stream V")
+
+
 # ---- non-default parameters (CLI overrides -k -f -t, ui/src/lib.rs:51-63) and weights ------
 @pytest.mark.parametrize("kernel", [capi.GS_KERNEL_SIMPLE, capi.GS_KERNEL_STREAM])
 def test_non_default_parameters(kernel):
@@ -153,7 +196,7 @@ def test_species_new_and_flip_contract():
     u0, v0 = oracle.init_species(64, 128)
     assert_bits_equal(in_u.make_scalar_view(sim.context), u0, "Species::new U")
     assert_bits_equal(in_v.make_scalar_view(sim.context), v0, "Species::new V")
-    assert in_u.raw_shape() == (66, 128)  # one slab: rows + 2 ghost rows, pitch 128
+    assert in_u.raw_shape() == (64 + 8, 128)  # one slab: rows + 2 x 4 ghost rows, pitch 128
     # perform_step + flip == perform_steps(1); results land in the input slot either way
     sim.perform_step(species)
     a = species.make_result_view()
@@ -211,7 +254,7 @@ def test_row_slabs_bit_identical_to_single(nslabs):
 def test_row_slabs_species_new_and_stepwise():
     sim = Simulation.new(Parameters(), args(devices=[0, 0, 0, 0]))
     species = sim.make_species([128, 256])
-    assert species.raw_shape() == (128 + 8, 256)
+    assert species.raw_shape() == (128 + 4 * 8, 256)
     for _ in range(30):
         sim.perform_step(species)
     sim.perform_steps(species, 31)
