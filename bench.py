@@ -38,13 +38,34 @@ def grid_for(n_gpus: int):
     return 16384 * n_gpus, 16384  # config 3 (N=1), config 4 shape (N=2), same cells per GPU
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU
+    box exposes 256 logical CPUs but grants a 16-CPU share per GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            text = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if text[0] != "max":
+                    n = min(n, max(1, int(int(text[0]) / int(text[1]))))
+            else:
+                quota = int(text[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(target_seconds: float = 15.0):
     """Times the CPU port (oracle/gs_cpu_parallel.c) of the reference's parallel backend on a
     bounded sample of the SAME workload: 16384 x 16384, Species::new init, a few steps."""
     from oracle import cpu_parallel
 
     rows, cols = 16384, 16384
-    threads = os.cpu_count() or 1
+    threads = usable_cpus()
     sim = cpu_parallel.ParallelSimulation(rows, cols, num_threads=threads, ftz=True)
     sim.perform_steps(1)                                  # touch pages / warm the thread team
     t0 = time.perf_counter()
@@ -135,10 +156,12 @@ def main() -> int:
     ctx.sync()
     barrier()
     torch.cuda.synchronize()
+    _, launches0 = ctx.info()
     t0 = time.perf_counter()
     ctx.timer_start()                               # HIP events on the library's own stream
     sim.perform_steps(species, args.steps)
     event_ms = ctx.timer_stop()
+    _, launches1 = ctx.info()
     ctx.sync()
     torch.cuda.synchronize()
     barrier()
@@ -153,9 +176,12 @@ def main() -> int:
     cells = rows * cols
     value = cells * args.steps / wall / 1e6
     # roofline of the dominant kernel: algorithmic bytes per launch / average launch duration.
-    # One launch = one time step of one GPU's slab (cells / N cells).
-    launch_ms = event_ms / args.steps
-    per_launch_bytes = BYTES_PER_CELL_STEP * cells / args.gpus
+    # One pass = one launch of the step kernel over one GPU's slab (plus, on a slab chain, the
+    # small boundary-band launch); it advances `steps / passes` time steps (temporal blocking).
+    launches = launches1 - launches0
+    passes = launches if args.gpus == 1 else launches // 2
+    launch_ms = event_ms / passes
+    per_launch_bytes = BYTES_PER_CELL_STEP * (cells / args.gpus) * args.steps / passes
     achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9
     result = {
         "metric": "Mcells×steps/s, 16384² f32 grid per GPU (Gray-Scott step, naive-rule parity)",
@@ -186,6 +212,8 @@ def main() -> int:
             "frac": achieved / HBM_PEAK_GBS,
             "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
             "launch_ms": launch_ms,
+            "launches": passes,
+            "steps_per_launch": args.steps / passes,
             "algorithmic_bytes_per_launch": per_launch_bytes,
             "traffic": measured_traffic(kernel_name),
         },

@@ -294,12 +294,12 @@ int32_t refresh_ghosts(gs_ctx *ctx, gs_field *f)
 }
 
 // Rows each wave marches over.  Measured at 16384^2 (profiles/r01_sweeps.md): short units win --
-// 16 rows for single steps, 64 for 4 fused steps (redundant rows 2K/rpu vs tail effects).
+// 16 rows for single steps, 32 for 4 fused steps (redundant rows 2K/rpu vs tail effects).
 int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse)
 {
     if (ctx->o.rows_per_block > 0) return ctx->o.rows_per_block;
     const long strips = (cols + 247) / 248;
-    const long want = fuse > 1 ? 16L * fuse : 16;
+    const long want = fuse > 1 ? 8L * fuse : 16;
     long rpu = ((long)rows * strips + 16383) / 16384; // keep >= 16384 waves per launch when possible
     if (rpu > want) rpu = want;
     if (rpu < 2L * fuse) rpu = 2L * fuse;

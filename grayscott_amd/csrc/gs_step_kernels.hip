@@ -448,7 +448,11 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     if (chunk >= chunks_a + chunks_b) return; // wave-uniform
     int ur0, ur1;
     if (chunk < chunks_a) {
-        ur0 = a.ra0 + chunk * rpu;
+        // Dispatch order: the last chunk of the range first, then chunks 0, 1, 2, ...  The first
+        // and last chunks touch the global top/bottom edge and take the slower general path;
+        // starting them first keeps them out of the launch's tail.
+        const int cc = chunk == 0 ? chunks_a - 1 : chunk - 1;
+        ur0 = a.ra0 + cc * rpu;
         ur1 = min(ur0 + rpu, a.ra1);
     } else {
         ur0 = a.rb0 + (chunk - chunks_a) * rpu;

@@ -32,9 +32,11 @@ def counter_values(path, needle, counter):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    needle = sys.argv[2] if len(sys.argv) > 2 else "gs_step_stream_k"
     label = sys.argv[3] if len(sys.argv) > 3 else "default"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    bench0 = json.loads(open(os.path.join(src, "bench_stats.json")).read().strip().splitlines()[-1])
+    auto = "gs_step_tb_k" if bench0["config"]["kernel"].startswith("tb-") else "gs_step_stream_k"
+    needle = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "auto" else auto
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     stats = os.path.join(src, "stats", "bench_kernel_stats.csv")
@@ -69,7 +71,8 @@ def main():
         "",
         f"* average duration under the profiler: **{avg_ms:.4f} ms**; `bench.py`'s own HIP-event figure in the same run: "
         f"{bench['roofline']['launch_ms']:.4f} ms (un-profiled runs are faster: profiling lowers clocks)",
-        f"* algorithmic bytes: {algo/2**30:.3f} GiB (16 B x {bench['config']['cells_per_gpu']} cells x steps per launch)",
+        f"* algorithmic bytes: {algo/2**30:.3f} GiB (16 B x {bench['config']['cells_per_gpu']} cells x "
+        f"{bench['roofline'].get('steps_per_launch', 1):g} steps per launch)",
         f"* FETCH_SIZE median {fetch_kib:.0f} KiB -> reads = 2 x FETCH_SIZE = **{read_bytes/2**30:.3f} GiB** (gfx950 half-count correction)",
         f"* WRITE_SIZE median {write_kib:.0f} KiB -> writes = **{write_bytes/2**30:.3f} GiB**",
         f"* HBM traffic = **{total/2**30:.3f} GiB = {total/algo:.3f} x algorithmic**",
