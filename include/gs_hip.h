@@ -31,12 +31,12 @@
  * Domain decomposition
  *   A context owns `n_local` row slabs (one per entry of device_ids; ids may repeat) which
  *   together cover the rows of this process; `world` processes (one per GPU when launched
- *   under torchrun) cover the global grid in rank order.  Slabs keep one ghost row above
- *   and below; after every step the ghost rows of the freshly written planes are refreshed
- *   from the neighbouring slab: by a device-to-device copy inside a process, by RCCL
- *   ncclSend/ncclRecv between processes, on a side stream overlapped with the interior
- *   update.  The reference has no multi-device code; its in-process precedent is
- *   SimulateCpu::split_grid (compute/shared/src/cpu.rs:111-154).
+ *   under torchrun) cover the global grid in rank order.  Slabs keep 4 ghost rows above and
+ *   below; a pass that fuses K <= 4 time steps updates the K boundary rows of each side
+ *   first and pushes them to the neighbouring slab's ghost rows -- by a device-to-device copy
+ *   inside a process, by RCCL ncclSend/ncclRecv between processes -- on a side stream,
+ *   overlapped with the interior update.  The reference has no multi-device code; its
+ *   in-process precedent is SimulateCpu::split_grid (compute/shared/src/cpu.rs:111-154).
  */
 #ifndef GS_HIP_H
 #define GS_HIP_H
@@ -82,7 +82,8 @@ typedef struct gs_params {
  *                   (GS_ERR_UNSUPPORTED) for weights that are not 0 or a power of two.    */
 typedef enum gs_math { GS_MATH_STRICT = 0, GS_MATH_FUSED = 1 } gs_math;
 
-/* Which step kernel gs_step launches. */
+/* Which step kernel runs.  AUTO = STREAM for a single gs_step, TB with fuse_steps (default 4)
+ * inside gs_run. */
 typedef enum gs_kernel {
     GS_KERNEL_AUTO = 0,    /* best measured variant for the shape                          */
     GS_KERNEL_SIMPLE = 1,  /* one thread per cell, global loads only (cross-check kernel)  */
@@ -134,7 +135,8 @@ int32_t gs_field_destroy(gs_ctx *ctx, gs_field *f);
 int32_t gs_field_shape(const gs_field *f, uint64_t *rows, uint64_t *cols);
 /* Rows [row0, row1) of the global grid that this process stores. */
 int32_t gs_field_local_rows(const gs_field *f, uint64_t *row0, uint64_t *row1);
-/* Concentration::raw_shape (mod.rs:223-228): local rows incl. ghost rows, row pitch in f32. */
+/* Concentration::raw_shape (mod.rs:223-228): local rows incl. 2 x 4 ghost rows per slab, row
+ * pitch in f32. */
 int32_t gs_field_raw_shape(const gs_field *f, uint64_t *raw_rows, uint64_t *pitch);
 
 int32_t gs_field_fill(gs_ctx *ctx, gs_field *f, float value);

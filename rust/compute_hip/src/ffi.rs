@@ -77,5 +77,14 @@ extern "C" {
         out_u: *mut gs_field,
         out_v: *mut gs_field,
     ) -> i32;
+    pub fn gs_run(
+        ctx: *mut gs_ctx,
+        u0: *mut gs_field,
+        v0: *mut gs_field,
+        u1: *mut gs_field,
+        v1: *mut gs_field,
+        steps: u64,
+        result_slot: *mut i32,
+    ) -> i32;
     pub fn gs_sync(ctx: *mut gs_ctx) -> i32;
 }

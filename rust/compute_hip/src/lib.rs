@@ -1,9 +1,9 @@
 //! MI355X (gfx950) HIP implementation of Gray-Scott simulation
 //!
 //! Thin shim over libgs_hip.so (hand-written HIP kernels behind a C ABI).  Storage lives in
-//! HBM as plain row-major f32 planes; `perform_steps` enqueues all steps asynchronously and
-//! flips the Rust-side handles per step, like the Vulkan backends re-derive their descriptor
-//! set per step (compute/gpu/naive/src/lib.rs:117-124).  Results match `compute_naive` bit
+//! HBM as plain row-major f32 planes; `perform_steps` enqueues all steps asynchronously with
+//! one `gs_run` call (the Vulkan backends batch the same way: one command buffer for N steps,
+//! compute/gpu/naive/src/lib.rs:99-131).  Results match `compute_naive` bit
 //! for bit (clipped-window boundary rule, FTZ-without-DAZ denormal handling).
 
 mod ffi;
@@ -203,12 +203,30 @@ impl SimulateCreate for Simulation {
 //
 impl Simulate for Simulation {
     fn perform_steps(&self, species: &mut Species<HipConcentration>, steps: usize) -> Result<(), HipError> {
-        for _ in 0..steps {
+        // One call enqueues every step: the library ping-pongs between the two slots and fuses up
+        // to 4 time steps per pass over HBM (temporal blocking); nothing blocks here.
+        let mut slot = 0i32;
+        {
             let (in_u, in_v, out_u, out_v) = species.in_out();
-            // asynchronous: only enqueues the kernel(s) of this step
-            check(unsafe { ffi::gs_step(self.context.0, in_u.field, in_v.field, out_u.field, out_v.field) })?;
-            species.flip()?; // finalize() is a no-op on freshly stepped planes
+            check(unsafe {
+                ffi::gs_run(self.context.0, in_u.field, in_v.field, out_u.field, out_v.field, steps as u64, &mut slot)
+            })?;
+        }
+        // "At the end of the simulation, the input concentrations of `species` will contain the
+        // final simulation results" (compute/shared/src/lib.rs:51-52): if the newest state sits
+        // in the output slot, swap the Rust-side handles (finalize() is a no-op on stepped planes).
+        if slot == 1 {
+            species.flip()?;
         }
         Ok(())
+    }
+}
+
+impl Simulation {
+    /// `SimulateStep`-style single step (compute/shared/src/cpu.rs:21-28): enqueue, then flip
+    pub fn perform_step(&self, species: &mut Species<HipConcentration>) -> Result<(), HipError> {
+        let (in_u, in_v, out_u, out_v) = species.in_out();
+        check(unsafe { ffi::gs_step(self.context.0, in_u.field, in_v.field, out_u.field, out_v.field) })?;
+        species.flip()
     }
 }
