@@ -15,7 +15,8 @@ from .simulation import (  # noqa: F401
     Parameters,
     Simulation,
     Species,
+    pinned_empty,
 )
 
 __all__ = ["capi", "GsError", "Evolving", "HipArgs", "HipConcentration", "HipContext",
-           "Parameters", "Simulation", "Species"]
+           "Parameters", "Simulation", "Species", "pinned_empty"]

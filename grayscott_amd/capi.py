@@ -32,6 +32,7 @@ EXPORTS = (
     "gs_field_local_rows", "gs_field_raw_shape", "gs_field_fill", "gs_field_fill_slice",
     "gs_field_finalize", "gs_field_upload", "gs_field_download", "gs_field_device_ptr",
     "gs_step", "gs_run", "gs_sync", "gs_timer_start", "gs_timer_stop", "gs_ctx_info",
+    "gs_host_alloc", "gs_host_free", "gs_field_download_async", "gs_download_wait",
 )
 
 
@@ -111,6 +112,10 @@ def load() -> ctypes.CDLL:
         "gs_timer_start": (i32, [vp]),
         "gs_timer_stop": (i32, [vp, P(f32)]),
         "gs_ctx_info": (i32, [vp, ctypes.c_char_p, ctypes.c_size_t, P(u64)]),
+        "gs_host_alloc": (i32, [P(vp), u64]),
+        "gs_host_free": (i32, [vp]),
+        "gs_field_download_async": (i32, [vp, vp, vp]),
+        "gs_download_wait": (i32, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

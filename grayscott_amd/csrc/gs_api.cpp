@@ -130,9 +130,12 @@ static_assert(sizeof(ncclUniqueId) == GS_UNIQUE_ID_BYTES, "RCCL unique id size c
 // ---------------------------------------------------------------------------------------
 struct SlabRt {
     int device = 0;
-    hipStream_t compute = nullptr, halo = nullptr;
+    hipStream_t compute = nullptr, halo = nullptr, copy = nullptr;
     hipEvent_t done[2] = {nullptr, nullptr}, halod[2] = {nullptr, nullptr};
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipEvent_t staged = nullptr, copied = nullptr; // asynchronous downloads
+    float *stage = nullptr;                        // dense device staging buffer
+    size_t stage_floats = 0;
 };
 
 struct gs_ctx {
@@ -206,6 +209,7 @@ int32_t sync_all(gs_ctx *ctx)
         GS_HIP(hipSetDevice(sl.device));
         GS_HIP(hipStreamSynchronize(sl.halo));
         GS_HIP(hipStreamSynchronize(sl.compute));
+        GS_HIP(hipStreamSynchronize(sl.copy));
     }
     return GS_OK;
 }
@@ -509,6 +513,10 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
         }
         if (sl.t0) (void)hipEventDestroy(sl.t0);
         if (sl.t1) (void)hipEventDestroy(sl.t1);
+        if (sl.staged) (void)hipEventDestroy(sl.staged);
+        if (sl.copied) (void)hipEventDestroy(sl.copied);
+        if (sl.copy) { (void)hipStreamSynchronize(sl.copy); (void)hipStreamDestroy(sl.copy); }
+        if (sl.stage) (void)hipFree(sl.stage);
         if (sl.halo) (void)hipStreamDestroy(sl.halo);
         if (sl.compute) (void)hipStreamDestroy(sl.compute);
     }
@@ -569,6 +577,9 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
         GS_HIP_B(hipDeviceGetStreamPriorityRange(&least, &greatest));
         GS_HIP_B(hipStreamCreateWithPriority(&sl.compute, hipStreamNonBlocking, least));
         GS_HIP_B(hipStreamCreateWithPriority(&sl.halo, hipStreamNonBlocking, greatest));
+        GS_HIP_B(hipStreamCreateWithFlags(&sl.copy, hipStreamNonBlocking));
+        GS_HIP_B(hipEventCreateWithFlags(&sl.staged, hipEventDisableTiming));
+        GS_HIP_B(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
         for (int k = 0; k < 2; ++k) {
             GS_HIP_B(hipEventCreateWithFlags(&sl.done[k], hipEventDisableTiming));
             GS_HIP_B(hipEventCreateWithFlags(&sl.halod[k], hipEventDisableTiming));
@@ -819,6 +830,67 @@ int32_t gs_sync(gs_ctx *ctx)
 {
     if (!ctx) return fail(GS_ERR_INVALID, "null context");
     return sync_all(ctx);
+}
+
+int32_t gs_host_alloc(void **out, uint64_t bytes)
+{
+    if (!out || bytes == 0) return fail(GS_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(GS_ERR_NOMEM, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes,
+                                     hipGetErrorString(e));
+    return GS_OK;
+}
+
+int32_t gs_host_free(void *p)
+{
+    if (!p) return GS_OK;
+    GS_HIP(hipHostFree(p));
+    return GS_OK;
+}
+
+int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host)
+{
+    if (!ctx || !f || !host || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad argument");
+    const uint64_t first = f->s.front().g_row0;
+    const int last = (int)((ctx->step_no + 1) & 1); // parity of the most recent pass
+    for (size_t i = 0; i < f->s.size(); ++i) {
+        SlabRt &sl = ctx->slabs[i];
+        const FieldSlab &fs = f->s[i];
+        GS_HIP(hipSetDevice(sl.device));
+        const size_t need = (size_t)fs.rows * f->cols;
+        if (sl.stage_floats < need) {
+            GS_HIP(hipStreamSynchronize(sl.copy));
+            if (sl.stage) GS_HIP(hipFree(sl.stage));
+            sl.stage = nullptr;
+            sl.stage_floats = 0;
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&sl.stage), need * sizeof(float));
+            if (e != hipSuccess) return fail(GS_ERR_NOMEM, "staging buffer: %s", hipGetErrorString(e));
+            sl.stage_floats = need;
+        }
+        // the previous image must have left the staging buffer; on a slab chain the boundary
+        // rows of the newest plane come from the halo stream
+        GS_HIP(hipStreamWaitEvent(sl.compute, sl.copied, 0));
+        if (ctx->total_slabs() > 1 && ctx->step_no > 0) GS_HIP(hipStreamWaitEvent(sl.compute, sl.halod[last], 0));
+        GS_HIP(hipMemcpy2DAsync(sl.stage, (size_t)f->cols * sizeof(float), fs.row0, (size_t)f->pitch * sizeof(float),
+                                (size_t)f->cols * sizeof(float), (size_t)fs.rows, hipMemcpyDeviceToDevice, sl.compute));
+        GS_HIP(hipEventRecord(sl.staged, sl.compute));
+        GS_HIP(hipStreamWaitEvent(sl.copy, sl.staged, 0));
+        GS_HIP(hipMemcpyAsync(host + (fs.g_row0 - first) * f->cols, sl.stage, need * sizeof(float),
+                              hipMemcpyDeviceToHost, sl.copy));
+        GS_HIP(hipEventRecord(sl.copied, sl.copy));
+    }
+    return GS_OK;
+}
+
+int32_t gs_download_wait(gs_ctx *ctx)
+{
+    if (!ctx) return fail(GS_ERR_INVALID, "null context");
+    for (auto &sl : ctx->slabs) {
+        GS_HIP(hipSetDevice(sl.device));
+        GS_HIP(hipStreamSynchronize(sl.copy));
+    }
+    return GS_OK;
 }
 
 int32_t gs_timer_start(gs_ctx *ctx)

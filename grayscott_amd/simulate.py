@@ -1,0 +1,129 @@
+"""``simulate``-equivalent driver loop on the HIP backend.
+
+Mirrors /root/reference/simulate/src/main.rs:46-127: ``nbimage`` images, ``nbextrastep`` steps
+between images, the V plane of every image handed to a writer thread through a bounded queue
+with buffer recycling (main.rs:73-121), shared CLI flags of ui/src/lib.rs:18-46.  Like the
+reference's ``async-gpu`` path (main.rs:99-106) the steps and the download of the result are
+enqueued together: the download of image i overlaps the steps of image i+1.
+
+    python -m grayscott_amd.simulate -n 100 -r 1080 -c 1920 -o out.npy
+
+Output: the reference writes an HDF5 dataset ``matrix[nbimage, rows, cols]`` f32
+(data/src/hdf5.rs:36-63); libhdf5/h5py are not in this image, so the same array is written as
+a ``.npy`` file (numpy format 1.0, C order) -- same shape, dtype and row order.
+"""
+from __future__ import annotations
+
+import argparse
+import queue
+import sys
+import threading
+import time
+
+import numpy as np
+
+from .simulation import HipArgs, Parameters, Simulation, pinned_empty
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser(prog="simulate", description="Perform Gray-Scott simulation")
+    ap.add_argument("-k", "--killrate", type=float, default=None)        # ui/src/lib.rs:20-22
+    ap.add_argument("-f", "--feedrate", type=float, default=None)        # :24-26
+    ap.add_argument("-e", "--nbextrastep", type=int, default=None)       # :28-30 (default 32, main.rs:52)
+    ap.add_argument("-r", "--nbrow", type=int, default=1080)             # :32-34
+    ap.add_argument("-c", "--nbcol", type=int, default=1920)             # :36-38
+    ap.add_argument("-t", "--deltat", type=float, default=None)          # :40-42
+    ap.add_argument("-n", "--nbimage", type=int, default=1000)           # main.rs:29-31
+    ap.add_argument("-o", "--output", default="output.npy")              # main.rs:33-35
+    ap.add_argument("--output-buffer", type=int, default=2)              # main.rs:37-43
+    return ap.parse_args(argv)
+
+
+def simulation_parameters(args) -> Parameters:
+    """``SharedArgs::simulation_parameters`` (ui/src/lib.rs:51-63)."""
+    p = Parameters()
+    if args.killrate is not None:
+        p.kill_rate = args.killrate
+    if args.feedrate is not None:
+        p.feed_rate = args.feedrate
+    if args.deltat is not None:
+        p.time_step = args.deltat
+    return p
+
+
+def run(args, hip_args: HipArgs | None = None, out=None) -> dict:
+    steps_per_image = args.nbextrastep if args.nbextrastep is not None else 32
+    shape = (args.nbrow, args.nbcol)
+    if args.output_buffer < 1:
+        raise ValueError("--output-buffer must be at least 1")
+    sim = Simulation.new(simulation_parameters(args), hip_args)
+    species = sim.make_species(shape)
+    ctx = sim.context
+    if out is None:
+        out = np.lib.format.open_memmap(args.output, mode="w+", dtype=np.float32,
+                                        shape=(args.nbimage,) + shape)
+
+    # I/O thread: writes images down and recycles their buffers (main.rs:73-87)
+    full: "queue.Queue" = queue.Queue(maxsize=args.output_buffer)
+    free: "queue.Queue" = queue.Queue()
+    for _ in range(args.output_buffer + 1):            # +1: the image being downloaded
+        free.put(pinned_empty(shape))
+    errors = []
+
+    def writer():
+        try:
+            index = 0
+            while True:
+                image = full.get()
+                if image is None:
+                    return
+                out[index] = image
+                index += 1
+                free.put(image)
+        except Exception as e:  # pragma: no cover - surfaced below
+            errors.append(e)
+
+    thread = threading.Thread(target=writer, daemon=True)
+    thread.start()
+    t0 = time.perf_counter()
+    pending = None
+    for _ in range(args.nbimage):
+        image = free.get()
+        sim.perform_steps(species, steps_per_image)     # enqueued behind the previous staging copy
+        if pending is not None:
+            ctx.download_wait()                         # previous image is complete ...
+            full.put(pending)                           # ... hand it to the I/O thread
+        species.write_result_view_after(image)          # this image: staged + copied while we go on
+        pending = image
+    if pending is not None:
+        ctx.download_wait()
+        full.put(pending)
+    full.put(None)
+    thread.join()
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    if errors:
+        raise errors[0]
+    if hasattr(out, "flush"):
+        out.flush()
+    cells = shape[0] * shape[1]
+    info = {
+        "images": args.nbimage, "steps_per_image": steps_per_image, "shape": shape, "seconds": elapsed,
+        "mcells_steps_per_s": cells * steps_per_image * args.nbimage / elapsed / 1e6,
+        "image_MB_per_s": cells * 4 * args.nbimage / elapsed / 1e6,
+    }
+    ctx.close()
+    return info
+
+
+def main(argv=None) -> int:
+    args = parse(argv)
+    info = run(args)
+    print("simulate: {images} images x {steps_per_image} steps on {shape[0]}x{shape[1]} in {seconds:.3f} s "
+          "({mcells_steps_per_s:.0f} Mcells*steps/s, {image_MB_per_s:.0f} MB/s of images)".format(**info),
+          file=sys.stderr)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -115,6 +115,10 @@ class HipContext:
     def sync(self) -> None:
         capi.check(self._lib.gs_sync(self.handle))
 
+    def download_wait(self) -> None:
+        """Wait for the asynchronous downloads enqueued so far (not for later steps)."""
+        capi.check(self._lib.gs_download_wait(self.handle))
+
     def timer_start(self) -> None:
         capi.check(self._lib.gs_timer_start(self.handle))
 
@@ -139,6 +143,34 @@ class HipContext:
             self.close()
         except Exception:
             pass
+
+
+class _PinnedOwner:
+    def __init__(self, lib, ptr):
+        self._lib, self._ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self._lib.gs_host_free(self._ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape: Sequence[int]) -> np.ndarray:
+    """float32 array in page-locked host memory (``gs_host_alloc``) for overlapped downloads."""
+    lib = capi.load()
+    n = int(np.prod(shape))
+    ptr = ctypes.c_void_p()
+    capi.check(lib.gs_host_alloc(ctypes.byref(ptr), max(n, 1) * 4))
+    buf = (ctypes.c_float * max(n, 1)).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=np.float32, count=n).reshape(shape)
+    _PINNED[id(buf)] = (buf, _PinnedOwner(lib, ptr))  # keep the owner alive with the buffer
+    import weakref
+    weakref.finalize(arr.base if arr.base is not None else arr, _PINNED.pop, id(buf), None)
+    return arr
+
+
+_PINNED = {}
 
 
 class HipConcentration:
@@ -218,6 +250,16 @@ class HipConcentration:
         assert target.dtype == np.float32 and target.flags.c_contiguous
         capi.check(context._lib.gs_field_download(context.handle, self.handle,
                                                   target.ctypes.data_as(ctypes.c_void_p)))
+
+    def write_scalar_view_after(self, context: HipContext, target: np.ndarray) -> None:
+        """``write_scalar_view_after`` (data/src/concentration/gpu/image/mod.rs:196-206): enqueue
+        the download behind the steps already enqueued and return at once; ``target`` (ideally
+        from ``pinned_empty``) is valid after ``context.download_wait()``."""
+        r0, r1 = self.local_rows()
+        assert target.shape == (r1 - r0, self._shape[1]), (target.shape, (r1 - r0, self._shape[1]))
+        assert target.dtype == np.float32 and target.flags.c_contiguous
+        capi.check(context._lib.gs_field_download_async(context.handle, self.handle,
+                                                        target.ctypes.data_as(ctypes.c_void_p)))
 
     def destroy(self) -> None:
         if self._h and self._ctx._h:
@@ -311,6 +353,10 @@ class Species:
 
     def write_result_view(self, target: np.ndarray) -> None:
         self.access_result(lambda v, ctx: v.write_scalar_view(ctx, target))
+
+    def write_result_view_after(self, target: np.ndarray) -> None:
+        """Asynchronous form used by the driver loop (simulate/src/main.rs:99-106)."""
+        self.access_result(lambda v, ctx: v.write_scalar_view_after(ctx, target))
 
 
 class Simulation:

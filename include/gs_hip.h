@@ -170,6 +170,22 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
 /* Wait for everything enqueued on this context (all local devices and streams). */
 int32_t gs_sync(gs_ctx *ctx);
 
+/* Overlapped result download -- the analogue of ImageConcentration::write_scalar_view_after /
+ * make_scalar_view_after (data/src/concentration/gpu/image/mod.rs:183-206), which `simulate`
+ * uses so that the N steps and the download of the result are one asynchronous submission
+ * (simulate/src/main.rs:99-106).
+ *   gs_host_alloc / gs_host_free   page-locked host memory for the images
+ *   gs_field_download_async        enqueue "copy this process's rows of `f` to `host`" behind
+ *                                  the work already enqueued and return at once.  The plane is
+ *                                  first densified into a device staging buffer, so steps
+ *                                  enqueued afterwards are not held back by PCIe; `host` must
+ *                                  stay valid until gs_download_wait / gs_sync.
+ *   gs_download_wait               wait for the downloads enqueued so far (not for later steps) */
+int32_t gs_host_alloc(void **out, uint64_t bytes);
+int32_t gs_host_free(void *p);
+int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host);
+int32_t gs_download_wait(gs_ctx *ctx);
+
 /* Device-side stopwatch on the context's compute stream(s) (HIP events): start/stop
  * bracket enqueued work; elapsed is the maximum over local slabs, in milliseconds. */
 int32_t gs_timer_start(gs_ctx *ctx);
