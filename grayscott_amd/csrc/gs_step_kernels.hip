@@ -365,6 +365,12 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
     auto fetch = [&](int row) {
         RowQ r;
         const int rr = min(max(row, row_lo), row_hi);
+#if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 1 /* experiment: no loads (VALU-only timing) */
+        const float fr = (float)rr * a.du + (float)lane;
+        r.u = make_float4(fr, fr + a.dv, fr + a.feed, fr + a.dt);
+        r.v = make_float4(fr * a.dv, fr, fr - a.feed, fr + a.du);
+        return r;
+#endif
         if (load_ok) {
             r.u = *reinterpret_cast<const float4 *>(bu + (ptrdiff_t)rr * pitch);
             r.v = *reinterpret_cast<const float4 *>(bv + (ptrdiff_t)rr * pitch);
@@ -416,13 +422,24 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                         const bool mrow = !EDGE || (row > 0) || a.top_present;
                         const bool prow = !EDGE || (row + 1 < a.rows) || a.bottom_present;
                         float4 nu, nv;
+#if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 2 /* experiment: no arithmetic (memory-only timing) */
+                        nu = make_float4(z.u[1] + m.u[0], z.u[2], z.u[3], z.u[4] + p.u[5]);
+                        nv = make_float4(z.v[1] + m.v[0], z.v[2], z.v[3], z.v[4] + p.v[5]);
+#else
                         cell<EDGE>(a, m, z, p, 1, mrow, prow, la[0], ra[0], nu.x, nv.x);
                         cell<EDGE>(a, m, z, p, 2, mrow, prow, la[1], ra[1], nu.y, nv.y);
                         cell<EDGE>(a, m, z, p, 3, mrow, prow, la[2], ra[2], nu.z, nv.z);
                         cell<EDGE>(a, m, z, p, 4, mrow, prow, la[3], ra[3], nu.w, nv.w);
+#endif
+#if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 1
+                        if (j < K) {
+                            w[j < K ? j : 0][s3] = widen_tb(nu, nv);
+                        } else if (store_ok && nu.x == 12345.678f) {
+#else
                         if (j < K) {
                             w[j < K ? j : 0][s3] = widen_tb(nu, nv);
                         } else if (store_ok) {
+#endif
                             *reinterpret_cast<float4 *>(a.out_u + (ptrdiff_t)row * pitch + c) = nu;
                             *reinterpret_cast<float4 *>(a.out_v + (ptrdiff_t)row * pitch + c) = nv;
                         }
