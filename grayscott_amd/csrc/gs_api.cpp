@@ -134,6 +134,7 @@ struct SlabRt {
     hipEvent_t done[2] = {nullptr, nullptr}, halod[2] = {nullptr, nullptr};
     hipEvent_t t0 = nullptr, t1 = nullptr;
     hipEvent_t staged = nullptr, copied = nullptr; // asynchronous downloads
+    hipEvent_t tune0 = nullptr, tune1 = nullptr;   // unit-height tuning
     float *stage = nullptr;                        // dense device staging buffer
     size_t stage_floats = 0;
 };
@@ -147,6 +148,13 @@ struct gs_ctx {
     ncclComm_t comm = nullptr;
     const char *last_kernel = "none";
     uint64_t launches = 0;
+    // rows-per-unit tuned on line for (rows, cols, fuse) of the last single-slab gs_run
+    uint64_t tuned_rows = 0, tuned_cols = 0;
+    int tuned_fuse = 0, tuned_rpu = 0;
+    // tuning in progress (may span several gs_run calls): next candidate, best so far
+    uint64_t tune_rows = 0, tune_cols = 0;
+    int tune_fuse = 0, tune_next = 0, tune_best_rpu = 0;
+    float tune_best_ms = 0.f;
     int total_slabs() const { return world * (int)slabs.size(); }
     int global_index(int i) const { return rank * (int)slabs.size() + i; }
 };
@@ -302,6 +310,9 @@ int32_t refresh_ghosts(gs_ctx *ctx, gs_field *f)
 int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse)
 {
     if (ctx->o.rows_per_block > 0) return ctx->o.rows_per_block;
+    if (ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse && ctx->tuned_rows == (uint64_t)rows &&
+        ctx->tuned_cols == (uint64_t)cols && ctx->total_slabs() == 1)
+        return ctx->tuned_rpu;
     const long strips = (cols + 247) / 248;
     const long want = fuse > 1 ? 8L * fuse : 16;
     long rpu = ((long)rows * strips + 16383) / 16384; // keep >= 16384 waves per launch when possible
@@ -515,6 +526,8 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
         if (sl.t1) (void)hipEventDestroy(sl.t1);
         if (sl.staged) (void)hipEventDestroy(sl.staged);
         if (sl.copied) (void)hipEventDestroy(sl.copied);
+        if (sl.tune0) (void)hipEventDestroy(sl.tune0);
+        if (sl.tune1) (void)hipEventDestroy(sl.tune1);
         if (sl.copy) { (void)hipStreamSynchronize(sl.copy); (void)hipStreamDestroy(sl.copy); }
         if (sl.stage) (void)hipFree(sl.stage);
         if (sl.halo) (void)hipStreamDestroy(sl.halo);
@@ -580,6 +593,8 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
         GS_HIP_B(hipStreamCreateWithFlags(&sl.copy, hipStreamNonBlocking));
         GS_HIP_B(hipEventCreateWithFlags(&sl.staged, hipEventDisableTiming));
         GS_HIP_B(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+        GS_HIP_B(hipEventCreate(&sl.tune0));
+        GS_HIP_B(hipEventCreate(&sl.tune1));
         for (int k = 0; k < 2; ++k) {
             GS_HIP_B(hipEventCreateWithFlags(&sl.done[k], hipEventDisableTiming));
             GS_HIP_B(hipEventCreateWithFlags(&sl.halod[k], hipEventDisableTiming));
@@ -816,11 +831,79 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     }
     // The short pass (steps % fuse) goes first so that a run ends on a full-depth ghost exchange
     // and the next run can start without a blocking refresh.
-    for (uint64_t n = 0; n < steps;) {
-        const int k = (n == 0 && steps % (uint64_t)fuse) ? (int)(steps % (uint64_t)fuse) : fuse;
+    uint64_t n = 0;
+    if (steps % (uint64_t)fuse) {
+        const int k = (int)(steps % (uint64_t)fuse);
         GS_TRY(step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], k));
         in = 1 - in;
         n += (uint64_t)k;
+    }
+    // On-line choice of the unit height (single slab, fused passes, no explicit setting): the
+    // best value depends on how the launch tiles the chip (tail effects vs 2K redundant rows per
+    // unit), so the first passes of a long run are timed with a few candidates -- they are real
+    // passes of the simulation, nothing is recomputed -- and the fastest is kept for this shape.
+    const bool tunable = ctx->total_slabs() == 1 && fuse > 1 && ctx->o.rows_per_block == 0 &&
+                         !(ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse && ctx->tuned_rows == u0->rows &&
+                           ctx->tuned_cols == u0->cols);
+    if (tunable) {
+        static const int cand[] = {8, 12, 16, 24, 32, 48, 64, 96, 128};
+        const int ncand = (int)(sizeof cand / sizeof cand[0]);
+        const uint64_t cells = u0->rows * u0->cols;
+        const int reps = cells >= (1ull << 24) ? 2 : (cells >= (1ull << 22) ? 4 : 8); // passes per candidate
+        if (ctx->tune_rows != u0->rows || ctx->tune_cols != u0->cols || ctx->tune_fuse != fuse) {
+            ctx->tune_rows = u0->rows;
+            ctx->tune_cols = u0->cols;
+            ctx->tune_fuse = fuse;
+            ctx->tune_next = 0;
+            ctx->tune_best_rpu = 0;
+            ctx->tune_best_ms = 0.f;
+        }
+        SlabRt &sl = ctx->slabs[0];
+        GS_HIP(hipSetDevice(sl.device));
+        bool warm = n > 0; // a pass of this call already ran
+        while (ctx->tune_next < ncand) {
+            const int rpu = cand[ctx->tune_next];
+            if (rpu < 2 * fuse || (uint64_t)rpu > u0->rows) { ctx->tune_next++; continue; }
+            const uint64_t passes_left = (steps - n) / (uint64_t)fuse;
+            if (passes_left < (uint64_t)reps + (warm ? 0 : 1)) break; // continue in the next gs_run
+            ctx->o.rows_per_block = rpu;
+            int32_t st = GS_OK;
+            if (!warm) { // untimed pass first
+                st = step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], fuse);
+                in = 1 - in;
+                n += (uint64_t)fuse;
+                warm = true;
+            }
+            if (st == GS_OK && hipEventRecord(sl.tune0, sl.compute) != hipSuccess) st = fail(GS_ERR_HIP, "hipEventRecord failed");
+            for (int r = 0; r < reps && st == GS_OK; ++r) {
+                st = step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], fuse);
+                in = 1 - in;
+                n += (uint64_t)fuse;
+            }
+            ctx->o.rows_per_block = 0;
+            float ms = 0.f;
+            if (st == GS_OK && (hipEventRecord(sl.tune1, sl.compute) != hipSuccess || hipEventSynchronize(sl.tune1) != hipSuccess ||
+                                hipEventElapsedTime(&ms, sl.tune0, sl.tune1) != hipSuccess))
+                st = fail(GS_ERR_HIP, "timing a tuning pass failed");
+            if (st != GS_OK) return st;
+            // prefer the incumbent unless the newcomer is clearly (> 1 %) faster
+            if (ctx->tune_best_rpu == 0 || ms < 0.99f * ctx->tune_best_ms) {
+                ctx->tune_best_ms = ms;
+                ctx->tune_best_rpu = rpu;
+            }
+            ctx->tune_next++;
+        }
+        if (ctx->tune_next >= ncand && ctx->tune_best_rpu > 0) {
+            ctx->tuned_rpu = ctx->tune_best_rpu;
+            ctx->tuned_fuse = fuse;
+            ctx->tuned_rows = u0->rows;
+            ctx->tuned_cols = u0->cols;
+        }
+    }
+    while (n < steps) {
+        GS_TRY(step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], fuse));
+        in = 1 - in;
+        n += (uint64_t)fuse;
     }
     if (result_slot) *result_slot = in;
     return GS_OK;
@@ -929,8 +1012,10 @@ int32_t gs_ctx_info(const gs_ctx *ctx, char *kernel_name, size_t cap, uint64_t *
 {
     if (!ctx) return fail(GS_ERR_INVALID, "null context");
     if (kernel_name && cap) {
-        std::strncpy(kernel_name, ctx->last_kernel, cap - 1);
-        kernel_name[cap - 1] = '\0';
+        if (ctx->tuned_rpu > 0)
+            std::snprintf(kernel_name, cap, "%s@%d", ctx->last_kernel, ctx->tuned_rpu); // tuned unit height
+        else
+            std::snprintf(kernel_name, cap, "%s", ctx->last_kernel);
     }
     if (launches) *launches = ctx->launches;
     return GS_OK;

@@ -163,7 +163,9 @@ int32_t gs_step(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs
 /* Simulate::perform_steps (compute/shared/src/lib.rs:48-58): `steps` steps ping-ponging
  * between slot 0 (u0, v0: input on entry) and slot 1.  *result_slot receives the slot that
  * holds the newest state (steps odd -> 1); the caller swaps its handles accordingly so that
- * "the input concentrations contain the final results" (:51-52).  Asynchronous. */
+ * "the input concentrations contain the final results" (:51-52).  Asynchronous, except that
+ * the first long run on a given shape times a few passes to choose the unit height (they are
+ * real passes of the simulation; set gs_options.rows_per_block to skip the tuning). */
 int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *v1,
                uint64_t steps, int32_t *result_slot);
 
@@ -191,8 +193,9 @@ int32_t gs_download_wait(gs_ctx *ctx);
 int32_t gs_timer_start(gs_ctx *ctx);
 int32_t gs_timer_stop(gs_ctx *ctx, float *elapsed_ms);
 
-/* Introspection for tests and the bench: name of the kernel variant last launched and the
- * number of kernel launches it took. */
+/* Introspection for tests and the bench: name of the kernel variant last launched
+ * ("tb-k4/strict@32" = 4 fused steps, strict math, tuned unit height 32 rows) and the number of
+ * kernel launches so far. */
 int32_t gs_ctx_info(const gs_ctx *ctx, char *kernel_name, size_t cap, uint64_t *launches);
 
 #ifdef __cplusplus
