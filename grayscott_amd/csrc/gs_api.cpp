@@ -83,35 +83,36 @@ struct Rccl {
 
 Rccl *rccl()
 {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.handle ? &r : nullptr;
-    tried = true;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (r.handle) break;
-    }
-    if (!r.handle) return nullptr;
-    bool ok = true;
-    auto sym = [&](const char *n) {
-        void *p = dlsym(r.handle, n);
-        if (!p) ok = false;
-        return p;
-    };
-    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
-    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
-    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
-    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
-    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
-    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
-    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-    if (!ok) {
-        dlclose(r.handle);
-        r.handle = nullptr;
-        return nullptr;
-    }
-    return &r;
+    // function-local static: initialised once, thread-safe (C++11)
+    static Rccl *const instance = []() -> Rccl * {
+        static Rccl r;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) return nullptr;
+        bool ok = true;
+        auto sym = [&](const char *n) {
+            void *p = dlsym(r.handle, n);
+            if (!p) ok = false;
+            return p;
+        };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!ok) {
+            dlclose(r.handle);
+            r.handle = nullptr;
+            return nullptr;
+        }
+        return &r;
+    }();
+    return instance;
 }
 
 #define GS_NCCL(R, expr)                                                                       \

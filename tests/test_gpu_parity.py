@@ -220,6 +220,28 @@ def test_species_new_and_flip_contract():
         sp2.write_result_view(np.empty((64, 127), np.float32))
 
 
+def test_set_params_between_runs_and_mixed_entry_points():
+    """gs_ctx_set_params mid-run, and gs_step (single-step kernel) interleaved with gs_run (fused)."""
+    u0, v0 = stress_fields((90, 400), 9)
+    p1, p2 = Parameters(), Parameters(feed_rate=0.03, kill_rate=0.06, time_step=0.5)
+    sim = Simulation.new(p1, args())
+    sp = species_from_arrays(sim, u0, v0)
+    sim.perform_steps(sp, 6)
+    sim.perform_step(sp)
+    sim.context.set_params(p2)
+    sim.perform_steps(sp, 9)
+    sim.perform_step(sp)
+    sim.perform_steps(sp, 2)
+    ref = oracle.run(u0, v0, 7, oracle_params(p1))
+    ref = oracle.run(ref[0], ref[1], 12, oracle_params(p2))
+    in_u, in_v, _, _ = sp.in_out()
+    assert_bits_equal(in_u.make_scalar_view(sim.context), ref[0], "U after set_params")
+    assert_bits_equal(in_v.make_scalar_view(sim.context), ref[1], "V after set_params")
+    with pytest.raises(GsError):  # fused math refuses non power-of-two weights at set_params too
+        s2 = Simulation.new(p1, args(math=capi.GS_MATH_FUSED))
+        s2.context.set_params(Parameters(weights=((1 / 6, 4 / 6, 1 / 6), (4 / 6, 0.0, 4 / 6), (1 / 6, 4 / 6, 1 / 6))))
+
+
 def test_error_behaviour():
     sim = Simulation.new(Parameters(), args())
     ctx = sim.context
