@@ -66,7 +66,8 @@ class GsOptions(ctypes.Structure):
         ("fuse_steps", ctypes.c_int32),
         ("use_graph", ctypes.c_int32),
         ("pitch_pad", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 10),
+        ("split", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 9),
     ]
 
 

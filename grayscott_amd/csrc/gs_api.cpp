@@ -144,6 +144,9 @@ struct gs_ctx {
     gs_params p;
     gs_options o;
     std::vector<SlabRt> slabs; // local slabs, top to bottom
+    std::vector<SlabRt> bands; // stream/event sets for the in-place row bands of a single slab
+    hipEvent_t band_join = nullptr;
+    bool bands_active = false; // the newest pass ran on the band streams
     int rank = 0, world = 1;
     uint64_t step_no = 0;
     ncclComm_t comm = nullptr;
@@ -151,10 +154,10 @@ struct gs_ctx {
     uint64_t launches = 0;
     // rows-per-unit tuned on line for (rows, cols, fuse) of the last single-slab gs_run
     uint64_t tuned_rows = 0, tuned_cols = 0;
-    int tuned_fuse = 0, tuned_rpu = 0;
+    int tuned_fuse = 0, tuned_rpu = 0, tuned_split = 0;
     // tuning in progress (may span several gs_run calls): next candidate, best so far
     uint64_t tune_rows = 0, tune_cols = 0;
-    int tune_fuse = 0, tune_next = 0, tune_best_rpu = 0;
+    int tune_fuse = 0, tune_next = 0, tune_best_rpu = 0, tune_best_split = 0;
     float tune_best_ms = 0.f;
     int total_slabs() const { return world * (int)slabs.size(); }
     int global_index(int i) const { return rank * (int)slabs.size() + i; }
@@ -219,6 +222,11 @@ int32_t sync_all(gs_ctx *ctx)
         GS_HIP(hipStreamSynchronize(sl.halo));
         GS_HIP(hipStreamSynchronize(sl.compute));
         GS_HIP(hipStreamSynchronize(sl.copy));
+    }
+    for (auto &b : ctx->bands) {
+        GS_HIP(hipSetDevice(b.device));
+        GS_HIP(hipStreamSynchronize(b.halo));
+        GS_HIP(hipStreamSynchronize(b.compute));
     }
     return GS_OK;
 }
@@ -323,7 +331,7 @@ int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fu
     return (int32_t)rpu;
 }
 
-int32_t launch_rows(gs_ctx *ctx, const GsStepArgs &a, hipStream_t stream, int fuse = 1)
+int32_t launch_rows(gs_ctx *ctx, const GsStepArgs &a, hipStream_t stream, int fuse)
 {
     int32_t kernel = ctx->o.kernel;
     if (kernel == GS_KERNEL_AUTO) kernel = fuse > 1 ? GS_KERNEL_TB : GS_KERNEL_STREAM;
@@ -379,6 +387,115 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
     return a;
 }
 
+// ---- in-place row bands of a single slab -------------------------------------------------
+// One slab can be scheduled as V row bands that alias the same planes: a band's "ghost rows" are
+// simply the neighbouring band's rows, so nothing is copied, but the dependency structure is
+// that of a slab chain: the next pass of a band only waits for its own previous pass and for the
+// K boundary rows of its neighbours.  The tail of pass n (waves draining at different times)
+// then overlaps the head of pass n+1 instead of idling the chip between dependent launches.
+int32_t ensure_bands(gs_ctx *ctx, int V)
+{
+    if ((int)ctx->bands.size() >= V) return GS_OK;
+    const int device = ctx->slabs[0].device;
+    GS_HIP(hipSetDevice(device));
+    int least = 0, greatest = 0;
+    GS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (!ctx->band_join) GS_HIP(hipEventCreateWithFlags(&ctx->band_join, hipEventDisableTiming));
+    while ((int)ctx->bands.size() < V) {
+        SlabRt b;
+        b.device = device;
+        GS_HIP(hipStreamCreateWithPriority(&b.compute, hipStreamNonBlocking, least));
+        GS_HIP(hipStreamCreateWithPriority(&b.halo, hipStreamNonBlocking, greatest));
+        for (int k = 0; k < 2; ++k) {
+            GS_HIP(hipEventCreateWithFlags(&b.done[k], hipEventDisableTiming));
+            GS_HIP(hipEventCreateWithFlags(&b.halod[k], hipEventDisableTiming));
+        }
+        ctx->bands.push_back(b);
+    }
+    return GS_OK;
+}
+
+// Make `stream` wait for everything the band streams were given (no-op when they are idle).
+int32_t join_bands(gs_ctx *ctx, hipStream_t stream)
+{
+    if (!ctx->bands_active) return GS_OK;
+    for (auto &b : ctx->bands)
+        for (int k = 0; k < 2; ++k) {
+            GS_HIP(hipStreamWaitEvent(stream, b.done[k], 0));
+            GS_HIP(hipStreamWaitEvent(stream, b.halod[k], 0));
+        }
+    return GS_OK;
+}
+
+int clamp_bands(const gs_field *f, int fuse, int V)
+{
+    if (V > 8) V = 8;
+    while (V > 1 && f->rows / (uint64_t)V < (uint64_t)(8 * fuse)) --V;
+    return V < 1 ? 1 : V;
+}
+
+int bands_for(const gs_ctx *ctx, const gs_field *f, int fuse)
+{
+    if (ctx->total_slabs() != 1 || fuse < 2) return 1;
+    int V = ctx->o.split;
+    if (V == 0 && ctx->tuned_split > 0 && ctx->tuned_fuse == fuse && ctx->tuned_rows == f->rows &&
+        ctx->tuned_cols == f->cols)
+        return clamp_bands(f, fuse, ctx->tuned_split);
+    if (V == 0) V = (f->rows * f->cols >= (1ull << 26)) ? 2 : 1; // measured: pays on large grids
+    if (V > 8) V = 8;
+    while (V > 1 && f->rows / (uint64_t)V < (uint64_t)(8 * fuse)) --V;
+    return V < 1 ? 1 : V;
+}
+
+int32_t step_bands(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs_field *out_v, int fuse, int V)
+{
+    GS_TRY(ensure_bands(ctx, V));
+    SlabRt &sl = ctx->slabs[0];
+    GS_HIP(hipSetDevice(sl.device));
+    // whatever was enqueued on the slab's own streams (fills, single steps, staging copies)
+    GS_HIP(hipEventRecord(ctx->band_join, sl.compute));
+    const GsStepArgs full = make_args(ctx, in_u, in_v, out_u, out_v, 0, fuse);
+    const int n = full.rows;
+    const int p = (int)(ctx->step_no & 1), q = p ^ 1;
+    for (int k = 0; k < V; ++k) {
+        SlabRt &b = ctx->bands[k];
+        const int r0 = (int)((int64_t)k * n / V), r1 = (int)((int64_t)(k + 1) * n / V);
+        GsStepArgs a = full;
+        const ptrdiff_t off = (ptrdiff_t)r0 * full.pitch;
+        a.in_u += off; a.in_v += off; a.out_u += off; a.out_v += off;
+        a.rows = r1 - r0;
+        a.top_present = k > 0;
+        a.bottom_present = k < V - 1;
+        const int nk = a.rows;
+        // band-edge rows first (high priority), so that the neighbours' next pass can start
+        GS_HIP(hipStreamWaitEvent(b.halo, ctx->band_join, 0));
+        GS_HIP(hipStreamWaitEvent(b.halo, b.done[q], 0));
+        if (k > 0) GS_HIP(hipStreamWaitEvent(b.halo, ctx->bands[k - 1].halod[q], 0));
+        if (k < V - 1) GS_HIP(hipStreamWaitEvent(b.halo, ctx->bands[k + 1].halod[q], 0));
+        GsStepArgs e = a;
+        e.ra0 = 0;
+        e.ra1 = nk <= 2 * fuse ? nk : fuse;
+        e.rb0 = nk <= 2 * fuse ? 0 : nk - fuse;
+        e.rb1 = nk <= 2 * fuse ? 0 : nk;
+        e.rows_per_unit = fuse;
+        GS_TRY(launch_rows(ctx, e, b.halo, fuse));
+        GS_HIP(hipEventRecord(b.halod[p], b.halo));
+        GS_HIP(hipStreamWaitEvent(b.compute, ctx->band_join, 0));
+        GS_HIP(hipStreamWaitEvent(b.compute, b.halod[q], 0));
+        if (nk > 2 * fuse) {
+            a.ra0 = fuse;
+            a.ra1 = nk - fuse;
+            GS_TRY(launch_rows(ctx, a, b.compute, fuse));
+        }
+        GS_HIP(hipEventRecord(b.done[p], b.compute));
+    }
+    ctx->bands_active = true;
+    ctx->step_no++;
+    out_u->ghost_depth = fuse;
+    out_v->ghost_depth = fuse;
+    return GS_OK;
+}
+
 // Advances the state by `fuse` time steps with ONE pass over the planes.  On a chain of slabs
 // the ghost rows are `fuse` deep for that pass: the boundary kernel updates the first and last
 // `fuse` rows, which are then pushed to the neighbours while the interior kernel runs.
@@ -390,6 +507,8 @@ int32_t step_impl(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, 
     if (S == 1) {
         SlabRt &sl = ctx->slabs[0];
         GS_HIP(hipSetDevice(sl.device));
+        GS_TRY(join_bands(ctx, sl.compute));
+        ctx->bands_active = false;
         GsStepArgs a = make_args(ctx, in_u, in_v, out_u, out_v, 0, fuse);
         a.ra0 = 0;
         a.ra1 = a.rows;
@@ -534,6 +653,16 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
         if (sl.halo) (void)hipStreamDestroy(sl.halo);
         if (sl.compute) (void)hipStreamDestroy(sl.compute);
     }
+    for (auto &b : ctx->bands) {
+        if (hipSetDevice(b.device) != hipSuccess) continue;
+        if (b.halo) { (void)hipStreamSynchronize(b.halo); (void)hipStreamDestroy(b.halo); }
+        if (b.compute) { (void)hipStreamSynchronize(b.compute); (void)hipStreamDestroy(b.compute); }
+        for (int k = 0; k < 2; ++k) {
+            if (b.done[k]) (void)hipEventDestroy(b.done[k]);
+            if (b.halod[k]) (void)hipEventDestroy(b.halod[k]);
+        }
+    }
+    if (ctx->band_join) (void)hipEventDestroy(ctx->band_join);
     (void)hipGetLastError(); // teardown failures must not leak into later calls' status
     delete ctx;
     return GS_OK;
@@ -846,9 +975,20 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     const bool tunable = ctx->total_slabs() == 1 && fuse > 1 && ctx->o.rows_per_block == 0 &&
                          !(ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse && ctx->tuned_rows == u0->rows &&
                            ctx->tuned_cols == u0->cols);
+    auto advance = [&](int V) -> int32_t {
+        const int32_t st = V > 1 ? step_bands(ctx, u[in], v[in], u[1 - in], v[1 - in], fuse, V)
+                                 : step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], fuse);
+        in = 1 - in;
+        n += (uint64_t)fuse;
+        return st;
+    };
     if (tunable) {
+        // phase A: unit heights with the default band count; phase B: other band counts with the
+        // best unit height (only when the band count is not pinned by the options)
         static const int cand[] = {8, 12, 16, 24, 32, 48, 64, 96, 128};
+        static const int alt[] = {1, 2, 3};
         const int ncand = (int)(sizeof cand / sizeof cand[0]);
+        const int nalt = ctx->o.split == 0 ? (int)(sizeof alt / sizeof alt[0]) : 0;
         const uint64_t cells = u0->rows * u0->cols;
         const int reps = cells >= (1ull << 24) ? 2 : (cells >= (1ull << 22) ? 4 : 8); // passes per candidate
         if (ctx->tune_rows != u0->rows || ctx->tune_cols != u0->cols || ctx->tune_fuse != fuse) {
@@ -857,31 +997,37 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
             ctx->tune_fuse = fuse;
             ctx->tune_next = 0;
             ctx->tune_best_rpu = 0;
+            ctx->tune_best_split = 0;
             ctx->tune_best_ms = 0.f;
         }
+        const int V0 = bands_for(ctx, u0, fuse);
         SlabRt &sl = ctx->slabs[0];
         GS_HIP(hipSetDevice(sl.device));
         bool warm = n > 0; // a pass of this call already ran
-        while (ctx->tune_next < ncand) {
-            const int rpu = cand[ctx->tune_next];
-            if (rpu < 2 * fuse || (uint64_t)rpu > u0->rows) { ctx->tune_next++; continue; }
+        while (ctx->tune_next < ncand + nalt) {
+            int rpu, V;
+            if (ctx->tune_next < ncand) {
+                rpu = cand[ctx->tune_next];
+                V = V0;
+                if (rpu < 2 * fuse || (uint64_t)rpu > u0->rows) { ctx->tune_next++; continue; }
+            } else {
+                rpu = ctx->tune_best_rpu;
+                V = clamp_bands(u0, fuse, alt[ctx->tune_next - ncand]);
+                if (rpu == 0 || V == V0 || V != alt[ctx->tune_next - ncand]) { ctx->tune_next++; continue; }
+            }
             const uint64_t passes_left = (steps - n) / (uint64_t)fuse;
             if (passes_left < (uint64_t)reps + (warm ? 0 : 1)) break; // continue in the next gs_run
             ctx->o.rows_per_block = rpu;
             int32_t st = GS_OK;
             if (!warm) { // untimed pass first
-                st = step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], fuse);
-                in = 1 - in;
-                n += (uint64_t)fuse;
+                st = advance(V);
                 warm = true;
             }
+            if (st == GS_OK) st = join_bands(ctx, sl.compute);
             if (st == GS_OK && hipEventRecord(sl.tune0, sl.compute) != hipSuccess) st = fail(GS_ERR_HIP, "hipEventRecord failed");
-            for (int r = 0; r < reps && st == GS_OK; ++r) {
-                st = step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], fuse);
-                in = 1 - in;
-                n += (uint64_t)fuse;
-            }
+            for (int r = 0; r < reps && st == GS_OK; ++r) st = advance(V);
             ctx->o.rows_per_block = 0;
+            if (st == GS_OK) st = join_bands(ctx, sl.compute);
             float ms = 0.f;
             if (st == GS_OK && (hipEventRecord(sl.tune1, sl.compute) != hipSuccess || hipEventSynchronize(sl.tune1) != hipSuccess ||
                                 hipEventElapsedTime(&ms, sl.tune0, sl.tune1) != hipSuccess))
@@ -891,21 +1037,20 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
             if (ctx->tune_best_rpu == 0 || ms < 0.99f * ctx->tune_best_ms) {
                 ctx->tune_best_ms = ms;
                 ctx->tune_best_rpu = rpu;
+                ctx->tune_best_split = V;
             }
             ctx->tune_next++;
         }
-        if (ctx->tune_next >= ncand && ctx->tune_best_rpu > 0) {
+        if (ctx->tune_next >= ncand + nalt && ctx->tune_best_rpu > 0) {
             ctx->tuned_rpu = ctx->tune_best_rpu;
+            ctx->tuned_split = ctx->tune_best_split;
             ctx->tuned_fuse = fuse;
             ctx->tuned_rows = u0->rows;
             ctx->tuned_cols = u0->cols;
         }
     }
-    while (n < steps) {
-        GS_TRY(step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], fuse));
-        in = 1 - in;
-        n += (uint64_t)fuse;
-    }
+    const int V = bands_for(ctx, u0, fuse);
+    while (n < steps) GS_TRY(advance(V));
     if (result_slot) *result_slot = in;
     return GS_OK;
 }
@@ -956,6 +1101,7 @@ int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host)
         // rows of the newest plane come from the halo stream
         GS_HIP(hipStreamWaitEvent(sl.compute, sl.copied, 0));
         if (ctx->total_slabs() > 1 && ctx->step_no > 0) GS_HIP(hipStreamWaitEvent(sl.compute, sl.halod[last], 0));
+        if (i == 0) GS_TRY(join_bands(ctx, sl.compute));
         GS_HIP(hipMemcpy2DAsync(sl.stage, (size_t)f->cols * sizeof(float), fs.row0, (size_t)f->pitch * sizeof(float),
                                 (size_t)f->cols * sizeof(float), (size_t)fs.rows, hipMemcpyDeviceToDevice, sl.compute));
         GS_HIP(hipEventRecord(sl.staged, sl.compute));
@@ -995,6 +1141,7 @@ int32_t gs_timer_stop(gs_ctx *ctx, float *elapsed_ms)
         GS_HIP(hipSetDevice(sl.device));
         if (ctx->total_slabs() > 1 && ctx->step_no > 0)
             GS_HIP(hipStreamWaitEvent(sl.compute, sl.halod[last], 0));
+        if (&sl == &ctx->slabs[0]) GS_TRY(join_bands(ctx, sl.compute));
         GS_HIP(hipEventRecord(sl.t1, sl.compute));
     }
     float worst = 0.0f;
@@ -1014,7 +1161,8 @@ int32_t gs_ctx_info(const gs_ctx *ctx, char *kernel_name, size_t cap, uint64_t *
     if (!ctx) return fail(GS_ERR_INVALID, "null context");
     if (kernel_name && cap) {
         if (ctx->tuned_rpu > 0)
-            std::snprintf(kernel_name, cap, "%s@%d", ctx->last_kernel, ctx->tuned_rpu); // tuned unit height
+            std::snprintf(kernel_name, cap, "%s@%dx%d", ctx->last_kernel, ctx->tuned_rpu,
+                          ctx->tuned_split > 0 ? ctx->tuned_split : 1); // tuned unit height x row bands
         else
             std::snprintf(kernel_name, cap, "%s", ctx->last_kernel);
     }

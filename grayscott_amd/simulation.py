@@ -73,6 +73,7 @@ class HipArgs:
     fuse_steps: int = field(default_factory=lambda: _env_int("GS_HIP_FUSE_STEPS", 0))
     use_graph: int = field(default_factory=lambda: _env_int("GS_HIP_USE_GRAPH", 0))
     pitch_pad: int = field(default_factory=lambda: _env_int("GS_HIP_PITCH_PAD", 0))
+    split: int = field(default_factory=lambda: _env_int("GS_HIP_SPLIT", 0))
     rank: int = 0
     world: int = 1
     unique_id: Optional[bytes] = None
@@ -82,6 +83,7 @@ class HipArgs:
         o.math, o.kernel = self.math, self.kernel
         o.rows_per_block, o.fuse_steps = self.rows_per_block, self.fuse_steps
         o.use_graph, o.pitch_pad = self.use_graph, self.pitch_pad
+        o.split = self.split
         return o
 
 

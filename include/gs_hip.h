@@ -100,7 +100,10 @@ typedef struct gs_options {
     int32_t fuse_steps;      /* steps fused per launch in gs_run (1..4; 0 = auto); single slab */
     int32_t use_graph;       /* 1 = replay gs_run batches through a hipGraph (0 = off)     */
     int32_t pitch_pad;       /* extra f32 of row pitch beyond the 64-float round-up        */
-    int32_t reserved[10];
+    int32_t split;           /* row bands a single slab is scheduled as (0 = auto, 1 = off):   *
+                              * adjacent bands only depend on each other's K boundary rows, so *
+                              * the tail of one pass overlaps the start of the next            */
+    int32_t reserved[9];
 } gs_options;
 
 typedef struct gs_ctx gs_ctx;     /* devices, streams, row partition, RCCL communicator    */
@@ -194,7 +197,7 @@ int32_t gs_timer_start(gs_ctx *ctx);
 int32_t gs_timer_stop(gs_ctx *ctx, float *elapsed_ms);
 
 /* Introspection for tests and the bench: name of the kernel variant last launched
- * ("tb-k4/strict@32" = 4 fused steps, strict math, tuned unit height 32 rows) and the number of
+ * ("tb-k4/strict@32x2" = 4 fused steps, strict math, tuned: 32-row units, 2 row bands) and the number of
  * kernel launches so far. */
 int32_t gs_ctx_info(const gs_ctx *ctx, char *kernel_name, size_t cap, uint64_t *launches);
 

@@ -27,7 +27,8 @@ pub struct gs_options {
     pub fuse_steps: i32,
     pub use_graph: i32,
     pub pitch_pad: i32,
-    pub reserved: [i32; 10],
+    pub split: i32,
+    pub reserved: [i32; 9],
 }
 
 #[repr(C)]

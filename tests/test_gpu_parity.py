@@ -174,6 +174,48 @@ def test_temporal_blocking_large_grid_vs_stream():
         assert_bits_equal(got[1], ref[1], f"TB{fuse} vs stream V")
 
 
+# ---- in-place row bands of a single slab (cross-pass overlap schedule) --------------------------
+@pytest.mark.parametrize("split", [2, 3, 5])
+def test_single_slab_row_bands_bit_exact(split):
+    for shape, steps in (((200, 300), 23), ((64, 128), 50), ((97, 1030), 9)):
+        u0, v0 = stress_fields(shape, 13)
+        ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True)
+        got_u, got_v, info = gpu_run(u0, v0, steps, args=args(split=split, rows_per_block=6))
+        assert_bits_equal(got_u, ref_u, f"U split {split} {shape}")
+        assert_bits_equal(got_v, ref_v, f"V split {split} {shape}")
+    # interleaved with single steps, parameter changes and asynchronous downloads
+    from grayscott_amd import pinned_empty
+    u0, v0 = stress_fields((160, 520), 3)
+    sim = Simulation.new(Parameters(), args(split=split))
+    sp = species_from_arrays(sim, u0, v0)
+    img = pinned_empty((160, 520))
+    sim.perform_steps(sp, 10)
+    sp.write_result_view_after(img)
+    sim.perform_steps(sp, 17)
+    sim.perform_step(sp)
+    sim.perform_steps(sp, 8)
+    sim.context.download_wait()
+    assert_bits_equal(img, oracle.run(u0, v0, 10)[1], "image behind band passes")
+    in_u, in_v, _, _ = sp.in_out()
+    ref = oracle.run(u0, v0, 36)
+    assert_bits_equal(in_u.make_scalar_view(sim.context), ref[0], "U bands + single steps")
+    assert_bits_equal(in_v.make_scalar_view(sim.context), ref[1], "V bands + single steps")
+
+
+def test_auto_row_bands_on_a_large_grid():
+    """8192 x 8192 = 2^26 cells turns the band schedule on by default; compare with the
+    single-step kernel run step by step."""
+    rows = cols = 8192
+    rng = np.random.default_rng(21)
+    u0 = rng.random((rows, cols), dtype=np.float32)
+    v0 = (rng.random((rows, cols), dtype=np.float32) * np.float32(0.5)).astype(np.float32)
+    ref = gpu_run(u0, v0, 14, args=args(kernel=capi.GS_KERNEL_STREAM))
+    got = gpu_run(u0, v0, 14)
+    assert got[2][0].startswith("tb-k4")
+    assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32))
+    assert np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32))
+
+
 # ---- non-default parameters (CLI overrides -k -f -t, ui/src/lib.rs:51-63) and weights ------
 @pytest.mark.parametrize("kernel", [capi.GS_KERNEL_SIMPLE, capi.GS_KERNEL_STREAM])
 def test_non_default_parameters(kernel):

@@ -19,10 +19,10 @@ export GS_HIP_ROWS_PER_BLOCK=${GS_HIP_ROWS_PER_BLOCK:-32}
 cd /tmp
 EXTRA=${GS_BENCH_EXTRA:-}
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
-    python3 "$ROOT/bench.py" --steps "$STEPS" --warmup 20 --no-cpu-baseline $EXTRA > "$OUT/bench_stats.json" 2> "$OUT/stats.log"
+    python3 "$ROOT/bench.py" --steps "$STEPS" --warmup 20 --no-cpu-baseline --no-extra $EXTRA > "$OUT/bench_stats.json" 2> "$OUT/stats.log"
 tail -1 "$OUT/bench_stats.json"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o bench -- \
-    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline $EXTRA > "$OUT/bench_fetch.json" 2> "$OUT/fetch.log"
+    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-extra $EXTRA > "$OUT/bench_fetch.json" 2> "$OUT/fetch.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o bench -- \
-    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline $EXTRA > "$OUT/bench_write.json" 2> "$OUT/write.log"
+    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-extra $EXTRA > "$OUT/bench_write.json" 2> "$OUT/write.log"
 find "$OUT" -name '*.csv' | head -20
