@@ -1,4 +1,4 @@
-// gs_step_kernels.hip -- gfx950 (CDNA4, wave64) kernels for one Gray-Scott time step.
+// gs_step_kernels.hip -- gfx950 (CDNA4, wave64) kernels for the Gray-Scott time step.
 //
 // Arithmetic spec: compute_naive::Simulation::perform_step,
 // /root/reference/compute/naive/src/lib.rs:42-83 -- for every cell, a row-major fold
@@ -23,12 +23,19 @@
 //
 // Kernels
 //   gs_step_simple_k   one thread per cell, literal window loop (cross-check kernel).
-//   gs_step_stream_k   the production kernel: a wave owns a 256-column strip (one 16-B
-//       load per lane per row and species), marches down `rows_per_unit` rows keeping a
-//       3-row window in registers, and gets its left/right neighbours from the adjacent
-//       lanes with DPP wave shifts (no LDS, no extra memory traffic); only lanes 0 and 63
-//       fetch one halo column each.  Each input element is read from HBM once per step
-//       except the 2 rows shared by vertically adjacent units.  HBM-bound: 16 B per cell.
+//   gs_step_stream_k   one step per launch: a wave owns a 256-column strip (one 16-B load
+//       per lane per row and species), marches down `rows_per_unit` rows keeping a 3-row
+//       window in registers, and gets its left/right neighbours from the adjacent lanes
+//       with DPP wave shifts (no LDS, no extra memory traffic); only lanes 0 and 63 fetch
+//       one halo column each.  Each input element is read from HBM once per step except
+//       the 2 rows shared by vertically adjacent units.  HBM-bound: 16 B per cell-step.
+//   gs_step_tb_k<K>    the production kernel of gs_run: K <= 4 time steps per launch
+//       (temporal blocking), K register-resident time levels per wave, sacrificial edge
+//       lanes instead of halo loads.  ~16 B of HBM traffic per cell for K steps;
+//       VALU-issue bound for K >= 3.  Bit-identical to K single steps.
+//
+// GS_TB_ABLATE (1: no memory traffic, 2: no arithmetic) are timing experiments only
+// (profiles/r01_sweeps.md, "ablation"); the shipped build never defines it.
 #include "gs_kernels.h"
 
 #ifndef GS_MATH_FUSED
