@@ -1,0 +1,60 @@
+"""Randomised parity: hypothesis draws shapes, parameters, step counts and scheduling options
+(kernel, fused steps, unit height, row bands, in-process slabs); every combination must be
+bit-identical to the oracle.  Scheduling options never change results -- that is the property."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import oracle
+from grayscott_amd import Parameters, capi
+from tests.helpers import assert_bits_equal, gpu_run, oracle_params
+from tests.test_gpu_parity import args
+
+pytestmark = pytest.mark.gpu
+
+POW2 = [0.0, 0.125, 0.25, 0.5, 1.0]
+
+
+@st.composite
+def cases(draw):
+    rows = draw(st.integers(1, 140))
+    cols = draw(st.one_of(st.integers(1, 40), st.integers(240, 270), st.integers(480, 530), st.integers(990, 1040)))
+    steps = draw(st.integers(1, 13))
+    seed = draw(st.integers(0, 2 ** 16))
+    kernel = draw(st.sampled_from([capi.GS_KERNEL_AUTO, capi.GS_KERNEL_STREAM, capi.GS_KERNEL_TB, capi.GS_KERNEL_SIMPLE]))
+    fuse = draw(st.integers(0, 4))
+    rpb = draw(st.sampled_from([0, 1, 2, 3, 5, 8, 16, 33]))
+    split = draw(st.integers(0, 4))
+    slabs = draw(st.integers(1, 4))
+    w = [[draw(st.sampled_from(POW2)) for _ in range(3)] for _ in range(3)]
+    p = Parameters(weights=tuple(tuple(r) for r in w),
+                   diffusion_rate_u=draw(st.sampled_from([0.1, 0.2, 0.05])),
+                   diffusion_rate_v=draw(st.sampled_from([0.05, 0.1])),
+                   feed_rate=draw(st.sampled_from([0.014, 0.03, 0.0])),
+                   kill_rate=draw(st.sampled_from([0.054, 0.06])),
+                   time_step=draw(st.sampled_from([1.0, 0.5, 0.75])))
+    tiny = draw(st.booleans())  # sprinkle values near the flush-to-zero threshold
+    return rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@given(cases())
+def test_any_schedule_matches_the_oracle(built, case):
+    rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny = case
+    slabs = min(slabs, rows)
+    rng = np.random.default_rng(seed)
+    u0 = rng.random((rows, cols), dtype=np.float32)
+    v0 = (rng.random((rows, cols), dtype=np.float32) * np.float32(0.5)).astype(np.float32)
+    if tiny:
+        mask = rng.random((rows, cols)) < 0.3
+        v0[mask] = (v0[mask] * np.float32(1e-37)).astype(np.float32)
+        u0[rng.random((rows, cols)) < 0.05] = np.float32(3e-38)
+    if kernel in (capi.GS_KERNEL_STREAM, capi.GS_KERNEL_SIMPLE):
+        fuse = 0
+    ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True)
+    got_u, got_v, info = gpu_run(u0, v0, steps, params=p,
+                                 args=args(kernel=kernel, fuse_steps=fuse, rows_per_block=rpb, split=split,
+                                           devices=[0] * slabs))
+    what = f"{rows}x{cols} steps={steps} kernel={info[0]} fuse={fuse} rpb={rpb} split={split} slabs={slabs}"
+    assert_bits_equal(got_u, ref_u, "U " + what)
+    assert_bits_equal(got_v, ref_v, "V " + what)
