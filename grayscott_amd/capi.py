@@ -21,7 +21,7 @@ GS_ERR_UNSUPPORTED = -5
 GS_ERR_NOMEM = -6
 
 GS_MATH_STRICT, GS_MATH_FUSED = 0, 1
-GS_KERNEL_AUTO, GS_KERNEL_SIMPLE, GS_KERNEL_STREAM, GS_KERNEL_TB = 0, 1, 2, 3
+GS_KERNEL_AUTO, GS_KERNEL_SIMPLE, GS_KERNEL_STREAM, GS_KERNEL_TB, GS_KERNEL_LDS = 0, 1, 2, 3, 4
 GS_UNIQUE_ID_BYTES = 128
 
 # Every symbol include/gs_hip.h declares; tests check that the library exports them all.

@@ -350,6 +350,9 @@ int32_t launch_rows(gs_ctx *ctx, const GsStepArgs &a, hipStream_t stream, int fu
     case GS_KERNEL_STREAM:
         e = fused ? gs_launch_stream_fused(a, stream, &name) : gs_launch_stream_strict(a, stream, &name);
         break;
+    case GS_KERNEL_LDS:
+        e = fused ? gs_launch_lds_fused(a, stream, &name) : gs_launch_lds_strict(a, stream, &name);
+        break;
     default:
         return fail(GS_ERR_UNSUPPORTED, "kernel variant %d is not built", kernel);
     }

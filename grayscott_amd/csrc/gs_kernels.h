@@ -30,7 +30,8 @@ struct GsStepArgs {
 #define GS_DECLARE_LAUNCHERS(SUFFIX)                                                           \
     hipError_t gs_launch_simple_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name); \
     hipError_t gs_launch_stream_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name); \
-    hipError_t gs_launch_tb_##SUFFIX(const GsStepArgs &a, int k, hipStream_t s, const char **name);
+    hipError_t gs_launch_tb_##SUFFIX(const GsStepArgs &a, int k, hipStream_t s, const char **name); \
+    hipError_t gs_launch_lds_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name);
 
 GS_DECLARE_LAUNCHERS(strict)
 GS_DECLARE_LAUNCHERS(fused)

@@ -490,6 +490,112 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         tb_march<K, false>(a, ur0, ur1, strip, lane);
 }
 
+// ------------------------------------------------------------------------------------
+// LDS-staged variant (one step per launch): the (tile + halo) stencil window of a block is
+// staged in LDS, then every lane reads its 3 x 6 neighbourhood back with ds_read_b128 +
+// two ds_read_b32 per row and species.  Kept as a measured alternative to the register
+// sliding window of gs_step_stream_k (north_star names LDS staging explicitly): it moves the
+// same HBM bytes, but adds an LDS write + read pass and a barrier per tile, and loses the
+// row-to-row register reuse (each input row is read from LDS three times).  Slower than the
+// stream kernel on MI355X, so GS_KERNEL_AUTO never picks it.
+// ------------------------------------------------------------------------------------
+constexpr int kLdsTileRows = 16;          // output rows per block (38 KB of LDS -> 4 blocks per CU)
+constexpr int kLdsRowFloats = 256 + 8;    // 4 halo floats each side keep float4 alignment
+
+template <bool EDGE>
+__device__ __forceinline__ void lds_tile(const GsStepArgs &a, int tr0, int tr1, int c0, float *su, float *sv)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = c0 + lane * 4;
+    const ptrdiff_t pitch = a.pitch;
+    const bool lane_ok = !EDGE || (c < a.pitch);
+    const bool halo_l = (lane == 0) && (!EDGE || c0 > 0);
+    const bool halo_r = (lane == 63) && (!EDGE || c + 4 < a.pitch);
+    // stage rows [tr0 - 1, tr1 + 1) of both species; row r lands in LDS row (r - tr0 + 1)
+    const int nrows = tr1 - tr0 + 2;
+    for (int lr = wave; lr < nrows; lr += 4) {
+        const int r = tr0 - 1 + lr; // ghost rows exist physically, so every row is loadable
+        float4 fu = make_float4(0.f, 0.f, 0.f, 0.f), fv = fu;
+        if (lane_ok) {
+            fu = *reinterpret_cast<const float4 *>(a.in_u + (ptrdiff_t)r * pitch + c);
+            fv = *reinterpret_cast<const float4 *>(a.in_v + (ptrdiff_t)r * pitch + c);
+        }
+        float *du = su + lr * kLdsRowFloats + 4 + lane * 4;
+        float *dv = sv + lr * kLdsRowFloats + 4 + lane * 4;
+        *reinterpret_cast<float4 *>(du) = fu;
+        *reinterpret_cast<float4 *>(dv) = fv;
+        if (halo_l) {
+            du[-1] = a.in_u[(ptrdiff_t)r * pitch + c - 1];
+            dv[-1] = a.in_v[(ptrdiff_t)r * pitch + c - 1];
+        }
+        if (halo_r) {
+            du[4] = a.in_u[(ptrdiff_t)r * pitch + c + 4];
+            dv[4] = a.in_v[(ptrdiff_t)r * pitch + c + 4];
+        }
+    }
+    __syncthreads();
+
+    bool la[4], ra[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        la[k] = EDGE && (c + k == 0);
+        ra[k] = EDGE && (c + k + 1 >= a.cols);
+    }
+    auto read_row = [&](int lr) {
+        RowW w;
+        const float *pu = su + lr * kLdsRowFloats + 4 + lane * 4;
+        const float *pv = sv + lr * kLdsRowFloats + 4 + lane * 4;
+        const float4 fu = *reinterpret_cast<const float4 *>(pu);
+        const float4 fv = *reinterpret_cast<const float4 *>(pv);
+        w.u[1] = fu.x; w.u[2] = fu.y; w.u[3] = fu.z; w.u[4] = fu.w;
+        w.v[1] = fv.x; w.v[2] = fv.y; w.v[3] = fv.z; w.v[4] = fv.w;
+        w.u[0] = pu[-1]; w.u[5] = pu[4];
+        w.v[0] = pv[-1]; w.v[5] = pv[4];
+        return w;
+    };
+    for (int r = tr0 + wave; r < tr1; r += 4) {
+        const int lr = r - tr0 + 1;
+        const RowW m = read_row(lr - 1), z = read_row(lr), p = read_row(lr + 1);
+        const bool mrow = !EDGE || (r > 0) || a.top_present;
+        const bool prow = !EDGE || (r + 1 < a.rows) || a.bottom_present;
+        float4 nu, nv;
+        cell<EDGE>(a, m, z, p, 1, mrow, prow, la[0], ra[0], nu.x, nv.x);
+        cell<EDGE>(a, m, z, p, 2, mrow, prow, la[1], ra[1], nu.y, nv.y);
+        cell<EDGE>(a, m, z, p, 3, mrow, prow, la[2], ra[2], nu.z, nv.z);
+        cell<EDGE>(a, m, z, p, 4, mrow, prow, la[3], ra[3], nu.w, nv.w);
+        if (lane_ok) {
+            *reinterpret_cast<float4 *>(a.out_u + (ptrdiff_t)r * pitch + c) = nu;
+            *reinterpret_cast<float4 *>(a.out_v + (ptrdiff_t)r * pitch + c) = nv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_lds_k)(GsStepArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float su[(kLdsTileRows + 2) * kLdsRowFloats];
+    __shared__ __attribute__((aligned(16))) float sv[(kLdsTileRows + 2) * kLdsRowFloats];
+    const int strips = (a.cols + 255) >> 8;
+    const int chunk = blockIdx.x / strips;
+    const int strip = blockIdx.x - chunk * strips;
+    const int chunks_a = (a.ra1 - a.ra0 + kLdsTileRows - 1) / kLdsTileRows;
+    int tr0, tr1;
+    if (chunk < chunks_a) {
+        tr0 = a.ra0 + chunk * kLdsTileRows;
+        tr1 = min(tr0 + kLdsTileRows, a.ra1);
+    } else {
+        tr0 = a.rb0 + (chunk - chunks_a) * kLdsTileRows;
+        tr1 = min(tr0 + kLdsTileRows, a.rb1);
+    }
+    const int c0 = strip << 8;
+    const bool edge = (c0 == 0) || (c0 + 256 >= a.cols) || (tr0 == 0 && !a.top_present) ||
+                      (tr1 == a.rows && !a.bottom_present);
+    if (edge)
+        lds_tile<true>(a, tr0, tr1, c0, su, sv);
+    else
+        lds_tile<false>(a, tr0, tr1, c0, su, sv);
+}
+
 } // namespace
 
 hipError_t GS_SUFFIX(gs_launch_simple)(const GsStepArgs &a, hipStream_t s, const char **name)
@@ -546,4 +652,20 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     default: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4>); break;
     }
     return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), kargs, 0, s);
+}
+
+hipError_t GS_SUFFIX(gs_launch_lds)(const GsStepArgs &a, hipStream_t s, const char **name)
+{
+    if (name) *name = "lds-tile16/" GS_MATH_NAME;
+    if (a.cols <= 0) return hipErrorInvalidValue;
+    const long chunks = ((long)(a.ra1 - a.ra0) + kLdsTileRows - 1) / kLdsTileRows +
+                        ((long)(a.rb1 - a.rb0) + kLdsTileRows - 1) / kLdsTileRows;
+    if (chunks <= 0) return hipSuccess;
+    const long strips = (a.cols + 255) >> 8;
+    const long blocks = chunks * strips;
+    if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
+    GsStepArgs args = a;
+    void *kargs[] = {&args};
+    return hipLaunchKernel(reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_lds_k)), dim3((unsigned)blocks),
+                           dim3(256), kargs, 0, s);
 }

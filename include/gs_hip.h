@@ -88,7 +88,9 @@ typedef enum gs_kernel {
     GS_KERNEL_AUTO = 0,    /* best measured variant for the shape                          */
     GS_KERNEL_SIMPLE = 1,  /* one thread per cell, global loads only (cross-check kernel)  */
     GS_KERNEL_STREAM = 2,  /* register sliding window, 16-B loads, DPP halo exchange       */
-    GS_KERNEL_TB = 3       /* temporally blocked streaming kernel: fuse_steps steps / launch */
+    GS_KERNEL_TB = 3,      /* temporally blocked streaming kernel: fuse_steps steps / launch */
+    GS_KERNEL_LDS = 4      /* LDS-staged (tile + halo) window, one step per launch (measured
+                              alternative to STREAM; never chosen by AUTO)                   */
 } gs_kernel;
 
 /* Backend options: the C view of the Rust `CliArgs` (compute/shared/src/lib.rs:20-25 --

@@ -32,7 +32,7 @@ def _built(built):
 
 
 # ---- small and ragged shapes, random data ---------------------------------------------------
-@pytest.mark.parametrize("kernel", [capi.GS_KERNEL_SIMPLE, capi.GS_KERNEL_STREAM])
+@pytest.mark.parametrize("kernel", [capi.GS_KERNEL_SIMPLE, capi.GS_KERNEL_STREAM, capi.GS_KERNEL_LDS])
 @pytest.mark.parametrize("shape", STRESS_SHAPES + [(5, 256), (9, 257), (33, 255), (6, 1024), (40, 1030)])
 def test_stress_shapes_bit_exact(shape, kernel):
     for seed in (0, 1, 2):
@@ -217,7 +217,7 @@ def test_auto_row_bands_on_a_large_grid():
 
 
 # ---- non-default parameters (CLI overrides -k -f -t, ui/src/lib.rs:51-63) and weights ------
-@pytest.mark.parametrize("kernel", [capi.GS_KERNEL_SIMPLE, capi.GS_KERNEL_STREAM])
+@pytest.mark.parametrize("kernel", [capi.GS_KERNEL_SIMPLE, capi.GS_KERNEL_STREAM, capi.GS_KERNEL_LDS])
 def test_non_default_parameters(kernel):
     pk = ((1 / 6, 4 / 6, 1 / 6), (4 / 6, 0.0, 4 / 6), (1 / 6, 4 / 6, 1 / 6))
     for p in (Parameters(feed_rate=0.03, kill_rate=0.06, time_step=0.5),

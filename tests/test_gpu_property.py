@@ -21,7 +21,8 @@ def cases(draw):
     cols = draw(st.one_of(st.integers(1, 40), st.integers(240, 270), st.integers(480, 530), st.integers(990, 1040)))
     steps = draw(st.integers(1, 13))
     seed = draw(st.integers(0, 2 ** 16))
-    kernel = draw(st.sampled_from([capi.GS_KERNEL_AUTO, capi.GS_KERNEL_STREAM, capi.GS_KERNEL_TB, capi.GS_KERNEL_SIMPLE]))
+    kernel = draw(st.sampled_from([capi.GS_KERNEL_AUTO, capi.GS_KERNEL_STREAM, capi.GS_KERNEL_TB, capi.GS_KERNEL_SIMPLE,
+                                   capi.GS_KERNEL_LDS]))
     fuse = draw(st.integers(0, 4))
     rpb = draw(st.sampled_from([0, 1, 2, 3, 5, 8, 16, 33]))
     split = draw(st.integers(0, 4))
@@ -49,7 +50,7 @@ def test_any_schedule_matches_the_oracle(built, case):
         mask = rng.random((rows, cols)) < 0.3
         v0[mask] = (v0[mask] * np.float32(1e-37)).astype(np.float32)
         u0[rng.random((rows, cols)) < 0.05] = np.float32(3e-38)
-    if kernel in (capi.GS_KERNEL_STREAM, capi.GS_KERNEL_SIMPLE):
+    if kernel in (capi.GS_KERNEL_STREAM, capi.GS_KERNEL_SIMPLE, capi.GS_KERNEL_LDS):
         fuse = 0
     ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True)
     got_u, got_v, info = gpu_run(u0, v0, steps, params=p,
