@@ -401,3 +401,29 @@ def test_headline_grid_16384_equivalence_chain():
     cu, cv = oracle.run(u0[-n:, -n:], v0[-n:, -n:], 3)
     assert_bits_equal(results[1][0][-n + 3:, -n + 3:], cu[3:, 3:], "far corner U")
     assert_bits_equal(results[1][1][-n + 3:, -n + 3:], cv[3:, 3:], "far corner V")
+
+
+def test_huge_grid_32768_index_width():
+    """32768 x 32768 (2^30 cells, 4 GiB per plane: byte offsets exceed 32 bits): the seed region
+    evolves exactly like the oracle on a crop, the far field stays the exact fixed point, and
+    the last row / column (largest offsets) follow the clipped-window rule."""
+    rows = cols = 32768
+    steps = 9
+    sim = Simulation.new(Parameters(), args())
+    sp = sim.make_species([rows, cols])
+    sim.perform_steps(sp, steps)
+    in_u, in_v, _, _ = sp.in_out()
+    v = in_v.make_scalar_view(sim.context)
+    (r0, r1), (c0, c1) = oracle.seed_ranges(rows, cols)
+    m = steps + 2
+    R0, R1, C0, C1 = r0 - 2 * m, r1 + 2 * m, c0 - 2 * m, c1 + 2 * m
+    u0, v0 = oracle.init_species(rows, cols)
+    cu, cv = oracle.run(u0[R0:R1, C0:C1], v0[R0:R1, C0:C1], steps)
+    del u0, v0
+    inner = (slice(m, R1 - R0 - m), slice(m, C1 - C0 - m))
+    assert_bits_equal(v[R0:R1, C0:C1][inner], cv[inner], "crop V at 32768^2")
+    assert not v[:R0].any() and not v[R1:].any() and not v[:, :C0].any() and not v[:, C1:].any()
+    del v
+    u = in_u.make_scalar_view(sim.context)
+    assert_bits_equal(u[R0:R1, C0:C1][inner], cu[inner], "crop U at 32768^2")
+    assert (u[-1] == 1.0).all() and (u[:, -1] == 1.0).all() and (u[0] == 1.0).all()
