@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""The reference's own benchmark grid (compute/shared/src/benchmark.rs:28-83) on the HIP backend:
+shapes [2^k, 2*2^k] for k = 3..11, the "compute" workload (perform_steps only, then a sync so
+that the work is actually done), throughput in cells x steps per second as criterion reports it
+(Throughput::Elements(rows * cols * steps), :55-59).  Steps: a subset of the reference's 1..256.
+
+    python tools/criterion_grid.py [--cpu]     # --cpu adds the parallel(block(autovec)) port
+
+Prints a markdown table (median of 7 timed iterations after 2 warm-up iterations).
+"""
+import argparse
+import os
+
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # the CPU port forks/joins per step: do not spin
+import statistics
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from grayscott_amd import HipArgs, Parameters, Simulation  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu", action="store_true")
+    a = ap.parse_args()
+    steps_list = [1, 16, 256]
+    print("| rows x cols | " + " | ".join(f"HIP {s} steps" for s in steps_list) +
+          (" | CPU port 16 steps |" if a.cpu else " |"))
+    print("|---|" + "---|" * (len(steps_list) + (1 if a.cpu else 0)))
+    sim = Simulation.new(Parameters(), HipArgs(devices=[0]))
+    for k in range(3, 12):
+        size = 2 ** k
+        shape = (size, 2 * size)
+        species = sim.make_species(shape)
+        cells = shape[0] * shape[1]
+        row = [f"{shape[0]} x {shape[1]}"]
+        for steps in steps_list:
+            times = []
+            for it in range(9):
+                t0 = time.perf_counter()
+                sim.perform_steps(species, steps)
+                sim.context.sync()
+                if it >= 2:
+                    times.append(time.perf_counter() - t0)
+            row.append(f"{cells * steps / statistics.median(times) / 1e6:.1f}")
+        if a.cpu:
+            from oracle import cpu_parallel
+
+            try:
+                threads = len(os.sched_getaffinity(0))
+                quota = open("/sys/fs/cgroup/cpu.max").read().split()
+                if quota[0] != "max":
+                    threads = min(threads, max(1, int(int(quota[0]) / int(quota[1]))))
+            except (OSError, ValueError, AttributeError):
+                threads = os.cpu_count() or 1
+            cpu = cpu_parallel.ParallelSimulation(shape[0], shape[1], num_threads=threads)
+            cpu.perform_steps(16)
+            times = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                cpu.perform_steps(16)
+                times.append(time.perf_counter() - t0)
+            row.append(f"{cells * 16 / statistics.median(times) / 1e6:.1f}")
+            cpu.close()
+        print("| " + " | ".join(row) + " |", flush=True)
+    print("\n(Mcells x steps / s; HIP timings include the host-side enqueue and one sync per iteration, "
+          "as criterion's `b.iter(|| workload(...))` would)")
+
+
+if __name__ == "__main__":
+    main()
