@@ -147,32 +147,19 @@ class HipContext:
             pass
 
 
-class _PinnedOwner:
-    def __init__(self, lib, ptr):
-        self._lib, self._ptr = lib, ptr
-
-    def __del__(self):
-        try:
-            self._lib.gs_host_free(self._ptr)
-        except Exception:
-            pass
-
-
 def pinned_empty(shape: Sequence[int]) -> np.ndarray:
-    """float32 array in page-locked host memory (``gs_host_alloc``) for overlapped downloads."""
-    lib = capi.load()
-    n = int(np.prod(shape))
-    ptr = ctypes.c_void_p()
-    capi.check(lib.gs_host_alloc(ctypes.byref(ptr), max(n, 1) * 4))
-    buf = (ctypes.c_float * max(n, 1)).from_address(ptr.value)
-    arr = np.frombuffer(buf, dtype=np.float32, count=n).reshape(shape)
-    _PINNED[id(buf)] = (buf, _PinnedOwner(lib, ptr))  # keep the owner alive with the buffer
+    """float32 array in page-locked host memory (``gs_host_alloc``) for overlapped downloads.
+    The allocation is released when the last view of it is garbage-collected."""
     import weakref
-    weakref.finalize(arr.base if arr.base is not None else arr, _PINNED.pop, id(buf), None)
-    return arr
 
-
-_PINNED = {}
+    lib = capi.load()
+    count = int(np.prod(shape))
+    ptr = ctypes.c_void_p()
+    capi.check(lib.gs_host_alloc(ctypes.byref(ptr), max(count, 1) * 4))
+    buf = (ctypes.c_float * max(count, 1)).from_address(ptr.value)
+    root = np.frombuffer(buf, dtype=np.float32)        # every view's .base; does not own the memory
+    weakref.finalize(root, lib.gs_host_free, ctypes.c_void_p(ptr.value))
+    return root[:count].reshape(shape)
 
 
 class HipConcentration:
