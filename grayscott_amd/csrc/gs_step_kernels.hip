@@ -464,17 +464,33 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, see above
     const int strips = (a.cols + kTbCols - 1) / kTbCols;
     const int unit = blockIdx.x * 4 + wave;
-    const int chunk = unit / strips;
-    const int strip = unit - chunk * strips;
     const int rpu = a.rows_per_unit;
     const int chunks_a = (a.ra1 - a.ra0 + rpu - 1) / rpu;
     const int chunks_b = (a.rb1 - a.rb0 + rpu - 1) / rpu;
-    if (chunk >= chunks_a + chunks_b) return; // wave-uniform
+    const int chunks = chunks_a + chunks_b;
+    if (unit >= chunks * strips) return; // wave-uniform
+    // Dispatch order.  Units on a global edge take the general path, which is about twice as
+    // slow (per-lane selects); a slow unit that starts in the last round of a launch stretches
+    // its tail, so all edge units go first: the left-most and right-most strips of every chunk,
+    // then (below) the first and last chunk, then everything else.
+    const int er = ((strips - 1) * kTbCols + 4 >= a.cols && strips >= 2) ? 2 : 1; // edge strips on the right
+    const int ne = 1 + er;                                                        // ... per chunk
+    int chunk, strip;
+    if (strips <= ne) {
+        chunk = unit / strips;
+        strip = unit - chunk * strips;
+    } else if (unit < chunks * ne) {
+        chunk = unit / ne;
+        const int se = unit - chunk * ne;
+        strip = se == 0 ? 0 : strips - er + (se - 1);
+    } else {
+        const int v = unit - chunks * ne, ni = strips - ne;
+        chunk = v / ni;
+        strip = 1 + (v - chunk * ni);
+    }
     int ur0, ur1;
     if (chunk < chunks_a) {
-        // Dispatch order: the last chunk of the range first, then chunks 0, 1, 2, ...  The first
-        // and last chunks touch the global top/bottom edge and take the slower general path;
-        // starting them first keeps them out of the launch's tail.
+        // the last chunk of the range first, then chunks 0, 1, 2, ... (top / bottom edge chunks)
         const int cc = chunk == 0 ? chunks_a - 1 : chunk - 1;
         ur0 = a.ra0 + cc * rpu;
         ur1 = min(ur0 + rpu, a.ra1);
