@@ -65,6 +65,13 @@ __device__ __forceinline__ void react(const GsStepArgs &a, float u, float v, flo
     out_v = v + dv * a.dt;
 }
 
+// m ? a : b for a per-lane all-ones / all-zeros mask: one v_bfi_b32, a full-rate VALU op
+// (v_cndmask_b32 measured ~8x slower on gfx950: tools/ubench/valu_rate.hip).
+__device__ __forceinline__ float blend(uint32_t m, float a, float b)
+{
+    return __builtin_bit_cast(float, (m & __builtin_bit_cast(uint32_t, a)) | (~m & __builtin_bit_cast(uint32_t, b)));
+}
+
 // Map a linear "row slot" onto the two row ranges of GsStepArgs.
 __device__ __forceinline__ int range_row(const GsStepArgs &a, int slot)
 {
@@ -177,7 +184,7 @@ __device__ __forceinline__ RowW widen(const RowIn &r)
 // (wave-uniform), `la` / `ra` whether the left / right neighbour column is absent (per lane).
 template <bool EDGE>
 __device__ __forceinline__ void cell(const GsStepArgs &a, const RowW &m, const RowW &z,
-                                     const RowW &p, int k, bool mrow, bool prow, bool la, bool ra,
+                                     const RowW &p, int k, bool mrow, bool prow, uint32_t la, uint32_t ra,
                                      float &out_u, float &out_v)
 {
     const float u = z.u[k], v = z.v[k];
@@ -199,10 +206,10 @@ __device__ __forceinline__ void cell(const GsStepArgs &a, const RowW &m, const R
 #define GS_ROW_TAPS(R, WI, WITH_CENTRE)                                                        \
     {                                                                                          \
         const float wl = a.w[WI][0];                                                           \
-        const float wc = la ? a.w[WI][0] : a.w[WI][1];                                         \
-        const float wr = la ? a.w[WI][1] : a.w[WI][2];                                         \
-        const float ul = la ? u : R.u[k - 1], vl = la ? v : R.v[k - 1];                        \
-        const float ur = ra ? u : R.u[k + 1], vr = ra ? v : R.v[k + 1];                        \
+        const float wc = blend(la, a.w[WI][0], a.w[WI][1]);                                    \
+        const float wr = blend(la, a.w[WI][1], a.w[WI][2]);                                    \
+        const float ul = blend(la, u, R.u[k - 1]), vl = blend(la, v, R.v[k - 1]);              \
+        const float ur = blend(ra, u, R.u[k + 1]), vr = blend(ra, v, R.v[k + 1]);              \
         GS_TAP(acc_u, wl, ul, u); GS_TAP(acc_v, wl, vl, v);                                    \
         if (WITH_CENTRE) { GS_TAP(acc_u, wc, R.u[k], u); GS_TAP(acc_v, wc, R.v[k], v); }       \
         GS_TAP(acc_u, wr, ur, u); GS_TAP(acc_v, wr, vr, v);                                    \
@@ -245,11 +252,17 @@ __device__ __forceinline__ void march(const GsStepArgs &a, int ur0, int ur1, int
 #pragma unroll
     for (int g = 0; g < G; ++g) n[g] = fetch(ur0 + 1 + g);
 
-    bool la[4], ra[4];
+    // per-lane masks (all ones = that neighbour column is clipped away).  c is a multiple of 4,
+    // so only the first of a lane's four cells can sit on the global left edge.
+    uint32_t la[4], ra[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        la[k] = EDGE && (c + k == 0);
-        ra[k] = EDGE && (c + k + 1 >= a.cols);
+        la[k] = (EDGE && k == 0 && c == 0) ? 0xffffffffu : 0u;
+        ra[k] = (EDGE && (c + k + 1 >= a.cols)) ? 0xffffffffu : 0u;
+        if (EDGE) { // keep the masks opaque, or the compiler turns every blend back into v_cndmask
+            if (k == 0) asm volatile("" : "+v"(la[k]));
+            asm volatile("" : "+v"(ra[k]));
+        }
     }
 
     for (int r = ur0; r < ur1; r += G) {
@@ -388,11 +401,17 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
         return r;
     };
 
-    bool la[4], ra[4];
+    // per-lane masks (all ones = that neighbour column is clipped away).  c is a multiple of 4,
+    // so only the first of a lane's four cells can sit on the global left edge.
+    uint32_t la[4], ra[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        la[k] = EDGE && (c + k == 0);
-        ra[k] = EDGE && (c + k + 1 >= a.cols);
+        la[k] = (EDGE && k == 0 && c == 0) ? 0xffffffffu : 0u;
+        ra[k] = (EDGE && (c + k + 1 >= a.cols)) ? 0xffffffffu : 0u;
+        if (EDGE) { // keep the masks opaque, or the compiler turns every blend back into v_cndmask
+            if (k == 0) asm volatile("" : "+v"(la[k]));
+            asm volatile("" : "+v"(ra[k]));
+        }
     }
 
     RowW w[K][3]; // w[j][slot]: level-j rows, newest in slot (tick % 3)
@@ -552,11 +571,17 @@ __device__ __forceinline__ void lds_tile(const GsStepArgs &a, int tr0, int tr1, 
     }
     __syncthreads();
 
-    bool la[4], ra[4];
+    // per-lane masks (all ones = that neighbour column is clipped away).  c is a multiple of 4,
+    // so only the first of a lane's four cells can sit on the global left edge.
+    uint32_t la[4], ra[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        la[k] = EDGE && (c + k == 0);
-        ra[k] = EDGE && (c + k + 1 >= a.cols);
+        la[k] = (EDGE && k == 0 && c == 0) ? 0xffffffffu : 0u;
+        ra[k] = (EDGE && (c + k + 1 >= a.cols)) ? 0xffffffffu : 0u;
+        if (EDGE) { // keep the masks opaque, or the compiler turns every blend back into v_cndmask
+            if (k == 0) asm volatile("" : "+v"(la[k]));
+            asm volatile("" : "+v"(ra[k]));
+        }
     }
     auto read_row = [&](int lr) {
         RowW w;
