@@ -21,6 +21,10 @@ struct GsStepArgs {
     int32_t top_present, bottom_present;
     int32_t ghost;         // ghost rows stored above / below the slab (>= fused steps on seams)
     int32_t rows_per_unit; // rows one wave marches over
+    // Tapered tail of range a (temporal-blocking kernel, filled in by its launcher): the first
+    // `big_chunks` chunks have rows_per_unit rows, the rest `small_rpu` rows, so that the units
+    // dispatched last are short and the launch drains quickly.
+    int32_t big_chunks, small_rpu;
     float w[3][3];         // stencil weights, row-major (parameters.rs:87-88)
     float du, dv, feed, feed_plus_kill, dt;
 };

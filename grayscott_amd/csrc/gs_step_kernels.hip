@@ -484,7 +484,8 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     const int strips = (a.cols + kTbCols - 1) / kTbCols;
     const int unit = blockIdx.x * 4 + wave;
     const int rpu = a.rows_per_unit;
-    const int chunks_a = (a.ra1 - a.ra0 + rpu - 1) / rpu;
+    const int small = a.small_rpu;
+    const int chunks_a = a.big_chunks + (a.ra1 - a.ra0 - a.big_chunks * rpu + small - 1) / small;
     const int chunks_b = (a.rb1 - a.rb0 + rpu - 1) / rpu;
     const int chunks = chunks_a + chunks_b;
     if (unit >= chunks * strips) return; // wave-uniform
@@ -511,8 +512,13 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     if (chunk < chunks_a) {
         // the last chunk of the range first, then chunks 0, 1, 2, ... (top / bottom edge chunks)
         const int cc = chunk == 0 ? chunks_a - 1 : chunk - 1;
-        ur0 = a.ra0 + cc * rpu;
-        ur1 = min(ur0 + rpu, a.ra1);
+        if (cc < a.big_chunks) {
+            ur0 = a.ra0 + cc * rpu;
+            ur1 = ur0 + rpu;
+        } else { // tapered tail: short units are dispatched last
+            ur0 = a.ra0 + a.big_chunks * rpu + (cc - a.big_chunks) * small;
+            ur1 = min(ur0 + small, a.ra1);
+        }
     } else {
         ur0 = a.rb0 + (chunk - chunks_a) * rpu;
         ur1 = min(ur0 + rpu, a.rb1);
@@ -677,13 +683,29 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     if (k < 1 || k > 4 || a.cols <= 0 || a.rows_per_unit <= 0) return hipErrorInvalidValue;
     if (name) *name = names[k - 1];
     const long rpu = a.rows_per_unit;
-    const long chunks = ((long)(a.ra1 - a.ra0) + rpu - 1) / rpu + ((long)(a.rb1 - a.rb0) + rpu - 1) / rpu;
+    const long rows_a = (long)a.ra1 - a.ra0;
+    const long strips = (a.cols + kTbCols - 1) / kTbCols;
+    // Tapered tail: when the launch has many more units than the chip has wave slots (2048 at
+    // 2 waves per SIMD), the last ~2 x 2048 units are cut to a quarter of the unit height, so that
+    // the drain phase at the end of the launch is short (dependent launches cannot overlap).
+    long big_chunks = rows_a > 0 ? rows_a / rpu : 0, small = rpu;
+    const long quarter = rpu / 4 >= 2L * k ? rpu / 4 : 2L * k;
+    if (quarter < rpu && (rows_a / rpu) * strips >= 8 * 2048) {
+        const long small_chunks = (2 * 2048 + strips - 1) / strips;
+        long small_rows = small_chunks * quarter;
+        if (small_rows > rows_a / 4) small_rows = rows_a / 4;
+        big_chunks = (rows_a - small_rows) / rpu;
+        small = quarter;
+    }
+    const long chunks_a = rows_a > 0 ? big_chunks + (rows_a - big_chunks * rpu + small - 1) / small : 0;
+    const long chunks = chunks_a + ((long)(a.rb1 - a.rb0) + rpu - 1) / rpu;
     if (chunks <= 0) return hipSuccess;
     if (k > a.ghost && (a.top_present || a.bottom_present)) return hipErrorInvalidValue;
-    const long strips = (a.cols + kTbCols - 1) / kTbCols;
     const long blocks = (chunks * strips + 3) / 4;
     if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
     GsStepArgs args = a;
+    args.big_chunks = (int32_t)big_chunks;
+    args.small_rpu = (int32_t)small;
     void *kargs[] = {&args};
     const void *fn = nullptr;
     switch (k) {
