@@ -690,7 +690,7 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // the drain phase at the end of the launch is short (dependent launches cannot overlap).
     long big_chunks = rows_a > 0 ? rows_a / rpu : 0, small = rpu;
     const long quarter = rpu / 4 >= 2L * k ? rpu / 4 : 2L * k;
-    if (quarter < rpu && (rows_a / rpu) * strips >= 8 * 2048) {
+    if (quarter < rpu && (rows_a / rpu) * strips >= 4 * 2048) {
         const long small_chunks = (2 * 2048 + strips - 1) / strips;
         long small_rows = small_chunks * quarter;
         if (small_rows > rows_a / 4) small_rows = rows_a / 4;
