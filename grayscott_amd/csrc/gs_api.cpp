@@ -314,8 +314,8 @@ int32_t refresh_ghosts(gs_ctx *ctx, gs_field *f)
     return GS_OK;
 }
 
-// Rows each wave marches over.  Measured at 16384^2 (profiles/r01_sweeps.md): short units win --
-// 16 rows for single steps, 32 for 4 fused steps (redundant rows 2K/rpu vs tail effects).
+// Rows each wave marches over when nothing was tuned on line (slab chains, short runs).  Measured
+// at 16384^2 (profiles/r01_sweeps.md, sweep17/18): 16 rows for single steps, 128 for 4 fused steps.
 int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse)
 {
     if (ctx->o.rows_per_block > 0) return ctx->o.rows_per_block;
@@ -323,7 +323,7 @@ int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fu
         ctx->tuned_cols == (uint64_t)cols && ctx->total_slabs() == 1)
         return ctx->tuned_rpu;
     const long strips = (cols + 247) / 248;
-    const long want = fuse > 1 ? 8L * fuse : 16;
+    const long want = fuse > 1 ? 32L * fuse : 16;
     long rpu = ((long)rows * strips + 16383) / 16384; // keep >= 16384 waves per launch when possible
     if (rpu > want) rpu = want;
     if (rpu < 2L * fuse) rpu = 2L * fuse;
