@@ -199,6 +199,20 @@ def main() -> int:
                  "note": "library default for large single-GPU grids: the slab is scheduled as row bands "
                          "whose passes overlap (several concurrent launches per pass)"}
         sim_b.context.close()
+        del species_b, sim_b
+        # informational: the fused-tap flavour (GS_MATH_FUSED: bit-identical wherever no sub-normal
+        # intermediate occurs, |diff| <= 1e-37 elsewhere -- inside north_star's 1e-5 tolerance)
+        sim_c = Simulation.new(Parameters(), HipArgs(devices=[local_rank], math=capi.GS_MATH_FUSED, split=1))
+        species_c = sim_c.make_species([rows, cols])
+        sim_c.perform_steps(species_c, max(args.warmup, 120))
+        sim_c.context.sync()
+        tc = time.perf_counter()
+        sim_c.perform_steps(species_c, args.steps)
+        sim_c.context.sync()
+        tc = time.perf_counter() - tc
+        fused = {"kernel": sim_c.context.info()[0], "value": rows * cols * args.steps / tc / 1e6}
+        sim_c.context.close()
+        del species_c, sim_c
     launch_ms = event_ms / passes
     per_launch_bytes = BYTES_PER_CELL_STEP * (cells / args.gpus) * args.steps / passes
     achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9
@@ -242,6 +256,7 @@ def main() -> int:
     }
     if extra is not None:
         result["default_schedule"] = extra
+        result["fused_flavour"] = fused
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
