@@ -154,10 +154,10 @@ struct gs_ctx {
     uint64_t launches = 0;
     // rows-per-unit tuned on line for (rows, cols, fuse) of the last single-slab gs_run
     uint64_t tuned_rows = 0, tuned_cols = 0;
-    int tuned_fuse = 0, tuned_rpu = 0, tuned_split = 0;
+    int tuned_fuse = 0, tuned_rpu = 0, tuned_split = 0, tuned_k = 0; // tuned_k: fused steps per pass chosen
     // tuning in progress (may span several gs_run calls): next candidate, best so far
     uint64_t tune_rows = 0, tune_cols = 0;
-    int tune_fuse = 0, tune_next = 0, tune_best_rpu = 0, tune_best_split = 0;
+    int tune_fuse = 0, tune_next = 0, tune_best_rpu = 0, tune_best_split = 0, tune_best_k = 0;
     float tune_best_ms = 0.f;
     int total_slabs() const { return world * (int)slabs.size(); }
     int global_index(int i) const { return rank * (int)slabs.size() + i; }
@@ -319,7 +319,7 @@ int32_t refresh_ghosts(gs_ctx *ctx, gs_field *f)
 int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse)
 {
     if (ctx->o.rows_per_block > 0) return ctx->o.rows_per_block;
-    if (ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse && ctx->tuned_rows == (uint64_t)rows &&
+    if (ctx->tuned_rpu > 0 && ctx->tuned_k == fuse && ctx->tuned_rows == (uint64_t)rows &&
         ctx->tuned_cols == (uint64_t)cols && ctx->total_slabs() == 1)
         return ctx->tuned_rpu;
     const long strips = (cols + 247) / 248;
@@ -441,7 +441,7 @@ int bands_for(const gs_ctx *ctx, const gs_field *f, int fuse)
 {
     if (ctx->total_slabs() != 1 || fuse < 2) return 1;
     int V = ctx->o.split;
-    if (V == 0 && ctx->tuned_split > 0 && ctx->tuned_fuse == fuse && ctx->tuned_rows == f->rows &&
+    if (V == 0 && ctx->tuned_split > 0 && ctx->tuned_k == fuse && ctx->tuned_rows == f->rows &&
         ctx->tuned_cols == f->cols)
         return clamp_bands(f, fuse, ctx->tuned_split);
     if (V == 0) V = (f->rows * f->cols >= (1ull << 26)) ? 2 : 1; // measured: pays on large grids
@@ -978,20 +978,24 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     const bool tunable = ctx->total_slabs() == 1 && fuse > 1 && ctx->o.rows_per_block == 0 &&
                          !(ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse && ctx->tuned_rows == u0->rows &&
                            ctx->tuned_cols == u0->cols);
-    auto advance = [&](int V) -> int32_t {
-        const int32_t st = V > 1 ? step_bands(ctx, u[in], v[in], u[1 - in], v[1 - in], fuse, V)
-                                 : step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], fuse);
+    auto advance = [&](int V, int k) -> int32_t {
+        const int32_t st = V > 1 ? step_bands(ctx, u[in], v[in], u[1 - in], v[1 - in], k, V)
+                                 : step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], k);
         in = 1 - in;
-        n += (uint64_t)fuse;
+        n += (uint64_t)k;
         return st;
     };
     if (tunable) {
         // phase A: unit heights with the default band count; phase B: other band counts with the
-        // best unit height (only when the band count is not pinned by the options)
+        // best unit height (when the band count is not pinned); phase C: fewer fused steps per pass
+        // with the best of A and B (when fuse_steps is not pinned) -- on small, cache-resident grids
+        // the 2K redundant rows per unit can cost more than the extra passes.
         static const int cand[] = {8, 12, 16, 24, 32, 48, 64, 96, 128};
         static const int alt[] = {1, 2, 3};
+        static const int altk[] = {3, 2};
         const int ncand = (int)(sizeof cand / sizeof cand[0]);
         const int nalt = ctx->o.split == 0 ? (int)(sizeof alt / sizeof alt[0]) : 0;
+        const int nk = ctx->o.fuse_steps == 0 ? (int)(sizeof altk / sizeof altk[0]) : 0;
         const uint64_t cells = u0->rows * u0->cols;
         const int reps = cells >= (1ull << 24) ? 2 : (cells >= (1ull << 22) ? 4 : 8); // passes per candidate
         if (ctx->tune_rows != u0->rows || ctx->tune_cols != u0->cols || ctx->tune_fuse != fuse) {
@@ -1001,34 +1005,40 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
             ctx->tune_next = 0;
             ctx->tune_best_rpu = 0;
             ctx->tune_best_split = 0;
+            ctx->tune_best_k = 0;
             ctx->tune_best_ms = 0.f;
         }
         const int V0 = bands_for(ctx, u0, fuse);
         SlabRt &sl = ctx->slabs[0];
         GS_HIP(hipSetDevice(sl.device));
         bool warm = n > 0; // a pass of this call already ran
-        while (ctx->tune_next < ncand + nalt) {
-            int rpu, V;
+        while (ctx->tune_next < ncand + nalt + nk) {
+            int rpu, V, k = fuse;
             if (ctx->tune_next < ncand) {
                 rpu = cand[ctx->tune_next];
                 V = V0;
                 if (rpu < 2 * fuse || (uint64_t)rpu > u0->rows) { ctx->tune_next++; continue; }
-            } else {
+            } else if (ctx->tune_next < ncand + nalt) {
                 rpu = ctx->tune_best_rpu;
                 V = clamp_bands(u0, fuse, alt[ctx->tune_next - ncand]);
                 if (rpu == 0 || V == V0 || V != alt[ctx->tune_next - ncand]) { ctx->tune_next++; continue; }
+            } else {
+                rpu = ctx->tune_best_rpu;
+                V = ctx->tune_best_split;
+                k = altk[ctx->tune_next - ncand - nalt];
+                if (rpu == 0 || k >= fuse) { ctx->tune_next++; continue; }
             }
-            const uint64_t passes_left = (steps - n) / (uint64_t)fuse;
+            const uint64_t passes_left = (steps - n) / (uint64_t)k;
             if (passes_left < (uint64_t)reps + (warm ? 0 : 1)) break; // continue in the next gs_run
             ctx->o.rows_per_block = rpu;
             int32_t st = GS_OK;
             if (!warm) { // untimed pass first
-                st = advance(V);
+                st = advance(V, k);
                 warm = true;
             }
             if (st == GS_OK) st = join_bands(ctx, sl.compute);
             if (st == GS_OK && hipEventRecord(sl.tune0, sl.compute) != hipSuccess) st = fail(GS_ERR_HIP, "hipEventRecord failed");
-            for (int r = 0; r < reps && st == GS_OK; ++r) st = advance(V);
+            for (int r = 0; r < reps && st == GS_OK; ++r) st = advance(V, k);
             ctx->o.rows_per_block = 0;
             if (st == GS_OK) st = join_bands(ctx, sl.compute);
             float ms = 0.f;
@@ -1036,24 +1046,33 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
                                 hipEventElapsedTime(&ms, sl.tune0, sl.tune1) != hipSuccess))
                 st = fail(GS_ERR_HIP, "timing a tuning pass failed");
             if (st != GS_OK) return st;
+            ms /= (float)(reps * k); // per time step
             // prefer the incumbent unless the newcomer is clearly (> 1 %) faster
             if (ctx->tune_best_rpu == 0 || ms < 0.99f * ctx->tune_best_ms) {
                 ctx->tune_best_ms = ms;
                 ctx->tune_best_rpu = rpu;
                 ctx->tune_best_split = V;
+                ctx->tune_best_k = k;
             }
             ctx->tune_next++;
         }
-        if (ctx->tune_next >= ncand + nalt && ctx->tune_best_rpu > 0) {
+        if (ctx->tune_next >= ncand + nalt + nk && ctx->tune_best_rpu > 0) {
             ctx->tuned_rpu = ctx->tune_best_rpu;
             ctx->tuned_split = ctx->tune_best_split;
+            ctx->tuned_k = ctx->tune_best_k;
             ctx->tuned_fuse = fuse;
             ctx->tuned_rows = u0->rows;
             ctx->tuned_cols = u0->cols;
         }
     }
-    const int V = bands_for(ctx, u0, fuse);
-    while (n < steps) GS_TRY(advance(V));
+    const bool tuned = ctx->total_slabs() == 1 && ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse &&
+                       ctx->tuned_rows == u0->rows && ctx->tuned_cols == u0->cols && ctx->tuned_k > 0;
+    const int kk = tuned ? ctx->tuned_k : fuse;
+    const int V = bands_for(ctx, u0, kk);
+    while (n < steps) {
+        const int k = (steps - n) >= (uint64_t)kk ? kk : (int)(steps - n);
+        GS_TRY(advance(k == kk ? V : 1, k));
+    }
     if (result_slot) *result_slot = in;
     return GS_OK;
 }
