@@ -196,8 +196,8 @@ def main() -> int:
         sim_b.context.sync()
         tb = time.perf_counter() - tb
         extra = {"schedule": sim_b.context.info()[0], "value": rows * cols * args.steps / tb / 1e6,
-                 "note": "library default for large single-GPU grids: the slab is scheduled as row bands "
-                         "whose passes overlap (several concurrent launches per pass)"}
+                 "note": "library default: unit height, row bands (@RxV: V > 1 = several concurrent "
+                         "launches per pass whose tails overlap) and fused steps chosen on line"}
         sim_b.context.close()
         del species_b, sim_b
         # informational: the fused-tap flavour (GS_MATH_FUSED: bit-identical wherever no sub-normal
