@@ -78,6 +78,8 @@ class HipContext {
     HipContext &operator=(const HipContext &) = delete;
     gs_ctx *get() const { return ctx_; }
     void sync() const { check(gs_sync(ctx_)); }
+    // waits for the asynchronous downloads enqueued so far (not for later steps)
+    void download_wait() const { check(gs_download_wait(ctx_)); }
 
   private:
     gs_ctx *ctx_ = nullptr;
@@ -135,6 +137,14 @@ class HipConcentration {
         if (target_shape != shape_) throw std::logic_error("write_scalar_view: target shape mismatch");
         check(gs_field_download(c->get(), f_, target));
     }
+    // write_scalar_view_after (data/src/concentration/gpu/image/mod.rs:196-206): enqueue the
+    // download behind the steps already enqueued; `target` (ideally from PinnedImage) is valid
+    // after HipContext::download_wait()
+    void write_scalar_view_after(Context &c, Precision *target, Shape target_shape)
+    {
+        if (target_shape != shape_) throw std::logic_error("write_scalar_view_after: target shape mismatch");
+        check(gs_field_download_async(c->get(), f_, target));
+    }
     gs_field *raw() const { return f_; }
 
   private:
@@ -145,6 +155,27 @@ class HipConcentration {
     Context ctx_;
     gs_field *f_ = nullptr;
     Shape shape_{};
+};
+
+// Page-locked host image for overlapped downloads (gs_host_alloc / gs_host_free).
+class PinnedImage {
+  public:
+    explicit PinnedImage(Shape s) : shape_(s)
+    {
+        void *p = nullptr;
+        check(gs_host_alloc(&p, (uint64_t)s[0] * s[1] * sizeof(Precision)));
+        data_ = static_cast<Precision *>(p);
+    }
+    ~PinnedImage() { gs_host_free(data_); }
+    PinnedImage(const PinnedImage &) = delete;
+    PinnedImage &operator=(const PinnedImage &) = delete;
+    Precision *data() { return data_; }
+    const Precision *data() const { return data_; }
+    Shape shape() const { return shape_; }
+
+  private:
+    Precision *data_ = nullptr;
+    Shape shape_;
 };
 
 // Pair of concentrations, slot 0 = input, slot 1 = output (concentration/mod.rs:140-187).
@@ -210,6 +241,10 @@ class Species {
     {
         v_.in().write_scalar_view(context_, target, target_shape);
     }
+    void write_result_view_after(PinnedImage &image)
+    {
+        v_.in().write_scalar_view_after(context_, image.data(), image.shape());
+    }
 
   private:
     Species(Context c, Evolving u, Evolving v) : context_(std::move(c)), u_(std::move(u)), v_(std::move(v)) {}
@@ -237,6 +272,13 @@ class Simulation {
             species.u().swap_slots();
             species.v().swap_slots();
         }
+    }
+    // SimulateStep::perform_step (compute/shared/src/cpu.rs:21-28): one gs_step, then flip
+    void perform_step(Species &species) const
+    {
+        check(gs_step(context_->get(), species.u().in().raw(), species.v().in().raw(), species.u().out().raw(),
+                      species.v().out().raw()));
+        species.flip();
     }
     const Context &context() const { return context_; }
 

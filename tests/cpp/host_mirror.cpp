@@ -19,7 +19,14 @@ int main(int argc, char **argv)
     try {
         gs::Simulation sim = gs::Simulation::new_(gs::Parameters());
         gs::Species species = sim.make_species({rows, cols});
-        sim.perform_steps(species, steps);
+        // the driver's pattern (simulate/src/main.rs:99-106): steps, asynchronous image, more steps
+        const std::size_t first = steps / 2;
+        sim.perform_steps(species, first);
+        gs::PinnedImage image({rows, cols});
+        species.write_result_view_after(image);
+        if (steps - first > 0) sim.perform_steps(species, steps - first - 1);
+        if (steps - first > 0) sim.perform_step(species);
+        species.context()->download_wait();
         std::vector<float> v(rows * cols);
         species.write_result_view(v.data(), {rows, cols});
         std::vector<float> u = species.u().in().make_scalar_view(species.context());
@@ -34,6 +41,7 @@ int main(int argc, char **argv)
         if (!f) return 4;
         std::fwrite(u.data(), sizeof(float), u.size(), f);
         std::fwrite(v.data(), sizeof(float), v.size(), f);
+        std::fwrite(image.data(), sizeof(float), rows * cols, f); // V after steps/2 steps
         std::fclose(f);
     } catch (const gs::HipError &e) {
         std::fprintf(stderr, "HipError: %s\n", e.what());

@@ -38,7 +38,8 @@ def test_cpp_mirror_matches_oracle(exe, tmp_path):
     out = tmp_path / "o.bin"
     r = subprocess.run([exe, str(rows), str(cols), str(steps), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    data = np.fromfile(out, np.float32).reshape(2, rows, cols)
+    data = np.fromfile(out, np.float32).reshape(3, rows, cols)
     u0, v0 = oracle.init_species(rows, cols)
     ref_u, ref_v = oracle.run(u0, v0, steps)
     assert data[0].tobytes() == ref_u.tobytes() and data[1].tobytes() == ref_v.tobytes()
+    assert data[2].tobytes() == oracle.run(u0, v0, steps // 2)[1].tobytes()  # the asynchronous image
