@@ -403,6 +403,31 @@ def test_headline_grid_16384_equivalence_chain():
     assert_bits_equal(results[1][1][-n + 3:, -n + 3:], cv[3:, 3:], "far corner V")
 
 
+@pytest.mark.parametrize("kw", [dict(kernel=capi.GS_KERNEL_SIMPLE), dict(kernel=capi.GS_KERNEL_STREAM), dict(),
+                                dict(kernel=capi.GS_KERNEL_LDS), dict(devices=[0, 0]), dict(math=capi.GS_MATH_FUSED)])
+def test_non_finite_values_spread_like_the_reference(kw):
+    """NaN / Inf cells: the same cells are non-finite as in the oracle after every step count and
+    all finite cells are bit-identical (NaN payloads are not compared: x86 and the GPU quiet NaNs
+    differently).  Checks that skipped centre taps, blends and sacrificial lanes neither hide nor
+    invent non-finite values."""
+    u0, v0 = stress_fields((40, 300), 17)
+    u0[5, 7] = np.nan
+    v0[20, 100] = np.inf
+    u0[39, 299] = -np.inf
+    v0[0, 0] = np.nan
+    for steps in (1, 3, 6):
+        ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True)
+        got_u, got_v, _ = gpu_run(u0, v0, steps, args=args(**kw))
+        for got, ref, name in ((got_u, ref_u, "U"), (got_v, ref_v, "V")):
+            bad_ref, bad_got = ~np.isfinite(ref), ~np.isfinite(got)
+            assert np.array_equal(np.isnan(ref), np.isnan(got)), f"{name} NaN positions, {steps} steps, {kw}"
+            assert np.array_equal(bad_ref, bad_got), f"{name} non-finite positions"
+            fin = ~bad_ref
+            assert np.array_equal(got[fin].view(np.uint32), ref[fin].view(np.uint32)), f"{name} finite cells"
+            inf = np.isinf(ref)
+            assert np.array_equal(got[inf], ref[inf]), f"{name} infinities (sign)"
+
+
 def test_huge_grid_32768_index_width():
     """32768 x 32768 (2^30 cells, 4 GiB per plane: byte offsets exceed 32 bits): the seed region
     evolves exactly like the oracle on a crop, the far field stays the exact fixed point, and
