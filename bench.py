@@ -109,6 +109,10 @@ def main() -> int:
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational band-schedule leg")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="N > 1 on a 1-GPU box: all ranks share GPU 0 and torch.distributed uses gloo; needs "
+                         "GS_RCCL_LIBRARY to name a transport that accepts several ranks per device "
+                         "(tests/cpp/shm_transport.cpp).  Checks the code path, the numbers mean nothing")
     args = ap.parse_args()
 
     import torch
@@ -128,14 +132,23 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         return 2
+    if args.rehearsal:
+        if world > 1 and not os.environ.get("GS_RCCL_LIBRARY"):
+            print("bench.py: --rehearsal needs GS_RCCL_LIBRARY", file=sys.stderr)
+            return 2
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    red_dev = "cpu" if args.rehearsal else "cuda"   # where the bootstrap / reduction tensors live
 
     unique_id = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-        buf = torch.zeros(capi.GS_UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if args.rehearsal:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        buf = torch.zeros(capi.GS_UNIQUE_ID_BYTES, dtype=torch.uint8, device=red_dev)
         if rank == 0:
             buf.copy_(torch.frombuffer(bytearray(capi.get_unique_id()), dtype=torch.uint8))
         dist.broadcast(buf, src=0)
@@ -172,7 +185,7 @@ def main() -> int:
     wall = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([wall, event_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, event_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, event_ms = float(t[0]), float(t[1])
 
@@ -230,7 +243,7 @@ def main() -> int:
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not args.rehearsal else "synthetic (REHEARSAL: ranks share one GPU, not a measurement)",
         "config": {
             "workload": f"{rows}x{cols} f32 (rows x cols), Species::new init, default feed/kill, "
                         f"double-buffered U/V in HBM",

@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -86,9 +87,13 @@ Rccl *rccl()
     // function-local static: initialised once, thread-safe (C++11)
     static Rccl *const instance = []() -> Rccl * {
         static Rccl r;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        // GS_RCCL_LIBRARY names the library to bind instead of the system's librccl (a custom
+        // RCCL build; the tests' shared-memory transport double, tests/cpp/shm_transport.cpp)
+        const char *user = std::getenv("GS_RCCL_LIBRARY");
+        for (const char *name : {user, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (!name || !*name) continue;
             r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r.handle) break;
+            if (r.handle || name == user) break; // an explicit choice never falls back silently
         }
         if (!r.handle) return nullptr;
         bool ok = true;

@@ -26,9 +26,10 @@ def oracle_params(p: Parameters) -> oracle.Params:
     return q
 
 
-def species_from_arrays(sim: Simulation, u0: np.ndarray, v0: np.ndarray) -> Species:
+def species_from_arrays(sim: Simulation, u0: np.ndarray, v0: np.ndarray, shape=None) -> Species:
+    """``u0``/``v0`` hold this process's rows; ``shape`` is the global shape when they differ."""
     ctx = sim.context
-    shape = u0.shape
+    shape = shape or u0.shape
     u = Evolving([HipConcentration(ctx, shape), HipConcentration(ctx, shape)])
     v = Evolving([HipConcentration(ctx, shape), HipConcentration(ctx, shape)])
     u.in_out()[0].upload(ctx, u0)

@@ -1,11 +1,18 @@
 """The multi-process leg (one process per rank, RCCL ncclSend/ncclRecv inside libgs_hip.so).
 
-A 1-GPU box cannot give every rank its own GPU, so both ranks are put on device 0; RCCL may
-refuse that ("duplicate GPU"), in which case the test is skipped and the in-process slab tests
-(tests/test_gpu_parity.py::test_row_slabs_*) remain the coverage of the exchange schedule.
-With >= 2 visible GPUs each rank takes its own device.
+A 1-GPU box cannot give every rank its own GPU, so all ranks are put on device 0.  RCCL refuses
+that ("duplicate GPU"), so there are two legs:
+
+* ``transport="rccl"``: the real library; skipped when RCCL refuses the rank layout (with >= 2
+  visible GPUs each rank takes its own device and the test runs);
+* ``transport="shm"``: ``GS_RCCL_LIBRARY`` points the library's loader at a test double
+  (tests/cpp/shm_transport.cpp: the same eight nccl* entry points over shared-memory mailboxes), so
+  that everything else on the multi-process path -- rank-local slabs, K-row send/recv groups and
+  their plane offsets, ghost-depth tracking and refreshes, the remainder pass, downloads of the
+  local rows -- runs for real in N processes and is compared bit for bit with the oracle.
 """
 import os
+import subprocess
 import socket
 import sys
 
@@ -23,11 +30,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, rows, cols, steps, out_dir):
+def _worker(rank, world, port, rows, cols, steps, out_dir, transport_lib, seed):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if transport_lib:
+        os.environ["GS_RCCL_LIBRARY"] = transport_lib
     import torch.distributed as dist
 
     from grayscott_amd import GsError, HipArgs, Parameters, Simulation, capi
@@ -40,10 +49,17 @@ def _worker(rank, world, port, rows, cols, steps, out_dir):
         sim = Simulation.new(Parameters(), HipArgs(devices=[device], rank=info.rank, world=info.world,
                                                    unique_id=info.unique_id))
     except GsError as e:
+        if transport_lib:
+            raise                      # the double has no reason to refuse
         open(os.path.join(out_dir, f"skip{rank}"), "w").write(str(e))
         return
-    species = sim.make_species([rows, cols])
     r0, r1 = gsd.slab_range(rows, world, rank)
+    if seed is None:
+        species = sim.make_species([rows, cols])
+    else:                              # stress fields: every slab boundary carries signal from step 1
+        from tests.helpers import species_from_arrays, stress_fields
+        u0, v0 = stress_fields((rows, cols), seed)
+        species = species_from_arrays(sim, u0[r0:r1], v0[r0:r1], shape=(rows, cols))
     assert species.u.in_out()[0].local_rows() == (r0, r1)
     sim.perform_steps(species, steps)          # fused passes + K-row RCCL exchanges
     for _ in range(3):
@@ -59,16 +75,50 @@ def _worker(rank, world, port, rows, cols, steps, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.fixture(scope="module")
+def shm_transport(built):
+    """Compile the librccl test double (host code only; hipcc for the HIP runtime headers)."""
+    from grayscott_amd import _build
+
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(out_dir, "libshm_transport.so")
+    src = os.path.join(ROOT, "tests", "cpp", "shm_transport.cpp")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.run([_build.hipcc(), "-O2", "-fPIC", "-shared", "-std=c++17", "-x", "hip", "--offload-arch=gfx950",
+                        src, "-o", lib, "-lrt", "-lpthread"], check=True)
+    return lib
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_rccl_ranks_match_oracle(tmp_path, built, world):
+    _ranks_match_oracle(tmp_path, world, 96, 300, 22, "", None)
+
+
+@pytest.mark.parametrize("world,rows,cols,steps,seed", [
+    (2, 96, 300, 22, None),      # Species::new, fused passes + remainder + single steps
+    (3, 96, 300, 22, 0),         # stress fields
+    (4, 1030, 777, 41, 1),       # uneven slabs (257/258 rows), several 248-column strips
+    (2, 7, 50, 9, 2),            # 3- and 4-row slabs: passes fuse 3 steps
+    (4, 4, 64, 5, 3),            # one row per rank: single-step passes only
+])
+def test_shm_ranks_match_oracle(tmp_path, built, shm_transport, world, rows, cols, steps, seed):
+    _ranks_match_oracle(tmp_path, world, rows, cols, steps, shm_transport, seed)
+
+
+def _ranks_match_oracle(tmp_path, world, rows, cols, steps, transport_lib, seed):
     import oracle
 
-    rows, cols, steps = 96, 300, 22
-    mp.spawn(_worker, args=(world, _free_port(), rows, cols, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), rows, cols, steps, str(tmp_path), transport_lib, seed),
+             nprocs=world, join=True)
     skips = [p for p in os.listdir(tmp_path) if p.startswith("skip")]
     if skips:
         pytest.skip("RCCL refused the rank layout on this box: " + open(tmp_path / skips[0]).read()[:200])
-    u0, v0 = oracle.init_species(rows, cols)
+    if seed is None:
+        u0, v0 = oracle.init_species(rows, cols)
+    else:
+        from tests.helpers import stress_fields
+        u0, v0 = stress_fields((rows, cols), seed)
     ref_u, ref_v = oracle.run(u0, v0, steps + 3)
     assert np.load(tmp_path / "u.npy").tobytes() == ref_u.tobytes()
     assert np.load(tmp_path / "v.npy").tobytes() == ref_v.tobytes()
