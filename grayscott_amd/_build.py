@@ -32,6 +32,12 @@ UNITS = [
     # (source, object, extra flags)
     ("gs_step_kernels.hip", "gs_step_strict.o",
      ["-DGS_MATH_FUSED=0", "-Xclang", "-fdenormal-fp-math-f32=preserve-sign,ieee"]),
+    # the specialised strict variants, without the SLP vectoriser: v_pk_*_f32 has the lane
+    # throughput of the plain ops on gfx950 and the packing costs them ~10 % extra v_mov
+    # (profiles/r01_sweeps.md, runs 49/50); every other kernel measures faster with it
+    ("gs_step_kernels.hip", "gs_step_strict_op.o",
+     ["-DGS_MATH_FUSED=0", "-DGS_TB_OP_ONLY=1", "-Xclang", "-fdenormal-fp-math-f32=preserve-sign,ieee",
+      "-fno-slp-vectorize"]),
     ("gs_step_kernels.hip", "gs_step_fused.o", ["-DGS_MATH_FUSED=1"]),
     ("gs_util_kernels.hip", "gs_util.o", []),
     ("gs_api.cpp", "gs_api.o", ["-x", "hip"]),

@@ -67,7 +67,8 @@ class GsOptions(ctypes.Structure):
         ("use_graph", ctypes.c_int32),
         ("pitch_pad", ctypes.c_int32),
         ("split", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 9),
+        ("general_kernels", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 8),
     ]
 
 

@@ -392,6 +392,11 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
     // both operands are normal numbers, so forming it here in f32 gives the same bits.
     a.feed_plus_kill = ctx->p.feed + ctx->p.kill;
     a.dt = ctx->p.dt;
+    if (!ctx->o.general_kernels) {
+        const float(*w)[3] = ctx->p.w;
+        if (w[0][1] == 0.5f && w[1][0] == 0.5f && w[1][2] == 0.5f && w[2][1] == 0.5f) a.fast |= 1;
+        if (ctx->p.dt == 1.0f) a.fast |= 2;
+    }
     return a;
 }
 

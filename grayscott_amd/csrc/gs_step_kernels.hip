@@ -29,7 +29,7 @@
 //       with DPP wave shifts (no LDS, no extra memory traffic); only lanes 0 and 63 fetch
 //       one halo column each.  Each input element is read from HBM once per step except
 //       the 2 rows shared by vertically adjacent units.  HBM-bound: 16 B per cell-step.
-//   gs_step_tb_k<K>    the production kernel of gs_run: K <= 4 time steps per launch
+//   gs_step_tb_k<K,FAST> the production kernel of gs_run: K <= 4 time steps per launch
 //       (temporal blocking), K register-resident time levels per wave, sacrificial edge
 //       lanes instead of halo loads.  ~16 B of HBM traffic per cell for K steps;
 //       VALU-issue bound for K >= 3.  Bit-identical to K single steps.
@@ -40,6 +40,15 @@
 
 #ifndef GS_MATH_FUSED
 #error "compile with -DGS_MATH_FUSED=0 or 1"
+#endif
+// GS_TB_OP_ONLY=1: this translation unit provides nothing but the parameter-specialised (".op")
+// instances of gs_step_tb_k, through gs_tb_op_kernel_strict().  They are built apart from the rest
+// because they want different optimiser settings (no SLP vectoriser; grayscott_amd/_build.py).
+#ifndef GS_TB_OP_ONLY
+#define GS_TB_OP_ONLY 0
+#endif
+#if GS_TB_OP_ONLY && GS_MATH_FUSED
+#error "the fused build has no specialised variants"
 #endif
 
 #if GS_MATH_FUSED
@@ -54,16 +63,35 @@
 
 namespace {
 
-// compute/naive/src/lib.rs:74-79, one rounded op per reference op.
+// compute/naive/src/lib.rs:74-79, one rounded op per reference op.  DT1: time_step == 1.0f,
+// where `du * dt` is the identity on every f32 (NaNs stay NaNs) and is not issued.
+template <bool DT1 = false>
 __device__ __forceinline__ void react(const GsStepArgs &a, float u, float v, float acc_u,
                                       float acc_v, float &out_u, float &out_v)
 {
     const float uv_square = (u * v) * v;
     const float du = (a.du * acc_u - uv_square) + a.feed * (1.0f - u);
     const float dv = (a.dv * acc_v + uv_square) - a.feed_plus_kill * v;
-    out_u = u + du * a.dt;
-    out_v = v + dv * a.dt;
+    out_u = DT1 ? u + du : u + du * a.dt;
+    out_v = DT1 ? v + dv : v + dv * a.dt;
 }
+
+// (s - c) * 0.5f in ONE instruction: v_sub_f32 with the VOP3 output modifier div:2.  The hardware
+// applies the modifier to the rounded difference, so the result has the bits of the two-operation
+// sequence -- measured on gfx950 over 1.4 M operand pairs including sub-normal, huge and non-finite
+// ones (tools/ubench/omod_probe.hip) -- with two provisos, both met by the strict build:
+//   * the modifier is ignored unless f32 results are flushed (FP_DENORM: the strict build's mode)
+//     and MODE.IEEE is clear (the kernels that use it clear the bit on entry);
+//   * a flushed result is +0 where the multiply gives -0.  A tap is only ever ADDED to the
+//     accumulator, which starts at +0 and therefore is never -0, and x + (+0) == x + (-0) for every
+//     x other than -0: the accumulator's bits are the same.
+__device__ __forceinline__ float half_diff(float s, float c)
+{
+    float r;
+    asm("v_sub_f32_e64 %0, %1, %2 div:2" : "=v"(r) : "v"(s), "v"(c));
+    return r;
+}
+#define GS_TAP_HALF(acc, s, c) (acc) = (acc) + half_diff((s), (c))
 
 // m ? a : b for a per-lane all-ones / all-zeros mask: one v_bfi_b32, a full-rate VALU op
 // (v_cndmask_b32 measured ~8x slower on gfx950: tools/ubench/valu_rate.hip).
@@ -79,6 +107,7 @@ __device__ __forceinline__ int range_row(const GsStepArgs &a, int slot)
     return slot < na ? a.ra0 + slot : a.rb0 + (slot - na);
 }
 
+#if !GS_TB_OP_ONLY
 // ------------------------------------------------------------------------------------
 // Cross-check kernel: literal restatement, one thread per cell.
 // ------------------------------------------------------------------------------------
@@ -113,6 +142,8 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_simple_k)(GsStepArgs a)
     a.out_u[o] = ou;
     a.out_v[o] = ov;
 }
+
+#endif // !GS_TB_OP_ONLY
 
 // ------------------------------------------------------------------------------------
 // Production kernel: register sliding window + DPP halo exchange.
@@ -182,14 +213,25 @@ __device__ __forceinline__ RowW widen(const RowIn &r)
 // One output cell.  k = 1..4 indexes the centre inside RowW.  Interior flavour: all eight
 // neighbours exist.  EDGE flavour: `mrow` / `prow` say whether the row above / below exists
 // (wave-uniform), `la` / `ra` whether the left / right neighbour column is absent (per lane).
-template <bool EDGE>
+// FAST (strict build, chosen by the host from the parameters; see gs_kernels.h): bit 0 = the four
+// side weights are exactly 0.5f (interior cells fold `sub, mul` into half_diff), bit 1 = dt == 1.
+template <bool EDGE, int FAST = 0>
 __device__ __forceinline__ void cell(const GsStepArgs &a, const RowW &m, const RowW &z,
                                      const RowW &p, int k, bool mrow, bool prow, uint32_t la, uint32_t ra,
                                      float &out_u, float &out_v)
 {
     const float u = z.u[k], v = z.v[k];
     float acc_u = 0.0f, acc_v = 0.0f;
-    if (!EDGE) {
+    if (!EDGE && (FAST & 1) && !GS_MATH_FUSED) {
+        GS_TAP(acc_u, a.w[0][0], m.u[k - 1], u); GS_TAP(acc_v, a.w[0][0], m.v[k - 1], v);
+        GS_TAP_HALF(acc_u, m.u[k], u);           GS_TAP_HALF(acc_v, m.v[k], v);
+        GS_TAP(acc_u, a.w[0][2], m.u[k + 1], u); GS_TAP(acc_v, a.w[0][2], m.v[k + 1], v);
+        GS_TAP_HALF(acc_u, z.u[k - 1], u);       GS_TAP_HALF(acc_v, z.v[k - 1], v);
+        GS_TAP_HALF(acc_u, z.u[k + 1], u);       GS_TAP_HALF(acc_v, z.v[k + 1], v);
+        GS_TAP(acc_u, a.w[2][0], p.u[k - 1], u); GS_TAP(acc_v, a.w[2][0], p.v[k - 1], v);
+        GS_TAP_HALF(acc_u, p.u[k], u);           GS_TAP_HALF(acc_v, p.v[k], v);
+        GS_TAP(acc_u, a.w[2][2], p.u[k + 1], u); GS_TAP(acc_v, a.w[2][2], p.v[k + 1], v);
+    } else if (!EDGE) {
         GS_TAP(acc_u, a.w[0][0], m.u[k - 1], u); GS_TAP(acc_v, a.w[0][0], m.v[k - 1], v);
         GS_TAP(acc_u, a.w[0][1], m.u[k], u);     GS_TAP(acc_v, a.w[0][1], m.v[k], v);
         GS_TAP(acc_u, a.w[0][2], m.u[k + 1], u); GS_TAP(acc_v, a.w[0][2], m.v[k + 1], v);
@@ -219,7 +261,7 @@ __device__ __forceinline__ void cell(const GsStepArgs &a, const RowW &m, const R
         if (prow) GS_ROW_TAPS(p, zi + 1, true)
 #undef GS_ROW_TAPS
     }
-    react(a, u, v, acc_u, acc_v, out_u, out_v);
+    react<(FAST & 2) != 0>(a, u, v, acc_u, acc_v, out_u, out_v);
 }
 
 template <int G, bool EDGE>
@@ -369,7 +411,7 @@ __device__ __forceinline__ RowW widen_tb(const float4 &u, const float4 &v)
     return w;
 }
 
-template <int K, bool EDGE>
+template <int K, bool EDGE, int FAST>
 __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, int strip, int lane)
 {
     const int c = strip * kTbCols - 4 + lane * 4; // first column of this lane (may be -4)
@@ -452,10 +494,10 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                         nu = make_float4(z.u[1] + m.u[0], z.u[2], z.u[3], z.u[4] + p.u[5]);
                         nv = make_float4(z.v[1] + m.v[0], z.v[2], z.v[3], z.v[4] + p.v[5]);
 #else
-                        cell<EDGE>(a, m, z, p, 1, mrow, prow, la[0], ra[0], nu.x, nv.x);
-                        cell<EDGE>(a, m, z, p, 2, mrow, prow, la[1], ra[1], nu.y, nv.y);
-                        cell<EDGE>(a, m, z, p, 3, mrow, prow, la[2], ra[2], nu.z, nv.z);
-                        cell<EDGE>(a, m, z, p, 4, mrow, prow, la[3], ra[3], nu.w, nv.w);
+                        cell<EDGE, FAST>(a, m, z, p, 1, mrow, prow, la[0], ra[0], nu.x, nv.x);
+                        cell<EDGE, FAST>(a, m, z, p, 2, mrow, prow, la[1], ra[1], nu.y, nv.y);
+                        cell<EDGE, FAST>(a, m, z, p, 3, mrow, prow, la[2], ra[2], nu.z, nv.z);
+                        cell<EDGE, FAST>(a, m, z, p, 4, mrow, prow, la[3], ra[3], nu.w, nv.w);
 #endif
 #if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 1
                         if (j < K) {
@@ -476,9 +518,12 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
     }
 }
 
-template <int K>
+template <int K, int FAST>
 __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
 {
+    // half_diff needs MODE.IEEE = 0: hwreg(HW_REG_MODE, offset 9, width 1).  The bit only governs
+    // the quieting of signalling NaNs otherwise, which parity does not cover.
+    if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, see above
     const int strips = (a.cols + kTbCols - 1) / kTbCols;
@@ -526,11 +571,12 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     const bool edge = (strip == 0) || ((strip + 1) * kTbCols + 4 >= a.cols) ||
                       (ur0 - K < 0 && !a.top_present) || (ur1 + K > a.rows && !a.bottom_present);
     if (edge)
-        tb_march<K, true>(a, ur0, ur1, strip, lane);
+        tb_march<K, true, FAST>(a, ur0, ur1, strip, lane);
     else
-        tb_march<K, false>(a, ur0, ur1, strip, lane);
+        tb_march<K, false, FAST>(a, ur0, ur1, strip, lane);
 }
 
+#if !GS_TB_OP_ONLY
 // ------------------------------------------------------------------------------------
 // LDS-staged variant (one step per launch): the (tile + halo) stencil window of a block is
 // staged in LDS, then every lane reads its 3 x 6 neighbourhood back with ds_read_b128 +
@@ -643,8 +689,11 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_lds_k)(GsStepArgs a)
         lds_tile<false>(a, tr0, tr1, c0, su, sv);
 }
 
+#endif // !GS_TB_OP_ONLY
+
 } // namespace
 
+#if !GS_TB_OP_ONLY
 hipError_t GS_SUFFIX(gs_launch_simple)(const GsStepArgs &a, hipStream_t s, const char **name)
 {
     if (name) *name = "simple/" GS_MATH_NAME;
@@ -678,10 +727,16 @@ hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const
 // K fused steps over the row ranges of GsStepArgs; on slab seams the ghost rows must be K deep.
 hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, const char **name)
 {
-    static const char *const names[4] = {"tb-k1/" GS_MATH_NAME, "tb-k2/" GS_MATH_NAME,
-                                         "tb-k3/" GS_MATH_NAME, "tb-k4/" GS_MATH_NAME};
+    // ".op": the variant specialised for the default (Oono-Puri) side weights and/or dt == 1
+    static const char *const names[2][4] = {
+        {"tb-k1/" GS_MATH_NAME, "tb-k2/" GS_MATH_NAME, "tb-k3/" GS_MATH_NAME, "tb-k4/" GS_MATH_NAME},
+        {"tb-k1/" GS_MATH_NAME ".op", "tb-k2/" GS_MATH_NAME ".op", "tb-k3/" GS_MATH_NAME ".op",
+         "tb-k4/" GS_MATH_NAME ".op"}};
     if (k < 1 || k > 4 || a.cols <= 0 || a.rows_per_unit <= 0) return hipErrorInvalidValue;
-    if (name) *name = names[k - 1];
+    // The fused build has no use for bit 0 (its taps are sub + fma already) and measured slower
+    // with bit 1 (profiles/r01_sweeps.md, run 48/49): it always runs the general variant.
+    const int fast = a.fast & (GS_MATH_FUSED ? 0 : 3);
+    if (name) *name = names[fast ? 1 : 0][k - 1];
     const long rpu = a.rows_per_unit;
     const long rows_a = (long)a.ra1 - a.ra0;
     const long strips = (a.cols + kTbCols - 1) / kTbCols;
@@ -708,12 +763,14 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     args.small_rpu = (int32_t)small;
     void *kargs[] = {&args};
     const void *fn = nullptr;
-    switch (k) {
-    case 1: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<1>); break;
-    case 2: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<2>); break;
-    case 3: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<3>); break;
-    default: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4>); break;
+    switch (fast ? 0 : k) {
+    case 0: fn = gs_tb_op_kernel_strict(k, fast); break;
+    case 1: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<1, 0>); break;
+    case 2: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<2, 0>); break;
+    case 3: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<3, 0>); break;
+    default: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 0>); break;
     }
+    if (!fn) return hipErrorInvalidValue;
     return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), kargs, 0, s);
 }
 
@@ -732,3 +789,20 @@ hipError_t GS_SUFFIX(gs_launch_lds)(const GsStepArgs &a, hipStream_t s, const ch
     return hipLaunchKernel(reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_lds_k)), dim3((unsigned)blocks),
                            dim3(256), kargs, 0, s);
 }
+#endif // !GS_TB_OP_ONLY
+
+#if GS_TB_OP_ONLY
+// Kernel entry of the specialised variant for K fused steps and `fast` in 1..3 (GsStepArgs::fast).
+const void *gs_tb_op_kernel_strict(int k, int fast)
+{
+#define GS_TB_CASE(KK, FF)                                                                      \
+    case (KK) * 4 + (FF): return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<KK, FF>);
+    switch (k * 4 + fast) {
+        GS_TB_CASE(1, 1) GS_TB_CASE(2, 1) GS_TB_CASE(3, 1) GS_TB_CASE(4, 1)
+        GS_TB_CASE(1, 2) GS_TB_CASE(2, 2) GS_TB_CASE(3, 2) GS_TB_CASE(4, 2)
+        GS_TB_CASE(1, 3) GS_TB_CASE(2, 3) GS_TB_CASE(3, 3) GS_TB_CASE(4, 3)
+    default: return nullptr;
+    }
+#undef GS_TB_CASE
+}
+#endif

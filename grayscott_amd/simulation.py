@@ -74,6 +74,7 @@ class HipArgs:
     use_graph: int = field(default_factory=lambda: _env_int("GS_HIP_USE_GRAPH", 0))
     pitch_pad: int = field(default_factory=lambda: _env_int("GS_HIP_PITCH_PAD", 0))
     split: int = field(default_factory=lambda: _env_int("GS_HIP_SPLIT", 0))
+    general_kernels: int = field(default_factory=lambda: _env_int("GS_HIP_GENERAL_KERNELS", 0))
     rank: int = 0
     world: int = 1
     unique_id: Optional[bytes] = None
@@ -84,6 +85,7 @@ class HipArgs:
         o.rows_per_block, o.fuse_steps = self.rows_per_block, self.fuse_steps
         o.use_graph, o.pitch_pad = self.use_graph, self.pitch_pad
         o.split = self.split
+        o.general_kernels = self.general_kernels
         return o
 
 

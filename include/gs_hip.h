@@ -105,7 +105,10 @@ typedef struct gs_options {
     int32_t split;           /* row bands a single slab is scheduled as (0 = auto, 1 = off):   *
                               * adjacent bands only depend on each other's K boundary rows, so *
                               * the tail of one pass overlaps the start of the next            */
-    int32_t reserved[9];
+    int32_t general_kernels; /* 1 = never use the kernel variants specialised for the default  *
+                              * side weights (0.5) / dt == 1; results are bit-identical either *
+                              * way, the switch exists for A/B timing and tests                */
+    int32_t reserved[8];
 } gs_options;
 
 typedef struct gs_ctx gs_ctx;     /* devices, streams, row partition, RCCL communicator    */

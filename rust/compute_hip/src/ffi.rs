@@ -28,7 +28,8 @@ pub struct gs_options {
     pub use_graph: i32,
     pub pitch_pad: i32,
     pub split: i32,
-    pub reserved: [i32; 9],
+    pub general_kernels: i32,
+    pub reserved: [i32; 8],
 }
 
 #[repr(C)]

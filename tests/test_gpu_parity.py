@@ -217,6 +217,60 @@ def test_auto_row_bands_on_a_large_grid():
 
 
 # ---- non-default parameters (CLI overrides -k -f -t, ui/src/lib.rs:51-63) and weights ------
+# ---- parameter-specialised variants of the temporal-blocking kernel ---------------------------
+def _tiny_fields(shape, seed):
+    """The left 60 % of the columns hold values of both signs around the flush threshold (2^-130 ..
+    2^-118 times an ordinary value), the rest ordinary values: V stays tiny inside the region for
+    many steps, so differences, halved differences, tap sums and reaction terms are sub-normal
+    there step after step (U leaves the range in one step: + F * (1 - u))."""
+    rng = np.random.default_rng(seed)
+    u, v = stress_fields(shape, seed)
+    scale = np.float32(2.0) ** rng.integers(-130, -118, size=shape).astype(np.float32)
+    sign = np.where(rng.random(shape) < 0.5, np.float32(-1), np.float32(1))
+    tiny = np.zeros(shape, bool)
+    tiny[:, : (shape[1] * 3) // 5] = True
+    u = np.where(tiny, u * scale * sign, u).astype(np.float32)
+    v = np.where(tiny, v * scale * sign, v).astype(np.float32)
+    return u, v
+
+
+@pytest.mark.parametrize("general", [0, 1])
+@pytest.mark.parametrize("fuse", [1, 2, 3, 4])
+def test_specialised_variants_bit_exact(fuse, general):
+    """GsStepArgs::fast: side weights == 0.5 (v_sub_f32 div:2 instead of sub, mul) and dt == 1
+    (no multiply) are specialisations of the strict kernel that must not change one bit, with
+    ordinary data and with data around the flush-to-zero threshold (the output modifier flushes
+    to +0 where the multiply flushes to -0)."""
+    quarter_corners = ((0.125, 0.5, 0.375), (0.5, 0.0, 0.5), (0.75, 0.5, 1.0))   # sides 0.5, odd corners
+    cases = [
+        (Parameters(), True),                                                       # both
+        (Parameters(time_step=0.5), True),                                          # sides only
+        (Parameters(weights=quarter_corners, diffusion_rate_u=0.05), True),         # both, other corners
+        (Parameters(weights=((0.25, 0.5, 0.25), (0.5, 0, 0.25), (0.25, 0.5, 0.25))), True),   # dt only
+        (Parameters(weights=((0.25, 0.5, 0.25), (0.5, 0, 0.25), (0.25, 0.5, 0.25)), time_step=0.75), False),
+    ]
+    for p, special in cases:
+        for shape, maker, seed in [((41, 500), stress_fields, 5), ((64, 300), _tiny_fields, 6), ((9, 1030), _tiny_fields, 7)]:
+            u0, v0 = maker(shape, seed)
+            for steps in (1, 4, 9):
+                ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True)
+                got_u, got_v, info = gpu_run(u0, v0, steps, params=p,
+                                             args=args(kernel=capi.GS_KERNEL_TB, fuse_steps=fuse, rows_per_block=12,
+                                                       general_kernels=general))
+                assert (".op" in info[0]) == (special and not general), (info, p)
+                assert_bits_equal(got_u, ref_u, f"U {info[0]} {shape} steps {steps} {p}")
+                assert_bits_equal(got_v, ref_v, f"V {info[0]} {shape} steps {steps} {p}")
+
+
+def test_specialised_variant_sees_subnormals():
+    """The sub-normal test data is real: the keep-denormals answer differs from the FTZ one."""
+    u0, v0 = _tiny_fields((64, 300), 6)
+    for steps in (1, 4, 9):
+        _, a_v = oracle.run(u0, v0, steps, ftz=True)
+        _, b_v = oracle.run(u0, v0, steps, ftz=False)
+        assert np.count_nonzero(a_v.view(np.uint32) != b_v.view(np.uint32)) > 1000
+
+
 @pytest.mark.parametrize("kernel", [capi.GS_KERNEL_SIMPLE, capi.GS_KERNEL_STREAM, capi.GS_KERNEL_LDS])
 def test_non_default_parameters(kernel):
     pk = ((1 / 6, 4 / 6, 1 / 6), (4 / 6, 0.0, 4 / 6), (1 / 6, 4 / 6, 1 / 6))
