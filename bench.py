@@ -108,7 +108,7 @@ def main() -> int:
     ap.add_argument("--rows", type=int, default=0, help="override the grid (diagnostics only)")
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the informational band-schedule leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the informational fused-flavour leg")
     ap.add_argument("--rehearsal", action="store_true",
                     help="N > 1 on a 1-GPU box: all ranks share GPU 0 and torch.distributed uses gloo; needs "
                          "GS_RCCL_LIBRARY to name a transport that accepts several ranks per device "
@@ -157,13 +157,21 @@ def main() -> int:
     rows, cols = grid_for(args.gpus)
     if args.rows and args.cols:
         rows, cols = args.rows, args.cols
-    # One kernel launch per pass (split=1), so that "launch" in the roofline object is unambiguous
-    # and comparable with rocprofv3's per-kernel average; the library's default schedule for large
-    # single-GPU grids (two row bands whose passes overlap) is timed separately below.
-    hip_args = HipArgs(devices=[local_rank], rank=rank, world=world, unique_id=unique_id, split=1)
+    # The library's defaults, nothing pinned: one kernel launch per pass, so "launch" in the roofline
+    # object is unambiguous and comparable with rocprofv3's per-kernel average.
+    hip_args = HipArgs(devices=[local_rank], rank=rank, world=world, unique_id=unique_id)
     sim = Simulation.new(Parameters(), hip_args)
-    species = sim.make_species([rows, cols])        # Species::new on the device, HBM-resident
     ctx = sim.context
+    if world == 1:
+        # gs_run chooses unit height / fused steps / columns per lane on line, from timed passes of
+        # the simulation itself (per context and shape).  Let it finish on a scratch set of planes,
+        # so that neither the W warm-up steps nor the K timed ones contain tuning passes whatever
+        # W and K are.  (Multi-process contexts do not tune.)
+        scratch = sim.make_species([rows, cols])
+        sim.perform_steps(scratch, 400)
+        ctx.sync()
+        del scratch
+    species = sim.make_species([rows, cols])        # Species::new on the device, HBM-resident
 
     def barrier():
         if world > 1:
@@ -199,31 +207,17 @@ def main() -> int:
     passes = launches if args.gpus == 1 else launches // 2
     extra = None
     if args.gpus == 1 and not args.no_extra:
-        # informational: the default schedule (row bands, tuned on line), same K steps
-        sim_b = Simulation.new(Parameters(), HipArgs(devices=[local_rank]))
-        species_b = sim_b.make_species([rows, cols])
-        sim_b.perform_steps(species_b, max(args.warmup, 120))
-        sim_b.context.sync()
-        tb = time.perf_counter()
-        sim_b.perform_steps(species_b, args.steps)
-        sim_b.context.sync()
-        tb = time.perf_counter() - tb
-        extra = {"schedule": sim_b.context.info()[0], "value": rows * cols * args.steps / tb / 1e6,
-                 "note": "library default: unit height, row bands (@RxV: V > 1 = several concurrent "
-                         "launches per pass whose tails overlap) and fused steps chosen on line"}
-        sim_b.context.close()
-        del species_b, sim_b
         # informational: the fused-tap flavour (GS_MATH_FUSED: bit-identical wherever no sub-normal
         # intermediate occurs, |diff| <= 1e-37 elsewhere -- inside north_star's 1e-5 tolerance)
-        sim_c = Simulation.new(Parameters(), HipArgs(devices=[local_rank], math=capi.GS_MATH_FUSED, split=1))
+        sim_c = Simulation.new(Parameters(), HipArgs(devices=[local_rank], math=capi.GS_MATH_FUSED))
         species_c = sim_c.make_species([rows, cols])
-        sim_c.perform_steps(species_c, max(args.warmup, 120))
+        sim_c.perform_steps(species_c, max(args.warmup, 400))
         sim_c.context.sync()
         tc = time.perf_counter()
         sim_c.perform_steps(species_c, args.steps)
         sim_c.context.sync()
         tc = time.perf_counter() - tc
-        fused = {"kernel": sim_c.context.info()[0], "value": rows * cols * args.steps / tc / 1e6}
+        extra = {"kernel": sim_c.context.info()[0], "value": rows * cols * args.steps / tc / 1e6}
         sim_c.context.close()
         del species_c, sim_c
     launch_ms = event_ms / passes
@@ -268,8 +262,7 @@ def main() -> int:
         },
     }
     if extra is not None:
-        result["default_schedule"] = extra
-        result["fused_flavour"] = fused
+        result["fused_flavour"] = extra
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -28,17 +28,17 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-ffp-contract
 # Experiment hook (tools/sweep runs): extra hipcc flags for the kernel translation units.
 EXTRA = os.environ.get("GS_HIP_EXTRA_FLAGS", "").split()
 
+# The step kernels are built without the SLP vectoriser: v_pk_*_f32 has the lane throughput of the
+# plain ops on gfx950 and the packing costs ~10 % extra v_mov (profiles/r01_sweeps.md, runs 49-57).
+KERNEL_FLAGS = ["-fno-slp-vectorize"]
+STRICT = ["-DGS_MATH_FUSED=0", "-Xclang", "-fdenormal-fp-math-f32=preserve-sign,ieee"]
+
 UNITS = [
     # (source, object, extra flags)
-    ("gs_step_kernels.hip", "gs_step_strict.o",
-     ["-DGS_MATH_FUSED=0", "-Xclang", "-fdenormal-fp-math-f32=preserve-sign,ieee"]),
-    # the specialised strict variants, without the SLP vectoriser: v_pk_*_f32 has the lane
-    # throughput of the plain ops on gfx950 and the packing costs them ~10 % extra v_mov
-    # (profiles/r01_sweeps.md, runs 49/50); every other kernel measures faster with it
-    ("gs_step_kernels.hip", "gs_step_strict_op.o",
-     ["-DGS_MATH_FUSED=0", "-DGS_TB_OP_ONLY=1", "-Xclang", "-fdenormal-fp-math-f32=preserve-sign,ieee",
-      "-fno-slp-vectorize"]),
-    ("gs_step_kernels.hip", "gs_step_fused.o", ["-DGS_MATH_FUSED=1"]),
+    ("gs_step_kernels.hip", "gs_step_strict.o", STRICT + KERNEL_FLAGS),
+    # the parameter-specialised strict variants: their own translation unit, compiled in parallel
+    ("gs_step_kernels.hip", "gs_step_strict_op.o", STRICT + ["-DGS_TB_OP_ONLY=1"] + KERNEL_FLAGS),
+    ("gs_step_kernels.hip", "gs_step_fused.o", ["-DGS_MATH_FUSED=1"] + KERNEL_FLAGS),
     ("gs_util_kernels.hip", "gs_util.o", []),
     ("gs_api.cpp", "gs_api.o", ["-x", "hip"]),
 ]

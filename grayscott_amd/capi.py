@@ -68,7 +68,8 @@ class GsOptions(ctypes.Structure):
         ("pitch_pad", ctypes.c_int32),
         ("split", ctypes.c_int32),
         ("general_kernels", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 8),
+        ("cols_per_lane", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 7),
     ]
 
 

@@ -140,7 +140,6 @@ struct SlabRt {
     hipEvent_t done[2] = {nullptr, nullptr}, halod[2] = {nullptr, nullptr};
     hipEvent_t t0 = nullptr, t1 = nullptr;
     hipEvent_t staged = nullptr, copied = nullptr; // asynchronous downloads
-    hipEvent_t tune0 = nullptr, tune1 = nullptr;   // unit-height tuning
     float *stage = nullptr;                        // dense device staging buffer
     size_t stage_floats = 0;
 };
@@ -152,6 +151,7 @@ struct gs_ctx {
     std::vector<SlabRt> bands; // stream/event sets for the in-place row bands of a single slab
     hipEvent_t band_join = nullptr;
     bool bands_active = false; // the newest pass ran on the band streams
+    int bands_v = 0, bands_rows = 0, bands_k = 0; // layout of that pass
     int rank = 0, world = 1;
     uint64_t step_no = 0;
     ncclComm_t comm = nullptr;
@@ -160,10 +160,12 @@ struct gs_ctx {
     // rows-per-unit tuned on line for (rows, cols, fuse) of the last single-slab gs_run
     uint64_t tuned_rows = 0, tuned_cols = 0;
     int tuned_fuse = 0, tuned_rpu = 0, tuned_split = 0, tuned_k = 0; // tuned_k: fused steps per pass chosen
+    int tuned_cpl = 0;                                               // columns per lane chosen
     // tuning in progress (may span several gs_run calls): next candidate, best so far
     uint64_t tune_rows = 0, tune_cols = 0;
-    int tune_fuse = 0, tune_next = 0, tune_best_rpu = 0, tune_best_split = 0, tune_best_k = 0;
+    int tune_fuse = 0, tune_next = 0, tune_best_rpu = 0, tune_best_split = 0, tune_best_k = 0, tune_best_cpl = 0;
     float tune_best_ms = 0.f;
+    std::vector<hipEvent_t> tune_events; // timing windows of one tuning phase (created on first use)
     int total_slabs() const { return world * (int)slabs.size(); }
     int global_index(int i) const { return rank * (int)slabs.size() + i; }
 };
@@ -319,15 +321,37 @@ int32_t refresh_ghosts(gs_ctx *ctx, gs_field *f)
     return GS_OK;
 }
 
+// Output columns per wave of the temporally blocked kernel (gs_step_kernels.hip: tb_cols_per_wave).
+long tb_strips(int32_t cols, int fuse, int cpl)
+{
+    const long w = (64 - 2 * ((fuse + cpl - 1) / cpl)) * (long)cpl;
+    return (cols + w - 1) / w;
+}
+
+bool tuned_for(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse)
+{
+    return ctx->tuned_rpu > 0 && ctx->tuned_k == fuse && ctx->tuned_rows == (uint64_t)rows &&
+           ctx->tuned_cols == (uint64_t)cols && ctx->total_slabs() == 1;
+}
+
+// Columns per lane of the temporally blocked kernel when nothing was tuned on line: 2 (measured
+// fastest from 4096^2 up, profiles/r01_sweeps.md runs 54-57) unless that cannot give every SIMD a
+// wave at a unit height of 8 * fuse rows, then 1.
+int32_t pick_cols_per_lane(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse)
+{
+    if (ctx->o.cols_per_lane > 0) return ctx->o.cols_per_lane;
+    if (tuned_for(ctx, rows, cols, fuse) && ctx->tuned_cpl > 0) return ctx->tuned_cpl;
+    if (fuse < 2) return 2;
+    return (long)rows * tb_strips(cols, fuse, 2) / (8L * fuse) >= 2048 ? 2 : 1;
+}
+
 // Rows each wave marches over when nothing was tuned on line (slab chains, short runs).  Measured
 // at 16384^2 (profiles/r01_sweeps.md, sweep17/18): 16 rows for single steps, 128 for 4 fused steps.
 int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse)
 {
     if (ctx->o.rows_per_block > 0) return ctx->o.rows_per_block;
-    if (ctx->tuned_rpu > 0 && ctx->tuned_k == fuse && ctx->tuned_rows == (uint64_t)rows &&
-        ctx->tuned_cols == (uint64_t)cols && ctx->total_slabs() == 1)
-        return ctx->tuned_rpu;
-    const long strips = (cols + 247) / 248;
+    if (tuned_for(ctx, rows, cols, fuse)) return ctx->tuned_rpu;
+    const long strips = fuse > 1 ? tb_strips(cols, fuse, pick_cols_per_lane(ctx, rows, cols, fuse)) : (cols + 255) / 256;
     const long want = fuse > 1 ? 32L * fuse : 16;
     long rpu = ((long)rows * strips + 16383) / 16384; // keep >= 16384 waves per launch when possible
     if (rpu > want) rpu = want;
@@ -384,6 +408,7 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
     a.bottom_present = k < ctx->total_slabs() - 1;
     a.ghost = kGhostRows;
     a.rows_per_unit = pick_rows_per_unit(ctx, a.rows, a.cols, fuse);
+    a.cpl = pick_cols_per_lane(ctx, a.rows, a.cols, fuse);
     std::memcpy(a.w, ctx->p.w, sizeof a.w);
     a.du = ctx->p.du;
     a.dv = ctx->p.dv;
@@ -450,11 +475,11 @@ int clamp_bands(const gs_field *f, int fuse, int V)
 int bands_for(const gs_ctx *ctx, const gs_field *f, int fuse)
 {
     if (ctx->total_slabs() != 1 || fuse < 2) return 1;
+    // Opt-in (gs_options.split >= 2).  Bands reach +3 % on the 16384^2 grid on a good day, but how
+    // the four streams of two bands share the chip varies from box to box and run to run (845 k to
+    // 936 k for one configuration, profiles/r01_sweeps.md runs 58-61); one launch per pass does not.
     int V = ctx->o.split;
-    if (V == 0 && ctx->tuned_split > 0 && ctx->tuned_k == fuse && ctx->tuned_rows == f->rows &&
-        ctx->tuned_cols == f->cols)
-        return clamp_bands(f, fuse, ctx->tuned_split);
-    if (V == 0) V = (f->rows * f->cols >= (1ull << 26)) ? 2 : 1; // measured: pays on large grids
+    if (V == 0) V = 1;
     if (V > 8) V = 8;
     while (V > 1 && f->rows / (uint64_t)V < (uint64_t)(8 * fuse)) --V;
     return V < 1 ? 1 : V;
@@ -465,10 +490,19 @@ int32_t step_bands(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u,
     GS_TRY(ensure_bands(ctx, V));
     SlabRt &sl = ctx->slabs[0];
     GS_HIP(hipSetDevice(sl.device));
-    // whatever was enqueued on the slab's own streams (fills, single steps, staging copies)
-    GS_HIP(hipEventRecord(ctx->band_join, sl.compute));
     const GsStepArgs full = make_args(ctx, in_u, in_v, out_u, out_v, 0, fuse);
     const int n = full.rows;
+    // The band-to-band events below order consecutive passes of ONE layout: the same row ranges
+    // and the same number of fused steps (a band waits for its neighbours' K-row boundary kernels
+    // only, and its interior kernel overwrites everything but its own K boundary rows).  Any other
+    // sequence starts behind a full barrier.
+    if (ctx->bands_active && (V != ctx->bands_v || n != ctx->bands_rows || fuse != ctx->bands_k))
+        GS_TRY(join_bands(ctx, sl.compute));
+    ctx->bands_v = V;
+    ctx->bands_rows = n;
+    ctx->bands_k = fuse;
+    // whatever was enqueued on the slab's own streams (fills, single steps, staging copies)
+    GS_HIP(hipEventRecord(ctx->band_join, sl.compute));
     const int p = (int)(ctx->step_no & 1), q = p ^ 1;
     for (int k = 0; k < V; ++k) {
         SlabRt &b = ctx->bands[k];
@@ -659,8 +693,6 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
         if (sl.t1) (void)hipEventDestroy(sl.t1);
         if (sl.staged) (void)hipEventDestroy(sl.staged);
         if (sl.copied) (void)hipEventDestroy(sl.copied);
-        if (sl.tune0) (void)hipEventDestroy(sl.tune0);
-        if (sl.tune1) (void)hipEventDestroy(sl.tune1);
         if (sl.copy) { (void)hipStreamSynchronize(sl.copy); (void)hipStreamDestroy(sl.copy); }
         if (sl.stage) (void)hipFree(sl.stage);
         if (sl.halo) (void)hipStreamDestroy(sl.halo);
@@ -676,6 +708,9 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
         }
     }
     if (ctx->band_join) (void)hipEventDestroy(ctx->band_join);
+    if (!ctx->tune_events.empty() && !ctx->slabs.empty() && hipSetDevice(ctx->slabs[0].device) == hipSuccess)
+        for (auto e : ctx->tune_events)
+            if (e) (void)hipEventDestroy(e);
     (void)hipGetLastError(); // teardown failures must not leak into later calls' status
     delete ctx;
     return GS_OK;
@@ -705,6 +740,9 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
     ctx->rank = rank;
     ctx->world = world;
     int32_t st = check_math(ctx->p, ctx->o.math);
+    if (st == GS_OK && ctx->o.cols_per_lane != 0 && ctx->o.cols_per_lane != 1 && ctx->o.cols_per_lane != 2 &&
+        ctx->o.cols_per_lane != 4)
+        st = fail(GS_ERR_INVALID, "cols_per_lane must be 0 (auto), 1, 2 or 4, not %d", ctx->o.cols_per_lane);
     if (st != GS_OK) { delete ctx; return st; }
 
     const int32_t one = 0;
@@ -736,8 +774,6 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
         GS_HIP_B(hipStreamCreateWithFlags(&sl.copy, hipStreamNonBlocking));
         GS_HIP_B(hipEventCreateWithFlags(&sl.staged, hipEventDisableTiming));
         GS_HIP_B(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
-        GS_HIP_B(hipEventCreate(&sl.tune0));
-        GS_HIP_B(hipEventCreate(&sl.tune1));
         for (int k = 0; k < 2; ++k) {
             GS_HIP_B(hipEventCreateWithFlags(&sl.done[k], hipEventDisableTiming));
             GS_HIP_B(hipEventCreateWithFlags(&sl.halod[k], hipEventDisableTiming));
@@ -996,18 +1032,28 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
         return st;
     };
     if (tunable) {
-        // phase A: unit heights with the default band count; phase B: other band counts with the
-        // best unit height (when the band count is not pinned); phase C: fewer fused steps per pass
+        // phase A: unit heights; (phase B, band counts: retired;) phase C: fewer fused steps per pass
         // with the best of A and B (when fuse_steps is not pinned) -- on small, cache-resident grids
-        // the 2K redundant rows per unit can cost more than the extra passes.
+        // the 2K redundant rows per unit can cost more than the extra passes; phase D (columns per
+        // lane not pinned): 1 and 4 columns per lane -- more, narrower waves for small grids; fewer,
+        // wider ones with 16-byte accesses -- with a few unit heights each (large grids skip the
+        // candidates that would only multiply tiny units).  A-C run with 2 columns per lane.
         static const int cand[] = {8, 12, 16, 24, 32, 48, 64, 96, 128};
         static const int alt[] = {1, 2, 3};
         static const int altk[] = {3, 2};
+        static const int candn[] = {8, 16, 32, 64, 128};
+        static const int cpls[] = {1, 4};
         const int ncand = (int)(sizeof cand / sizeof cand[0]);
-        const int nalt = ctx->o.split == 0 ? (int)(sizeof alt / sizeof alt[0]) : 0;
+        const int nalt = 0; // band counts are not explored any more (see bands_for); phase B is empty
+        (void)alt;
         const int nk = ctx->o.fuse_steps == 0 ? (int)(sizeof altk / sizeof altk[0]) : 0;
         const uint64_t cells = u0->rows * u0->cols;
-        const int reps = cells >= (1ull << 24) ? 2 : (cells >= (1ull << 22) ? 4 : 8); // passes per candidate
+        const int ncandn = (int)(sizeof candn / sizeof candn[0]);
+        const int nn = ctx->o.cols_per_lane == 0 ? ncandn * (int)(sizeof cpls / sizeof cpls[0]) : 0;
+        const bool large = cells > (1ull << 26);
+        const int user_cpl = ctx->o.cols_per_lane;
+        // timed passes per candidate: short passes need more of them for a stable comparison
+        const int reps = cells >= (1ull << 27) ? 2 : (cells >= (1ull << 24) ? 6 : 8);
         if (ctx->tune_rows != u0->rows || ctx->tune_cols != u0->cols || ctx->tune_fuse != fuse) {
             ctx->tune_rows = u0->rows;
             ctx->tune_cols = u0->cols;
@@ -1016,57 +1062,109 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
             ctx->tune_best_rpu = 0;
             ctx->tune_best_split = 0;
             ctx->tune_best_k = 0;
+            ctx->tune_best_cpl = 0;
             ctx->tune_best_ms = 0.f;
         }
         const int V0 = bands_for(ctx, u0, fuse);
         SlabRt &sl = ctx->slabs[0];
         GS_HIP(hipSetDevice(sl.device));
-        bool warm = n > 0; // a pass of this call already ran
-        while (ctx->tune_next < ncand + nalt + nk) {
-            int rpu, V, k = fuse;
-            if (ctx->tune_next < ncand) {
-                rpu = cand[ctx->tune_next];
-                V = V0;
-                if (rpu < 2 * fuse || (uint64_t)rpu > u0->rows) { ctx->tune_next++; continue; }
-            } else if (ctx->tune_next < ncand + nalt) {
-                rpu = ctx->tune_best_rpu;
-                V = clamp_bands(u0, fuse, alt[ctx->tune_next - ncand]);
-                if (rpu == 0 || V == V0 || V != alt[ctx->tune_next - ncand]) { ctx->tune_next++; continue; }
-            } else {
-                rpu = ctx->tune_best_rpu;
-                V = ctx->tune_best_split;
-                k = altk[ctx->tune_next - ncand - nalt];
-                if (rpu == 0 || k >= fuse) { ctx->tune_next++; continue; }
+        // Candidates of one phase do not depend on each other, so a whole phase is enqueued
+        // back to back -- per candidate: [an untimed pass when the kernel changes,] event, `reps`
+        // passes, event, `reps` passes, event -- and the host waits once per phase: no idle gaps
+        // (clock ramps) between the timing windows.  A candidate's time is the shorter of its two
+        // windows.
+        struct Trial { int rpu, V, k, cpl; };
+        // Timestamp "everything enqueued so far has finished" without holding anything back: after
+        // a banded pass the event is recorded on the copy stream, which is made to wait for the
+        // bands (a record on the compute stream would turn every window boundary into a barrier
+        // between passes, and hide exactly the overlap that bands are for).
+        auto mark = [&](hipEvent_t ev) -> int32_t {
+            hipStream_t ts = sl.compute;
+            if (ctx->bands_active) {
+                ts = sl.copy;
+                GS_TRY(join_bands(ctx, ts));
             }
-            const uint64_t passes_left = (steps - n) / (uint64_t)k;
-            if (passes_left < (uint64_t)reps + (warm ? 0 : 1)) break; // continue in the next gs_run
-            ctx->o.rows_per_block = rpu;
-            int32_t st = GS_OK;
-            if (!warm) { // untimed pass first
-                st = advance(V, k);
-                warm = true;
-            }
-            if (st == GS_OK) st = join_bands(ctx, sl.compute);
-            if (st == GS_OK && hipEventRecord(sl.tune0, sl.compute) != hipSuccess) st = fail(GS_ERR_HIP, "hipEventRecord failed");
-            for (int r = 0; r < reps && st == GS_OK; ++r) st = advance(V, k);
-            ctx->o.rows_per_block = 0;
-            if (st == GS_OK) st = join_bands(ctx, sl.compute);
-            float ms = 0.f;
-            if (st == GS_OK && (hipEventRecord(sl.tune1, sl.compute) != hipSuccess || hipEventSynchronize(sl.tune1) != hipSuccess ||
-                                hipEventElapsedTime(&ms, sl.tune0, sl.tune1) != hipSuccess))
-                st = fail(GS_ERR_HIP, "timing a tuning pass failed");
-            if (st != GS_OK) return st;
-            ms /= (float)(reps * k); // per time step
-            // prefer the incumbent unless the newcomer is clearly (> 1 %) faster
-            if (ctx->tune_best_rpu == 0 || ms < 0.99f * ctx->tune_best_ms) {
-                ctx->tune_best_ms = ms;
-                ctx->tune_best_rpu = rpu;
-                ctx->tune_best_split = V;
-                ctx->tune_best_k = k;
-            }
-            ctx->tune_next++;
+            GS_HIP(hipEventRecord(ev, ts));
+            return GS_OK;
+        };
+        constexpr int kMaxBatch = 10;
+        if (ctx->tune_events.empty()) {
+            ctx->tune_events.resize(3 * kMaxBatch, nullptr);
+            for (auto &e : ctx->tune_events) GS_HIP(hipEventCreate(&e));
         }
-        if (ctx->tune_next >= ncand + nalt + nk && ctx->tune_best_rpu > 0) {
+        const int phase_end[4] = {ncand, ncand + nalt, ncand + nalt + nk, ncand + nalt + nk + nn};
+        int warm_cpl = 0, warm_k = 0; // kernel of the newest pass enqueued by this call
+        bool out_of_steps = false;
+        while (ctx->tune_next < phase_end[3] && !out_of_steps) {
+            int phase = 0;
+            while (ctx->tune_next >= phase_end[phase]) ++phase;
+            Trial batch[kMaxBatch];
+            int nb = 0;
+            int32_t st = GS_OK;
+            for (; ctx->tune_next < phase_end[phase] && nb < kMaxBatch && st == GS_OK; ++ctx->tune_next) {
+                Trial t{0, V0, fuse, user_cpl ? user_cpl : 2};
+                const int i = ctx->tune_next - (phase ? phase_end[phase - 1] : 0);
+                if (phase == 0) {
+                    t.rpu = cand[i];
+                    if (t.rpu < 2 * fuse || (uint64_t)t.rpu > u0->rows) continue;
+                } else if (phase == 1) {
+                    t.rpu = ctx->tune_best_rpu;
+                    t.V = clamp_bands(u0, fuse, alt[i]);
+                    if (t.rpu == 0 || t.V == V0 || t.V != alt[i]) continue;
+                } else if (phase == 2) {
+                    t.rpu = ctx->tune_best_rpu;
+                    t.V = ctx->tune_best_split;
+                    t.k = altk[i];
+                    if (t.rpu == 0 || t.k >= fuse) continue;
+                } else {
+                    t.cpl = cpls[i / ncandn];
+                    t.rpu = candn[i % ncandn];
+                    t.V = ctx->tune_best_split;
+                    t.k = ctx->tune_best_k;
+                    if (ctx->tune_best_rpu == 0 || t.rpu < 2 * t.k || (uint64_t)t.rpu > u0->rows ||
+                        (large && (t.cpl == 1 || t.rpu < 32)))
+                        continue;
+                }
+                if ((steps - n) / (uint64_t)t.k < (uint64_t)(2 * reps + 1)) { // continue in the next gs_run
+                    out_of_steps = true;
+                    break;
+                }
+                ctx->o.rows_per_block = t.rpu;
+                ctx->o.cols_per_lane = t.cpl;
+                if (t.cpl != warm_cpl || t.k != warm_k) { // another kernel: one untimed pass first
+                    st = advance(t.V, t.k);
+                    warm_cpl = t.cpl;
+                    warm_k = t.k;
+                }
+                for (int w = 0; w < 3 && st == GS_OK; ++w) {
+                    st = mark(ctx->tune_events[3 * nb + w]);
+                    for (int r = 0; r < reps && w < 2 && st == GS_OK; ++r) st = advance(t.V, t.k);
+                }
+                ctx->o.rows_per_block = 0;
+                ctx->o.cols_per_lane = user_cpl;
+                batch[nb++] = t;
+            }
+            if (st != GS_OK) return st;
+            if (nb > 0 && hipEventSynchronize(ctx->tune_events[3 * (nb - 1) + 2]) != hipSuccess)
+                return fail(GS_ERR_HIP, "waiting for the tuning passes failed");
+            for (int b = 0; b < nb; ++b) {
+                float w0 = 0.f, w1 = 0.f;
+                if (hipEventElapsedTime(&w0, ctx->tune_events[3 * b], ctx->tune_events[3 * b + 1]) != hipSuccess ||
+                    hipEventElapsedTime(&w1, ctx->tune_events[3 * b + 1], ctx->tune_events[3 * b + 2]) != hipSuccess)
+                    return fail(GS_ERR_HIP, "timing a tuning pass failed");
+                const float ms = (w0 < w1 ? w0 : w1) / (float)(reps * batch[b].k); // per time step
+                // prefer the incumbent unless the newcomer is clearly (> 1 %) faster
+                if (ctx->tune_best_rpu == 0 || ms < 0.99f * ctx->tune_best_ms) {
+                    ctx->tune_best_ms = ms;
+                    ctx->tune_best_rpu = batch[b].rpu;
+                    ctx->tune_best_split = batch[b].V;
+                    ctx->tune_best_k = batch[b].k;
+                    ctx->tune_best_cpl = batch[b].cpl;
+                }
+            }
+        }
+        if (ctx->tune_next >= ncand + nalt + nk + nn && ctx->tune_best_rpu > 0) {
+            ctx->tuned_cpl = ctx->tune_best_cpl;
             ctx->tuned_rpu = ctx->tune_best_rpu;
             ctx->tuned_split = ctx->tune_best_split;
             ctx->tuned_k = ctx->tune_best_k;

@@ -29,6 +29,8 @@ struct GsStepArgs {
     // instructions): bit 0 = the four side weights w[0][1], w[1][0], w[1][2], w[2][1] are exactly
     // 0.5f, bit 1 = dt is exactly 1.0f.  Both hold for Parameters::default().
     int32_t fast;
+    // Columns per lane of the temporal-blocking kernel: 4 (0 means 4), 2 or 1.
+    int32_t cpl;
     float w[3][3];         // stencil weights, row-major (parameters.rs:87-88)
     float du, dv, feed, feed_plus_kill, dt;
 };
@@ -46,7 +48,7 @@ GS_DECLARE_LAUNCHERS(fused)
 
 // Entry points of the parameter-specialised temporal-blocking kernels (strict flavour only; their
 // own translation unit, see gs_step_kernels.hip: GS_TB_OP_ONLY).  nullptr for an unknown variant.
-const void *gs_tb_op_kernel_strict(int k, int fast);
+const void *gs_tb_op_kernel_strict(int k, int fast, int cpl);
 
 // Plane utilities (math-agnostic, defined once in gs_util_kernels.hip).
 hipError_t gs_launch_fill_rect(float *row0, int32_t pitch, int32_t r0, int32_t r1, int32_t c0,

@@ -42,8 +42,8 @@
 #error "compile with -DGS_MATH_FUSED=0 or 1"
 #endif
 // GS_TB_OP_ONLY=1: this translation unit provides nothing but the parameter-specialised (".op")
-// instances of gs_step_tb_k, through gs_tb_op_kernel_strict().  They are built apart from the rest
-// because they want different optimiser settings (no SLP vectoriser; grayscott_amd/_build.py).
+// instances of gs_step_tb_k, through gs_tb_op_kernel_strict() (24 kernels: built apart from the
+// rest so that the translation units compile in parallel; grayscott_amd/_build.py).
 #ifndef GS_TB_OP_ONLY
 #define GS_TB_OP_ONLY 0
 #endif
@@ -215,9 +215,9 @@ __device__ __forceinline__ RowW widen(const RowIn &r)
 // (wave-uniform), `la` / `ra` whether the left / right neighbour column is absent (per lane).
 // FAST (strict build, chosen by the host from the parameters; see gs_kernels.h): bit 0 = the four
 // side weights are exactly 0.5f (interior cells fold `sub, mul` into half_diff), bit 1 = dt == 1.
-template <bool EDGE, int FAST = 0>
-__device__ __forceinline__ void cell(const GsStepArgs &a, const RowW &m, const RowW &z,
-                                     const RowW &p, int k, bool mrow, bool prow, uint32_t la, uint32_t ra,
+template <bool EDGE, int FAST = 0, typename Row = RowW>
+__device__ __forceinline__ void cell(const GsStepArgs &a, const Row &m, const Row &z,
+                                     const Row &p, int k, bool mrow, bool prow, uint32_t la, uint32_t ra,
                                      float &out_u, float &out_v)
 {
     const float u = z.u[k], v = z.v[k];
@@ -387,7 +387,14 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_stream_k)(GsStepArgs a)
 //   algorithmic traffic 16 B * K per cell: the kernel moves from HBM-bound (K = 1, 2)
 //   towards VALU-bound (K = 4).
 // ------------------------------------------------------------------------------------
-constexpr int kTbCols = 248; // output columns per wave
+// Columns per lane (CPL).  The wide layout above (4 columns per lane, 16-B accesses) is the one
+// for large grids.  Small grids do not have enough 248-column strips x row units to fill 256 CUs,
+// so the same march also exists with 2 and 1 columns per lane: 2x / 4x more waves for the same
+// unit height.  A sacrificial lane of CPL columns absorbs CPL levels, so ceil(K / CPL) lanes per
+// side are sacrificial and a wave produces (64 - 2 * ceil(K / CPL)) * CPL output columns.
+__host__ __device__ constexpr int tb_sacrificial_lanes(int k, int cpl) { return (k + cpl - 1) / cpl; }
+__host__ __device__ constexpr int tb_cols_per_wave(int k, int cpl) { return (64 - 2 * tb_sacrificial_lanes(k, cpl)) * cpl; }
+static_assert(tb_cols_per_wave(4, 4) == 248 && tb_cols_per_wave(4, 1) == 56 && tb_cols_per_wave(3, 2) == 120, "");
 
 // Measured on MI355X while tuning this kernel (tools/ubench/valu_rate.hip, sweeps under
 // profiles/): packed v_pk_{add,mul}_f32 have the same lane throughput as scalar VALU ops
@@ -395,28 +402,54 @@ constexpr int kTbCols = 248; // output columns per wave
 // columns are fetched once per row and kept, not re-read at each use), v_cndmask is ~8x a
 // scalar op (kept out of the interior path), and 2 or 4 waves per SIMD issue at full rate
 // while 3 do not.  The kernel is VALU-issue bound for K >= 3.
+template <int CPL>
 struct RowQ { // a level-0 row as fetched (no halo columns: sacrificial lanes instead)
-    float4 u, v;
+    float u[CPL], v[CPL];
+};
+template <int CPL>
+struct RowT { // [0] = column c-1, [1..CPL] = own columns, [CPL+1] = column c+CPL
+    float u[CPL + 2], v[CPL + 2];
 };
 
-__device__ __forceinline__ RowW widen_tb(const float4 &u, const float4 &v)
+template <int CPL>
+__device__ __forceinline__ RowT<CPL> widen_tb(const float (&u)[CPL], const float (&v)[CPL])
 {
-    RowW w;
-    w.u[1] = u.x; w.u[2] = u.y; w.u[3] = u.z; w.u[4] = u.w;
-    w.v[1] = v.x; w.v[2] = v.y; w.v[3] = v.z; w.v[4] = v.w;
-    w.u[0] = from_prev_lane(u.w, u.w); // lanes 0 / 63 keep a don't-care value
-    w.u[5] = from_next_lane(u.x, u.x);
-    w.v[0] = from_prev_lane(v.w, v.w);
-    w.v[5] = from_next_lane(v.x, v.x);
+    RowT<CPL> w;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { w.u[1 + i] = u[i]; w.v[1 + i] = v[i]; }
+    w.u[0] = from_prev_lane(u[CPL - 1], u[CPL - 1]); // lanes 0 / 63 keep a don't-care value
+    w.u[CPL + 1] = from_next_lane(u[0], u[0]);
+    w.v[0] = from_prev_lane(v[CPL - 1], v[CPL - 1]);
+    w.v[CPL + 1] = from_next_lane(v[0], v[0]);
     return w;
 }
 
-template <int K, bool EDGE, int FAST>
+template <int CPL> struct VecOf;
+template <> struct VecOf<4> { using type = float4; };
+template <> struct VecOf<2> { using type = float2; };
+template <> struct VecOf<1> { using type = float; };
+
+template <int CPL>
+__device__ __forceinline__ void load_cols(const float *p, float (&out)[CPL])
+{
+    const typename VecOf<CPL>::type x = *reinterpret_cast<const typename VecOf<CPL>::type *>(p);
+    __builtin_memcpy(out, &x, sizeof x);
+}
+template <int CPL>
+__device__ __forceinline__ void store_cols(float *p, const float (&in)[CPL])
+{
+    typename VecOf<CPL>::type x;
+    __builtin_memcpy(&x, in, sizeof x);
+    *reinterpret_cast<typename VecOf<CPL>::type *>(p) = x;
+}
+
+template <int K, bool EDGE, int FAST, int CPL>
 __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, int strip, int lane)
 {
-    const int c = strip * kTbCols - 4 + lane * 4; // first column of this lane (may be -4)
+    constexpr int S = tb_sacrificial_lanes(K, CPL), W = tb_cols_per_wave(K, CPL);
+    const int c = strip * W + (lane - S) * CPL; // first column of this lane (may be negative)
     const bool load_ok = !EDGE || (c >= 0 && c < a.pitch);
-    const bool store_ok = (lane >= 1) && (lane <= 62) && (!EDGE || c < a.pitch);
+    const bool store_ok = (lane >= S) && (lane < 64 - S) && (!EDGE || c < a.pitch);
     const ptrdiff_t pitch = a.pitch;
     const float *bu = a.in_u + c, *bv = a.in_v + c;
 
@@ -425,29 +458,29 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
     const int row_lo = max(ur0 - K, a.top_present ? -a.ghost : 0);
     const int row_hi = min(ur1 + K - 1, a.bottom_present ? a.rows + a.ghost - 1 : a.rows - 1);
     auto fetch = [&](int row) {
-        RowQ r;
+        RowQ<CPL> r;
         const int rr = min(max(row, row_lo), row_hi);
 #if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 1 /* experiment: no loads (VALU-only timing) */
         const float fr = (float)rr * a.du + (float)lane;
-        r.u = make_float4(fr, fr + a.dv, fr + a.feed, fr + a.dt);
-        r.v = make_float4(fr * a.dv, fr, fr - a.feed, fr + a.du);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) { r.u[i] = fr + a.dv * (float)i; r.v[i] = fr * a.dv - a.feed * (float)i; }
         return r;
 #endif
         if (load_ok) {
-            r.u = *reinterpret_cast<const float4 *>(bu + (ptrdiff_t)rr * pitch);
-            r.v = *reinterpret_cast<const float4 *>(bv + (ptrdiff_t)rr * pitch);
+            load_cols<CPL>(bu + (ptrdiff_t)rr * pitch, r.u);
+            load_cols<CPL>(bv + (ptrdiff_t)rr * pitch, r.v);
         } else {
-            r.u = make_float4(0.f, 0.f, 0.f, 0.f);
-            r.v = r.u;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) { r.u[i] = 0.f; r.v[i] = 0.f; }
         }
         return r;
     };
 
-    // per-lane masks (all ones = that neighbour column is clipped away).  c is a multiple of 4,
-    // so only the first of a lane's four cells can sit on the global left edge.
-    uint32_t la[4], ra[4];
+    // per-lane masks (all ones = that neighbour column is clipped away).  c is a multiple of CPL,
+    // so only the first of a lane's cells can sit on the global left edge.
+    uint32_t la[CPL], ra[CPL];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < CPL; ++k) {
         la[k] = (EDGE && k == 0 && c == 0) ? 0xffffffffu : 0u;
         ra[k] = (EDGE && (c + k + 1 >= a.cols)) ? 0xffffffffu : 0u;
         if (EDGE) { // keep the masks opaque, or the compiler turns every blend back into v_cndmask
@@ -456,8 +489,8 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
         }
     }
 
-    RowW w[K][3]; // w[j][slot]: level-j rows, newest in slot (tick % 3)
-    RowQ q[3];    // prefetch queue of level-0 rows, 3 ticks deep
+    RowT<CPL> w[K][3]; // w[j][slot]: level-j rows, newest in slot (tick % 3)
+    RowQ<CPL> q[3];    // prefetch queue of level-0 rows, 3 ticks deep
     const int first = ur0 - K; // level-0 row of tick 0
     const int nticks = (ur1 - ur0) + 2 * K;
 #pragma unroll
@@ -467,7 +500,7 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
 #pragma unroll
         for (int sl = 0; sl < 3; ++sl)
 #pragma unroll
-            for (int e = 0; e < 6; ++e) { w[j][sl].u[e] = 0.f; w[j][sl].v[e] = 0.f; }
+            for (int e = 0; e < CPL + 2; ++e) { w[j][sl].u[e] = 0.f; w[j][sl].v[e] = 0.f; }
 
     for (int t = 0; t < nticks; t += 3) {
 #pragma unroll
@@ -475,7 +508,7 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
             const int tick = t + s3;
             if (tick < nticks) {
                 const int l0 = first + tick; // level-0 row entering the pipeline
-                w[0][s3] = widen_tb(q[s3].u, q[s3].v);
+                w[0][s3] = widen_tb<CPL>(q[s3].u, q[s3].v);
                 q[s3] = fetch(l0 + 3);
 #pragma unroll
                 for (int j = 1; j <= K; ++j) {
@@ -484,32 +517,31 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                     const bool need = (row >= ur0 - (K - j)) && (row < ur1 + (K - j)) &&
                                       (!EDGE || ((row >= 0 || a.top_present) && (row < a.rows || a.bottom_present)));
                     if (need) {
-                        const RowW &m = w[j - 1][(s3 + 1) % 3]; // row - 1
-                        const RowW &z = w[j - 1][(s3 + 2) % 3]; // row
-                        const RowW &p = w[j - 1][s3];           // row + 1
+                        const RowT<CPL> &m = w[j - 1][(s3 + 1) % 3]; // row - 1
+                        const RowT<CPL> &z = w[j - 1][(s3 + 2) % 3]; // row
+                        const RowT<CPL> &p = w[j - 1][s3];           // row + 1
                         const bool mrow = !EDGE || (row > 0) || a.top_present;
                         const bool prow = !EDGE || (row + 1 < a.rows) || a.bottom_present;
-                        float4 nu, nv;
+                        float nu[CPL], nv[CPL];
 #if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 2 /* experiment: no arithmetic (memory-only timing) */
-                        nu = make_float4(z.u[1] + m.u[0], z.u[2], z.u[3], z.u[4] + p.u[5]);
-                        nv = make_float4(z.v[1] + m.v[0], z.v[2], z.v[3], z.v[4] + p.v[5]);
+#pragma unroll
+                        for (int k = 0; k < CPL; ++k) { nu[k] = z.u[k + 1] + m.u[k]; nv[k] = z.v[k + 1] + p.v[k + 2]; }
 #else
-                        cell<EDGE, FAST>(a, m, z, p, 1, mrow, prow, la[0], ra[0], nu.x, nv.x);
-                        cell<EDGE, FAST>(a, m, z, p, 2, mrow, prow, la[1], ra[1], nu.y, nv.y);
-                        cell<EDGE, FAST>(a, m, z, p, 3, mrow, prow, la[2], ra[2], nu.z, nv.z);
-                        cell<EDGE, FAST>(a, m, z, p, 4, mrow, prow, la[3], ra[3], nu.w, nv.w);
+#pragma unroll
+                        for (int k = 0; k < CPL; ++k)
+                            cell<EDGE, FAST>(a, m, z, p, k + 1, mrow, prow, la[k], ra[k], nu[k], nv[k]);
 #endif
 #if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 1
                         if (j < K) {
-                            w[j < K ? j : 0][s3] = widen_tb(nu, nv);
-                        } else if (store_ok && nu.x == 12345.678f) {
+                            w[j < K ? j : 0][s3] = widen_tb<CPL>(nu, nv);
+                        } else if (store_ok && nu[0] == 12345.678f) {
 #else
                         if (j < K) {
-                            w[j < K ? j : 0][s3] = widen_tb(nu, nv);
+                            w[j < K ? j : 0][s3] = widen_tb<CPL>(nu, nv);
                         } else if (store_ok) {
 #endif
-                            *reinterpret_cast<float4 *>(a.out_u + (ptrdiff_t)row * pitch + c) = nu;
-                            *reinterpret_cast<float4 *>(a.out_v + (ptrdiff_t)row * pitch + c) = nv;
+                            store_cols<CPL>(a.out_u + (ptrdiff_t)row * pitch + c, nu);
+                            store_cols<CPL>(a.out_v + (ptrdiff_t)row * pitch + c, nv);
                         }
                     }
                 }
@@ -518,15 +550,16 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
     }
 }
 
-template <int K, int FAST>
+template <int K, int FAST, int CPL>
 __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
 {
     // half_diff needs MODE.IEEE = 0: hwreg(HW_REG_MODE, offset 9, width 1).  The bit only governs
     // the quieting of signalling NaNs otherwise, which parity does not cover.
     if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0);
+    constexpr int W = tb_cols_per_wave(K, CPL), S = tb_sacrificial_lanes(K, CPL);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, see above
-    const int strips = (a.cols + kTbCols - 1) / kTbCols;
+    const int strips = (a.cols + W - 1) / W;
     const int unit = blockIdx.x * 4 + wave;
     const int rpu = a.rows_per_unit;
     const int small = a.small_rpu;
@@ -537,8 +570,9 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     // Dispatch order.  Units on a global edge take the general path, which is about twice as
     // slow (per-lane selects); a slow unit that starts in the last round of a launch stretches
     // its tail, so all edge units go first: the left-most and right-most strips of every chunk,
-    // then (below) the first and last chunk, then everything else.
-    const int er = ((strips - 1) * kTbCols + 4 >= a.cols && strips >= 2) ? 2 : 1; // edge strips on the right
+    // then (below) the first and last chunk, then everything else.  A strip is a right-edge strip
+    // when its window, sacrificial lanes included, reaches the last column.
+    const int er = ((strips - 1) * W + S * CPL >= a.cols && strips >= 2) ? 2 : 1; // edge strips on the right
     const int ne = 1 + er;                                                        // ... per chunk
     int chunk, strip;
     if (strips <= ne) {
@@ -568,12 +602,12 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         ur0 = a.rb0 + (chunk - chunks_a) * rpu;
         ur1 = min(ur0 + rpu, a.rb1);
     }
-    const bool edge = (strip == 0) || ((strip + 1) * kTbCols + 4 >= a.cols) ||
+    const bool edge = (strip == 0) || ((strip + 1) * W + S * CPL >= a.cols) ||
                       (ur0 - K < 0 && !a.top_present) || (ur1 + K > a.rows && !a.bottom_present);
     if (edge)
-        tb_march<K, true, FAST>(a, ur0, ur1, strip, lane);
+        tb_march<K, true, FAST, CPL>(a, ur0, ur1, strip, lane);
     else
-        tb_march<K, false, FAST>(a, ur0, ur1, strip, lane);
+        tb_march<K, false, FAST, CPL>(a, ur0, ur1, strip, lane);
 }
 
 #if !GS_TB_OP_ONLY
@@ -727,19 +761,27 @@ hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const
 // K fused steps over the row ranges of GsStepArgs; on slab seams the ghost rows must be K deep.
 hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, const char **name)
 {
-    // ".op": the variant specialised for the default (Oono-Puri) side weights and/or dt == 1
-    static const char *const names[2][4] = {
-        {"tb-k1/" GS_MATH_NAME, "tb-k2/" GS_MATH_NAME, "tb-k3/" GS_MATH_NAME, "tb-k4/" GS_MATH_NAME},
-        {"tb-k1/" GS_MATH_NAME ".op", "tb-k2/" GS_MATH_NAME ".op", "tb-k3/" GS_MATH_NAME ".op",
-         "tb-k4/" GS_MATH_NAME ".op"}};
+    // "cN": N columns per lane (4 = the wide layout); ".op": the variant specialised for the
+    // default (Oono-Puri) side weights, with or without dt == 1
+#define GS_TB_NAMES(C)                                                                          \
+    {{"tb-k1" C "/" GS_MATH_NAME, "tb-k2" C "/" GS_MATH_NAME, "tb-k3" C "/" GS_MATH_NAME, "tb-k4" C "/" GS_MATH_NAME}, \
+     {"tb-k1" C "/" GS_MATH_NAME ".op", "tb-k2" C "/" GS_MATH_NAME ".op", "tb-k3" C "/" GS_MATH_NAME ".op",            \
+      "tb-k4" C "/" GS_MATH_NAME ".op"}}
+    static const char *const names[3][2][4] = {GS_TB_NAMES("c1"), GS_TB_NAMES("c2"), GS_TB_NAMES("")};
+#undef GS_TB_NAMES
     if (k < 1 || k > 4 || a.cols <= 0 || a.rows_per_unit <= 0) return hipErrorInvalidValue;
+    const int cpl = a.cpl == 0 ? 4 : a.cpl;
+    if (cpl != 1 && cpl != 2 && cpl != 4) return hipErrorInvalidValue;
     // The fused build has no use for bit 0 (its taps are sub + fma already) and measured slower
-    // with bit 1 (profiles/r01_sweeps.md, run 48/49): it always runs the general variant.
-    const int fast = a.fast & (GS_MATH_FUSED ? 0 : 3);
-    if (name) *name = names[fast ? 1 : 0][k - 1];
+    // with bit 1 (profiles/r01_sweeps.md, runs 48/49): it always runs the general variant.  dt == 1
+    // alone (fast == 2) is not worth a variant either.
+    int fast = a.fast & (GS_MATH_FUSED ? 0 : 3);
+    if (fast == 2) fast = 0;
+    if (name) *name = names[cpl == 1 ? 0 : (cpl == 2 ? 1 : 2)][fast ? 1 : 0][k - 1];
     const long rpu = a.rows_per_unit;
     const long rows_a = (long)a.ra1 - a.ra0;
-    const long strips = (a.cols + kTbCols - 1) / kTbCols;
+    const long W = tb_cols_per_wave(k, cpl);
+    const long strips = (a.cols + W - 1) / W;
     // Tapered tail: when the launch has many more units than the chip has wave slots (2048 at
     // 2 waves per SIMD), the last ~2 x 2048 units are cut to a quarter of the unit height, so that
     // the drain phase at the end of the launch is short (dependent launches cannot overlap).
@@ -763,13 +805,20 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     args.small_rpu = (int32_t)small;
     void *kargs[] = {&args};
     const void *fn = nullptr;
-    switch (fast ? 0 : k) {
-    case 0: fn = gs_tb_op_kernel_strict(k, fast); break;
-    case 1: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<1, 0>); break;
-    case 2: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<2, 0>); break;
-    case 3: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<3, 0>); break;
-    default: fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 0>); break;
+#define GS_TB_CASE(KK, CC)                                                                      \
+    case (KK) * 8 + (CC): fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<KK, 0, CC>); break;
+    if (fast) {
+#if !GS_MATH_FUSED
+        fn = gs_tb_op_kernel_strict(k, fast, cpl);
+#endif
+    } else {
+        switch (k * 8 + cpl) {
+            GS_TB_CASE(1, 4) GS_TB_CASE(2, 4) GS_TB_CASE(3, 4) GS_TB_CASE(4, 4)
+            GS_TB_CASE(1, 2) GS_TB_CASE(2, 2) GS_TB_CASE(3, 2) GS_TB_CASE(4, 2)
+            GS_TB_CASE(1, 1) GS_TB_CASE(2, 1) GS_TB_CASE(3, 1) GS_TB_CASE(4, 1)
+        }
     }
+#undef GS_TB_CASE
     if (!fn) return hipErrorInvalidValue;
     return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), kargs, 0, s);
 }
@@ -792,17 +841,20 @@ hipError_t GS_SUFFIX(gs_launch_lds)(const GsStepArgs &a, hipStream_t s, const ch
 #endif // !GS_TB_OP_ONLY
 
 #if GS_TB_OP_ONLY
-// Kernel entry of the specialised variant for K fused steps and `fast` in 1..3 (GsStepArgs::fast).
-const void *gs_tb_op_kernel_strict(int k, int fast)
+// Kernel entry of the specialised variant for K fused steps, `fast` in {1, 3} (GsStepArgs::fast)
+// and `cpl` columns per lane.
+const void *gs_tb_op_kernel_strict(int k, int fast, int cpl)
 {
-#define GS_TB_CASE(KK, FF)                                                                      \
-    case (KK) * 4 + (FF): return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<KK, FF>);
-    switch (k * 4 + fast) {
-        GS_TB_CASE(1, 1) GS_TB_CASE(2, 1) GS_TB_CASE(3, 1) GS_TB_CASE(4, 1)
-        GS_TB_CASE(1, 2) GS_TB_CASE(2, 2) GS_TB_CASE(3, 2) GS_TB_CASE(4, 2)
-        GS_TB_CASE(1, 3) GS_TB_CASE(2, 3) GS_TB_CASE(3, 3) GS_TB_CASE(4, 3)
+#define GS_TB_CASE(KK, FF, CC)                                                                  \
+    case ((KK) * 4 + (FF)) * 8 + (CC): return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<KK, FF, CC>);
+#define GS_TB_CASES(FF, CC) GS_TB_CASE(1, FF, CC) GS_TB_CASE(2, FF, CC) GS_TB_CASE(3, FF, CC) GS_TB_CASE(4, FF, CC)
+    switch ((k * 4 + fast) * 8 + cpl) {
+        GS_TB_CASES(1, 4) GS_TB_CASES(3, 4)
+        GS_TB_CASES(1, 2) GS_TB_CASES(3, 2)
+        GS_TB_CASES(1, 1) GS_TB_CASES(3, 1)
     default: return nullptr;
     }
+#undef GS_TB_CASES
 #undef GS_TB_CASE
 }
 #endif

@@ -75,6 +75,7 @@ class HipArgs:
     pitch_pad: int = field(default_factory=lambda: _env_int("GS_HIP_PITCH_PAD", 0))
     split: int = field(default_factory=lambda: _env_int("GS_HIP_SPLIT", 0))
     general_kernels: int = field(default_factory=lambda: _env_int("GS_HIP_GENERAL_KERNELS", 0))
+    cols_per_lane: int = field(default_factory=lambda: _env_int("GS_HIP_COLS_PER_LANE", 0))
     rank: int = 0
     world: int = 1
     unique_id: Optional[bytes] = None
@@ -86,6 +87,7 @@ class HipArgs:
         o.use_graph, o.pitch_pad = self.use_graph, self.pitch_pad
         o.split = self.split
         o.general_kernels = self.general_kernels
+        o.cols_per_lane = self.cols_per_lane
         return o
 
 

@@ -102,13 +102,17 @@ typedef struct gs_options {
     int32_t fuse_steps;      /* steps fused per launch in gs_run (1..4; 0 = auto); single slab */
     int32_t use_graph;       /* 1 = replay gs_run batches through a hipGraph (0 = off)     */
     int32_t pitch_pad;       /* extra f32 of row pitch beyond the 64-float round-up        */
-    int32_t split;           /* row bands a single slab is scheduled as (0 = auto, 1 = off):   *
-                              * adjacent bands only depend on each other's K boundary rows, so *
-                              * the tail of one pass overlaps the start of the next            */
+    int32_t split;           /* row bands a single slab is scheduled as (0 or 1 = off): adjacent  *
+                              * bands only depend on each other's K boundary rows, so the tail *
+                              * of one pass overlaps the start of the next.  Opt-in: the gain  *
+                              * (up to +3 % at 16384^2) is not stable from box to box          */
     int32_t general_kernels; /* 1 = never use the kernel variants specialised for the default  *
                               * side weights (0.5) / dt == 1; results are bit-identical either *
                               * way, the switch exists for A/B timing and tests                */
-    int32_t reserved[8];
+    int32_t cols_per_lane;   /* columns per lane of the temporally blocked kernel: 4 (wide, for  *
+                              * large grids), 2 or 1 (more, narrower waves for small grids);   *
+                              * 0 = chosen on line by gs_run                                   */
+    int32_t reserved[7];
 } gs_options;
 
 typedef struct gs_ctx gs_ctx;     /* devices, streams, row partition, RCCL communicator    */

@@ -29,7 +29,8 @@ pub struct gs_options {
     pub pitch_pad: i32,
     pub split: i32,
     pub general_kernels: i32,
-    pub reserved: [i32; 8],
+    pub cols_per_lane: i32,
+    pub reserved: [i32; 7],
 }
 
 #[repr(C)]

@@ -132,16 +132,21 @@ def test_fused_refuses_non_power_of_two_weights():
 
 
 # ---- temporal blocking: K fused steps per launch are bit-identical to K single steps ---------
+@pytest.mark.parametrize("cpl", [4, 2, 1])
 @pytest.mark.parametrize("fuse", [1, 2, 3, 4])
-def test_temporal_blocking_bit_exact(fuse):
+def test_temporal_blocking_bit_exact(fuse, cpl):
+    """K fused steps, wide and narrow lane layouts; the widths straddle the strip widths of every
+    (K, columns per lane) pair: (64 - 2 * ceil(K / cpl)) * cpl output columns per wave."""
     for shape in [(1, 1), (1, 7), (7, 1), (2, 2), (3, 5), (17, 33), (64, 128), (250, 130), (9, 247), (9, 248),
-                  (9, 249), (30, 252), (30, 253), (41, 500), (12, 1030)]:
+                  (9, 249), (30, 252), (30, 253), (41, 500), (12, 1030), (9, 55), (9, 56), (9, 57), (7, 61),
+                  (7, 62), (7, 63), (11, 119), (11, 120), (11, 121), (11, 124), (11, 125), (5, 113)]:
         u0, v0 = stress_fields(shape, 2)
         for steps in (1, 4, 7):
             ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True)
             got_u, got_v, info = gpu_run(u0, v0, steps, args=args(kernel=capi.GS_KERNEL_TB, fuse_steps=fuse,
-                                                                  rows_per_block=5))
+                                                                  rows_per_block=5, cols_per_lane=cpl))
             assert info[0].startswith("tb-k"), info
+            assert ("c%d/" % cpl in info[0]) == (cpl != 4), info
             assert_bits_equal(got_u, ref_u, f"TB{fuse} U {shape} steps {steps}")
             assert_bits_equal(got_v, ref_v, f"TB{fuse} V {shape} steps {steps}")
 
@@ -202,16 +207,18 @@ def test_single_slab_row_bands_bit_exact(split):
     assert_bits_equal(in_v.make_scalar_view(sim.context), ref[1], "V bands + single steps")
 
 
-def test_auto_row_bands_on_a_large_grid():
-    """8192 x 8192 = 2^26 cells turns the band schedule on by default; compare with the
-    single-step kernel run step by step."""
+@pytest.mark.parametrize("split", [0, 2])
+def test_row_bands_on_a_large_grid(split):
+    """8192 x 8192 with the default schedule and with two row bands (plus the on-line tuning
+    passes of a 300-step run); compare with the single-step kernel run step by step."""
     rows = cols = 8192
     rng = np.random.default_rng(21)
     u0 = rng.random((rows, cols), dtype=np.float32)
     v0 = (rng.random((rows, cols), dtype=np.float32) * np.float32(0.5)).astype(np.float32)
-    ref = gpu_run(u0, v0, 14, args=args(kernel=capi.GS_KERNEL_STREAM))
-    got = gpu_run(u0, v0, 14)
-    assert got[2][0].startswith("tb-k4")
+    steps = 14 if split == 0 else 300
+    ref = gpu_run(u0, v0, steps, args=args(kernel=capi.GS_KERNEL_STREAM))
+    got = gpu_run(u0, v0, steps, args=args(split=split))
+    assert got[2][0].startswith("tb-k"), got[2]
     assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32))
     assert np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32))
 
@@ -235,8 +242,8 @@ def _tiny_fields(shape, seed):
 
 
 @pytest.mark.parametrize("general", [0, 1])
-@pytest.mark.parametrize("fuse", [1, 2, 3, 4])
-def test_specialised_variants_bit_exact(fuse, general):
+@pytest.mark.parametrize("fuse,cpl", [(1, 4), (2, 4), (3, 4), (4, 4), (4, 2), (3, 1), (4, 1), (2, 2)])
+def test_specialised_variants_bit_exact(fuse, cpl, general):
     """GsStepArgs::fast: side weights == 0.5 (v_sub_f32 div:2 instead of sub, mul) and dt == 1
     (no multiply) are specialisations of the strict kernel that must not change one bit, with
     ordinary data and with data around the flush-to-zero threshold (the output modifier flushes
@@ -246,7 +253,7 @@ def test_specialised_variants_bit_exact(fuse, general):
         (Parameters(), True),                                                       # both
         (Parameters(time_step=0.5), True),                                          # sides only
         (Parameters(weights=quarter_corners, diffusion_rate_u=0.05), True),         # both, other corners
-        (Parameters(weights=((0.25, 0.5, 0.25), (0.5, 0, 0.25), (0.25, 0.5, 0.25))), True),   # dt only
+        (Parameters(weights=((0.25, 0.5, 0.25), (0.5, 0, 0.25), (0.25, 0.5, 0.25))), False),  # dt == 1 alone: no variant
         (Parameters(weights=((0.25, 0.5, 0.25), (0.5, 0, 0.25), (0.25, 0.5, 0.25)), time_step=0.75), False),
     ]
     for p, special in cases:
@@ -256,7 +263,7 @@ def test_specialised_variants_bit_exact(fuse, general):
                 ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True)
                 got_u, got_v, info = gpu_run(u0, v0, steps, params=p,
                                              args=args(kernel=capi.GS_KERNEL_TB, fuse_steps=fuse, rows_per_block=12,
-                                                       general_kernels=general))
+                                                       general_kernels=general, cols_per_lane=cpl))
                 assert (".op" in info[0]) == (special and not general), (info, p)
                 assert_bits_equal(got_u, ref_u, f"U {info[0]} {shape} steps {steps} {p}")
                 assert_bits_equal(got_v, ref_v, f"V {info[0]} {shape} steps {steps} {p}")

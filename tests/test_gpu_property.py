@@ -27,7 +27,11 @@ def cases(draw):
     rpb = draw(st.sampled_from([0, 1, 2, 3, 5, 8, 16, 33]))
     split = draw(st.integers(0, 4))
     slabs = draw(st.integers(1, 4))
+    cpl = draw(st.sampled_from([0, 1, 2, 4]))
+    general = draw(st.integers(0, 1))
     w = [[draw(st.sampled_from(POW2)) for _ in range(3)] for _ in range(3)]
+    if draw(st.booleans()):                       # the default side weights: specialised kernels
+        w[0][1] = w[1][0] = w[1][2] = w[2][1] = 0.5
     p = Parameters(weights=tuple(tuple(r) for r in w),
                    diffusion_rate_u=draw(st.sampled_from([0.1, 0.2, 0.05])),
                    diffusion_rate_v=draw(st.sampled_from([0.05, 0.1])),
@@ -35,13 +39,13 @@ def cases(draw):
                    kill_rate=draw(st.sampled_from([0.054, 0.06])),
                    time_step=draw(st.sampled_from([1.0, 0.5, 0.75])))
     tiny = draw(st.booleans())  # sprinkle values near the flush-to-zero threshold
-    return rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny
+    return rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny, cpl, general
 
 
-@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
 @given(cases())
 def test_any_schedule_matches_the_oracle(built, case):
-    rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny = case
+    rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny, cpl, general = case
     slabs = min(slabs, rows)
     rng = np.random.default_rng(seed)
     u0 = rng.random((rows, cols), dtype=np.float32)
@@ -55,7 +59,8 @@ def test_any_schedule_matches_the_oracle(built, case):
     ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True)
     got_u, got_v, info = gpu_run(u0, v0, steps, params=p,
                                  args=args(kernel=kernel, fuse_steps=fuse, rows_per_block=rpb, split=split,
-                                           devices=[0] * slabs))
-    what = f"{rows}x{cols} steps={steps} kernel={info[0]} fuse={fuse} rpb={rpb} split={split} slabs={slabs}"
+                                           devices=[0] * slabs, cols_per_lane=cpl, general_kernels=general))
+    what = (f"{rows}x{cols} steps={steps} kernel={info[0]} fuse={fuse} rpb={rpb} split={split} slabs={slabs} "
+            f"cpl={cpl} general={general} {p}")
     assert_bits_equal(got_u, ref_u, "U " + what)
     assert_bits_equal(got_v, ref_v, "V " + what)

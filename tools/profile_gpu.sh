@@ -15,7 +15,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 # Pin the unit height so that every profiled launch is the same kernel configuration (an
 # un-pinned run spends its first passes trying several heights, gs_run's on-line tuning).
-export GS_HIP_ROWS_PER_BLOCK=${GS_HIP_ROWS_PER_BLOCK:-64}
+export GS_HIP_ROWS_PER_BLOCK=${GS_HIP_ROWS_PER_BLOCK:-128}
 cd /tmp
 EXTRA=${GS_BENCH_EXTRA:-}
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
