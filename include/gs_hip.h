@@ -100,7 +100,8 @@ typedef struct gs_options {
     int32_t kernel;          /* gs_kernel; default AUTO                                    */
     int32_t rows_per_block;  /* rows each wave marches over (0 = auto)                     */
     int32_t fuse_steps;      /* steps fused per launch in gs_run (1..4; 0 = auto); single slab */
-    int32_t use_graph;       /* 1 = replay gs_run batches through a hipGraph (0 = off)     */
+    int32_t use_graph;       /* 1 = gs_run replays batches of 16 passes through a hipGraph: one host-side *
+                              * launch per batch (single slab, no row bands; 0 = off)                   */
     int32_t pitch_pad;       /* extra f32 of row pitch beyond the 64-float round-up        */
     int32_t split;           /* row bands a single slab is scheduled as (0 or 1 = off): adjacent  *
                               * bands only depend on each other's K boundary rows, so the tail *

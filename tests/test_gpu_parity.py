@@ -224,6 +224,41 @@ def test_row_bands_on_a_large_grid(split):
 
 
 # ---- non-default parameters (CLI overrides -k -f -t, ui/src/lib.rs:51-63) and weights ------
+# ---- hipGraph replay of pass batches (gs_options.use_graph) -----------------------------------
+def test_graph_replay_bit_exact_and_invalidated_by_every_input():
+    """Batches of 16 passes replayed through a hipGraph: same bits; the captured launches carry
+    plane addresses, shape, tuning and parameters, so changing any of them must rebuild the graph
+    (two species alternating on one context, parameters changed between runs, pinned unit height)."""
+    g = np.load(os.path.join(GOLDEN, "species_new_64x128.npz"))
+    sim = Simulation.new(Parameters(), args(use_graph=1))
+    species = sim.make_species([64, 128])
+    sim.perform_steps(species, 1000)          # tuning passes first, then graph batches, then a remainder
+    in_u, in_v, _, _ = species.in_out()
+    assert_bits_equal(in_u.make_scalar_view(sim.context), g["u_1000"], "graph U 1000")
+    assert_bits_equal(in_v.make_scalar_view(sim.context), g["v_1000"], "graph V 1000")
+
+    u0, v0 = stress_fields((41, 500), 8)
+    u1, v1 = stress_fields((41, 500), 9)
+    p2 = Parameters(feed_rate=0.03, kill_rate=0.06, time_step=0.5)
+    sim = Simulation.new(Parameters(), args(use_graph=1, rows_per_block=8))
+    a, b = species_from_arrays(sim, u0, v0), species_from_arrays(sim, u1, v1)
+    done_a = done_b = 0
+    ref_a, ref_b = (u0, v0), (u1, v1)
+    for params, steps in ((Parameters(), 150), (p2, 131), (Parameters(), 64)):
+        sim.context.set_params(params)
+        for sp, which in ((a, "a"), (b, "b"), (a, "a")):
+            sim.perform_steps(sp, steps)
+            if which == "a":
+                ref_a = oracle.run(ref_a[0], ref_a[1], steps, oracle_params(params), ftz=True)
+                ref = ref_a
+            else:
+                ref_b = oracle.run(ref_b[0], ref_b[1], steps, oracle_params(params), ftz=True)
+                ref = ref_b
+            iu, iv, _, _ = sp.in_out()
+            assert_bits_equal(iu.make_scalar_view(sim.context), ref[0], f"graph U {which} {steps} {params}")
+            assert_bits_equal(iv.make_scalar_view(sim.context), ref[1], f"graph V {which} {steps} {params}")
+
+
 # ---- parameter-specialised variants of the temporal-blocking kernel ---------------------------
 def _tiny_fields(shape, seed):
     """The left 60 % of the columns hold values of both signs around the flush threshold (2^-130 ..

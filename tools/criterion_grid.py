@@ -6,7 +6,9 @@ that the work is actually done), throughput in cells x steps per second as crite
 
     python tools/criterion_grid.py [--cpu]     # --cpu adds the parallel(block(autovec)) port
 
-Prints a markdown table (median of 7 timed iterations after 2 warm-up iterations).
+Prints a markdown table: like criterion, every benchmark first iterates for a warm-up time (0.5 s
+here, 3 s in criterion's default) -- the library finishes its on-line tuning for the shape in that
+time -- and then reports the median of 15 timed iterations.
 """
 import argparse
 import os
@@ -23,12 +25,13 @@ from grayscott_amd import HipArgs, Parameters, Simulation  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="gs_options.use_graph = 1")
     a = ap.parse_args()
     steps_list = [1, 16, 256]
     print("| rows x cols | " + " | ".join(f"HIP {s} steps" for s in steps_list) +
           (" | CPU port 16 steps |" if a.cpu else " |"))
     print("|---|" + "---|" * (len(steps_list) + (1 if a.cpu else 0)))
-    sim = Simulation.new(Parameters(), HipArgs(devices=[0]))
+    sim = Simulation.new(Parameters(), HipArgs(devices=[0], use_graph=1 if a.graph else 0))
     for k in range(3, 12):
         size = 2 ** k
         shape = (size, 2 * size)
@@ -37,12 +40,15 @@ def main():
         row = [f"{shape[0]} x {shape[1]}"]
         for steps in steps_list:
             times = []
-            for it in range(9):
+            t_end = time.perf_counter() + 0.5
+            while time.perf_counter() < t_end:
+                sim.perform_steps(species, steps)
+                sim.context.sync()
+            for it in range(15):
                 t0 = time.perf_counter()
                 sim.perform_steps(species, steps)
                 sim.context.sync()
-                if it >= 2:
-                    times.append(time.perf_counter() - t0)
+                times.append(time.perf_counter() - t0)
             row.append(f"{cells * steps / statistics.median(times) / 1e6:.1f}")
         if a.cpu:
             from oracle import cpu_parallel
