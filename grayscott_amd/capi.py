@@ -22,6 +22,7 @@ GS_ERR_NOMEM = -6
 
 GS_MATH_STRICT, GS_MATH_FUSED = 0, 1
 GS_KERNEL_AUTO, GS_KERNEL_SIMPLE, GS_KERNEL_STREAM, GS_KERNEL_TB, GS_KERNEL_LDS = 0, 1, 2, 3, 4
+GS_BOUNDARY_CLIPPED, GS_BOUNDARY_ZERO_HALO = 0, 1
 GS_UNIQUE_ID_BYTES = 128
 
 # Every symbol include/gs_hip.h declares; tests check that the library exports them all.
@@ -69,7 +70,8 @@ class GsOptions(ctypes.Structure):
         ("split", ctypes.c_int32),
         ("general_kernels", ctypes.c_int32),
         ("cols_per_lane", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 7),
+        ("boundary", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 6),
     ]
 
 

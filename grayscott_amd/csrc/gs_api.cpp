@@ -420,6 +420,7 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
     a.ghost = kGhostRows;
     a.rows_per_unit = pick_rows_per_unit(ctx, a.rows, a.cols, fuse);
     a.cpl = pick_cols_per_lane(ctx, a.rows, a.cols, fuse);
+    a.zero_halo = ctx->o.boundary == GS_BOUNDARY_ZERO_HALO;
     std::memcpy(a.w, ctx->p.w, sizeof a.w);
     a.du = ctx->p.du;
     a.dv = ctx->p.dv;
@@ -756,6 +757,8 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
     if (st == GS_OK && ctx->o.cols_per_lane != 0 && ctx->o.cols_per_lane != 1 && ctx->o.cols_per_lane != 2 &&
         ctx->o.cols_per_lane != 4)
         st = fail(GS_ERR_INVALID, "cols_per_lane must be 0 (auto), 1, 2 or 4, not %d", ctx->o.cols_per_lane);
+    if (st == GS_OK && ctx->o.boundary != GS_BOUNDARY_CLIPPED && ctx->o.boundary != GS_BOUNDARY_ZERO_HALO)
+        st = fail(GS_ERR_INVALID, "unknown boundary rule %d", ctx->o.boundary);
     if (st != GS_OK) { delete ctx; return st; }
 
     const int32_t one = 0;

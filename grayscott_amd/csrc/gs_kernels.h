@@ -31,6 +31,9 @@ struct GsStepArgs {
     int32_t fast;
     // Columns per lane of the temporal-blocking kernel: 4 (0 means 4), 2 or 1.
     int32_t cpl;
+    // Boundary rule on global edges: 0 = naive's clipped window (weights anchored at the window's
+    // top-left corner), 1 = full window with zeros outside the grid (gs_boundary in gs_hip.h).
+    int32_t zero_halo;
     float w[3][3];         // stencil weights, row-major (parameters.rs:87-88)
     float du, dv, feed, feed_plus_kill, dt;
 };

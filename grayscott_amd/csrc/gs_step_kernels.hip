@@ -128,15 +128,26 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_simple_k)(GsStepArgs a)
     const float u = a.in_u[o], v = a.in_v[o];
 
     float acc_u = 0.0f, acc_v = 0.0f;
-    const int i_off = top ? 1 : 0, j_off = left ? 1 : 0;
-    for (int di = top ? -1 : 0; di <= (bottom ? 1 : 0); ++di)
-        for (int dj = left ? -1 : 0; dj <= (right ? 1 : 0); ++dj) {
-            const float w = a.w[di + i_off][dj + j_off];
-            const float su = a.in_u[o + di * pitch + dj];
-            const float sv = a.in_v[o + di * pitch + dj];
-            GS_TAP(acc_u, w, su, u);
-            GS_TAP(acc_v, w, sv, v);
-        }
+    if (a.zero_halo) { // full window, centred weights, zeros outside the grid
+        for (int di = -1; di <= 1; ++di)
+            for (int dj = -1; dj <= 1; ++dj) {
+                const bool inside = (di >= 0 || top) && (di <= 0 || bottom) && (dj >= 0 || left) && (dj <= 0 || right);
+                const float su = inside ? a.in_u[o + di * pitch + dj] : 0.0f;
+                const float sv = inside ? a.in_v[o + di * pitch + dj] : 0.0f;
+                GS_TAP(acc_u, a.w[di + 1][dj + 1], su, u);
+                GS_TAP(acc_v, a.w[di + 1][dj + 1], sv, v);
+            }
+    } else {
+        const int i_off = top ? 1 : 0, j_off = left ? 1 : 0;
+        for (int di = top ? -1 : 0; di <= (bottom ? 1 : 0); ++di)
+            for (int dj = left ? -1 : 0; dj <= (right ? 1 : 0); ++dj) {
+                const float w = a.w[di + i_off][dj + j_off];
+                const float su = a.in_u[o + di * pitch + dj];
+                const float sv = a.in_v[o + di * pitch + dj];
+                GS_TAP(acc_u, w, su, u);
+                GS_TAP(acc_v, w, sv, v);
+            }
+    }
     float ou, ov;
     react(a, u, v, acc_u, acc_v, ou, ov);
     a.out_u[o] = ou;
@@ -240,6 +251,26 @@ __device__ __forceinline__ void cell(const GsStepArgs &a, const Row &m, const Ro
         GS_TAP(acc_u, a.w[2][0], p.u[k - 1], u); GS_TAP(acc_v, a.w[2][0], p.v[k - 1], v);
         GS_TAP(acc_u, a.w[2][1], p.u[k], u);     GS_TAP(acc_v, a.w[2][1], p.v[k], v);
         GS_TAP(acc_u, a.w[2][2], p.u[k + 1], u); GS_TAP(acc_v, a.w[2][2], p.v[k + 1], v);
+    } else if (a.zero_halo) {
+        // GS_BOUNDARY_ZERO_HALO: all nine taps, centred weights; a neighbour outside the grid reads
+        // as 0 (per-lane column masks, wave-uniform row flags).
+#define GS_ROW_TAPS_Z(R, WI, PRESENT, WITH_CENTRE)                                             \
+    {                                                                                          \
+        const float ul = (PRESENT) ? blend(la, 0.0f, R.u[k - 1]) : 0.0f;                       \
+        const float vl = (PRESENT) ? blend(la, 0.0f, R.v[k - 1]) : 0.0f;                       \
+        const float ur = (PRESENT) ? blend(ra, 0.0f, R.u[k + 1]) : 0.0f;                       \
+        const float vr = (PRESENT) ? blend(ra, 0.0f, R.v[k + 1]) : 0.0f;                       \
+        GS_TAP(acc_u, a.w[WI][0], ul, u); GS_TAP(acc_v, a.w[WI][0], vl, v);                    \
+        if (WITH_CENTRE) {                                                                     \
+            GS_TAP(acc_u, a.w[WI][1], (PRESENT) ? R.u[k] : 0.0f, u);                           \
+            GS_TAP(acc_v, a.w[WI][1], (PRESENT) ? R.v[k] : 0.0f, v);                           \
+        }                                                                                      \
+        GS_TAP(acc_u, a.w[WI][2], ur, u); GS_TAP(acc_v, a.w[WI][2], vr, v);                    \
+    }
+        GS_ROW_TAPS_Z(m, 0, mrow, true)
+        GS_ROW_TAPS_Z(z, 1, true, false)
+        GS_ROW_TAPS_Z(p, 2, prow, true)
+#undef GS_ROW_TAPS_Z
     } else {
         // Weight row of the centre row: 1 normally, 0 when the row above is clipped away.
         // Weight column of the centre column: 1 normally, 0 when the left column is clipped.

@@ -32,6 +32,16 @@ from .capi import GsError
 
 STENCIL_WEIGHTS = ((0.25, 0.5, 0.25), (0.5, 0.0, 0.5), (0.25, 0.5, 0.25))  # parameters.rs:116-122
 
+# The reference picks its stencil at compile time with cargo features (data/Cargo.toml:28-58,
+# parameters.rs:91-122); here every set is a run-time value of ``Parameters.weights`` (the
+# reference's ``weights-runtime`` feature).  Only the power-of-two sets can use GS_MATH_FUSED.
+STENCILS = {
+    "oono-puri": STENCIL_WEIGHTS,                                                    # default
+    "5points": ((0.0, 1.0, 0.0), (1.0, 0.0, 1.0), (0.0, 1.0, 0.0)),                 # weights-5points
+    "patrakarttunen": ((1 / 6, 4 / 6, 1 / 6), (4 / 6, 0.0, 4 / 6), (1 / 6, 4 / 6, 1 / 6)),   # weights-patrakarttunen
+    "pretty": ((1.0, 1.0, 1.0), (1.0, 1.0, 1.0), (1.0, 1.0, 1.0)),                  # weights-pretty
+}
+
 
 @dataclass
 class Parameters:
@@ -43,6 +53,11 @@ class Parameters:
     feed_rate: float = 0.014
     kill_rate: float = 0.054
     time_step: float = 1.0
+
+    @classmethod
+    def with_stencil(cls, name: str, **kw) -> "Parameters":
+        """Default parameters with one of the reference's named stencils (``STENCILS``)."""
+        return cls(weights=STENCILS[name], **kw)
 
     def to_c(self) -> capi.GsParams:
         p = capi.GsParams()
@@ -76,6 +91,7 @@ class HipArgs:
     split: int = field(default_factory=lambda: _env_int("GS_HIP_SPLIT", 0))
     general_kernels: int = field(default_factory=lambda: _env_int("GS_HIP_GENERAL_KERNELS", 0))
     cols_per_lane: int = field(default_factory=lambda: _env_int("GS_HIP_COLS_PER_LANE", 0))
+    boundary: int = field(default_factory=lambda: _env_int("GS_HIP_BOUNDARY", capi.GS_BOUNDARY_CLIPPED))
     rank: int = 0
     world: int = 1
     unique_id: Optional[bytes] = None
@@ -88,6 +104,7 @@ class HipArgs:
         o.split = self.split
         o.general_kernels = self.general_kernels
         o.cols_per_lane = self.cols_per_lane
+        o.boundary = self.boundary
         return o
 
 

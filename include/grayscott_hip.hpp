@@ -40,6 +40,20 @@ struct Parameters {
     Precision diffusion_rate_u = 0.1f, diffusion_rate_v = 0.05f;
     Precision feed_rate = 0.014f, kill_rate = 0.054f, time_step = 1.0f;
 
+    // the reference's compile-time stencil choices (data/Cargo.toml:28-58, parameters.rs:91-122) as
+    // run-time values: "oono-puri" (default), "5points", "patrakarttunen", "pretty"
+    static Parameters with_stencil(const std::string &name)
+    {
+        Parameters p;
+        if (name == "5points") p.weights = {{{0.f, 1.f, 0.f}, {1.f, 0.f, 1.f}, {0.f, 1.f, 0.f}}};
+        else if (name == "patrakarttunen") {
+            const Precision a = 1.0f / 6.0f, b = 4.0f / 6.0f;
+            p.weights = {{{a, b, a}, {b, 0.f, b}, {a, b, a}}};
+        } else if (name == "pretty") p.weights = {{{1.f, 1.f, 1.f}, {1.f, 1.f, 1.f}, {1.f, 1.f, 1.f}}};
+        else if (name != "oono-puri") throw std::invalid_argument("unknown stencil " + name);
+        return p;
+    }
+
     gs_params to_c() const
     {
         gs_params p;
@@ -58,6 +72,7 @@ struct Parameters {
 struct HipArgs {
     std::vector<int32_t> devices{0};
     int32_t math = GS_MATH_STRICT, kernel = GS_KERNEL_AUTO, rows_per_block = 0;
+    int32_t boundary = GS_BOUNDARY_CLIPPED;
 };
 
 // Concentration::Context: owner of the gs_ctx.
@@ -71,6 +86,7 @@ class HipContext {
         o.math = args.math;
         o.kernel = args.kernel;
         o.rows_per_block = args.rows_per_block;
+        o.boundary = args.boundary;
         check(gs_ctx_create(&ctx_, &p, &o, args.devices.data(), (int32_t)args.devices.size(), 0, 1, nullptr));
     }
     ~HipContext() { gs_ctx_destroy(ctx_); }

@@ -93,6 +93,15 @@ typedef enum gs_kernel {
                               alternative to STREAM; never chosen by AUTO)                   */
 } gs_kernel;
 
+/* Rule on the edges of the global grid.  The reference has two:
+ * CLIPPED   -- compute_naive's, the parity target: the 3x3 window is clipped to the grid and the
+ *              weights are indexed from the clipped window's top-left corner
+ *              (compute/naive/src/lib.rs:57-71);
+ * ZERO_HALO -- the Vulkan and SIMD backends': full window, weights centred, cells outside the grid
+ *              read as 0 (compute/gpu/naive/src/pipeline.rs:105-113, main.comp:37-44;
+ *              data/src/concentration/simd/mod.rs:281-326), here with naive's operation order. */
+enum gs_boundary { GS_BOUNDARY_CLIPPED = 0, GS_BOUNDARY_ZERO_HALO = 1 };
+
 /* Backend options: the C view of the Rust `CliArgs` (compute/shared/src/lib.rs:20-25 --
  * every field has a default; zero-initialise and override). */
 typedef struct gs_options {
@@ -113,7 +122,8 @@ typedef struct gs_options {
     int32_t cols_per_lane;   /* columns per lane of the temporally blocked kernel: 4 (wide, for  *
                               * large grids), 2 or 1 (more, narrower waves for small grids);   *
                               * 0 = chosen on line by gs_run                                   */
-    int32_t reserved[7];
+    int32_t boundary;        /* gs_boundary; default CLIPPED                                     */
+    int32_t reserved[6];
 } gs_options;
 
 typedef struct gs_ctx gs_ctx;     /* devices, streams, row partition, RCCL communicator    */

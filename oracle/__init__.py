@@ -11,6 +11,8 @@ bit-for-bit agreement with the independently written numpy restatement
 (``oracle.numpy_ref``); see ``oracle/gs_oracle.c`` for the file:line citations.
 """
 from .cpu_oracle import (  # noqa: F401
+    CLIPPED,
+    ZERO_HALO,
     Params,
     build,
     default_params,

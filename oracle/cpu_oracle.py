@@ -71,6 +71,8 @@ def _lib():
         lib.gs_oracle_step_rows.restype = None
         lib.gs_oracle_run.argtypes = [fp, fp, fp, fp, sz, sz, pp, sz, ctypes.c_int, ctypes.c_int]
         lib.gs_oracle_run.restype = ctypes.c_int
+        lib.gs_oracle_set_boundary.argtypes = [ctypes.c_int]
+        lib.gs_oracle_set_boundary.restype = ctypes.c_int
         _LIB = lib
     return _LIB
 
@@ -114,23 +116,42 @@ def step_rows(u, v, out_u, out_v, params: Params, r0: int, r1: int, ftz: bool = 
                                ctypes.byref(params), r0, r1, int(ftz), nthreads)
 
 
-def step(u, v, params: Params | None = None, ftz: bool = True, nthreads: int = 0):
-    """One naive step of the whole grid; returns new (U, V)."""
+CLIPPED, ZERO_HALO = 0, 1   # boundary rules: naive's clipped window (parity target) / zero halo
+
+
+class _Boundary:
+    """``with _Boundary(rule):`` runs the enclosed steps with that boundary rule."""
+
+    def __init__(self, rule: int):
+        self.rule = rule
+
+    def __enter__(self):
+        self.was = _lib().gs_oracle_set_boundary(self.rule)
+
+    def __exit__(self, *exc):
+        _lib().gs_oracle_set_boundary(self.was)
+
+
+def step(u, v, params: Params | None = None, ftz: bool = True, nthreads: int = 0, boundary: int = CLIPPED):
+    """One step of the whole grid; returns new (U, V)."""
     params = params or default_params()
     u = np.ascontiguousarray(u, np.float32)
     v = np.ascontiguousarray(v, np.float32)
     ou, ov = np.empty_like(u), np.empty_like(v)
-    step_rows(u, v, ou, ov, params, 0, u.shape[0], ftz, nthreads)
+    with _Boundary(boundary):
+        step_rows(u, v, ou, ov, params, 0, u.shape[0], ftz, nthreads)
     return ou, ov
 
 
-def run(u, v, steps: int, params: Params | None = None, ftz: bool = True, nthreads: int = 0):
+def run(u, v, steps: int, params: Params | None = None, ftz: bool = True, nthreads: int = 0,
+        boundary: int = CLIPPED):
     """``perform_steps``: returns (U, V) after ``steps`` steps (inputs are not modified)."""
     params = params or default_params()
     u0 = np.array(u, np.float32, order="C", copy=True)
     v0 = np.array(v, np.float32, order="C", copy=True)
     u1, v1 = np.empty_like(u0), np.empty_like(v0)
     rows, cols = u0.shape
-    slot = _lib().gs_oracle_run(_fp(u0), _fp(u1), _fp(v0), _fp(v1), rows, cols,
-                                ctypes.byref(params), steps, int(ftz), nthreads)
+    with _Boundary(boundary):
+        slot = _lib().gs_oracle_run(_fp(u0), _fp(u1), _fp(v0), _fp(v1), rows, cols,
+                                    ctypes.byref(params), steps, int(ftz), nthreads)
     return (u1, v1) if slot else (u0, v0)

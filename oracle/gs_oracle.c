@@ -130,6 +130,49 @@ static inline void naive_cell(const float *in_u, const float *in_v, float *out_u
     out_v[r * cols + c] = v + dv * p->dt;                                     /* :79 */
 }
 
+/* The OTHER boundary rule of the reference (boundary-rule summary): full
+ * 3x3 window, weights aligned on the centre, cells outside the grid read as 0 -- the Vulkan
+ * backends' sampler (ClampToBorder + FloatOpaqueBlack, compute/gpu/naive/src/pipeline.rs:105-113;
+ * the fold compute/gpu/naive/src/main.comp:37-44) and the zero halo of the SIMD storage
+ * (data/src/concentration/simd/mod.rs:281-326).  Those backends fix neither the tap order nor
+ * the contraction of their arithmetic, so this restatement keeps naive's: row-major fold,
+ * acc = acc + w * (elem - centre), one rounding per operation, then the same update as above.
+ * It is the checker of the library's GS_BOUNDARY_ZERO_HALO option; the parity target of the
+ * round stays the clipped-window rule above. */
+static inline void zero_halo_cell(const float *in_u, const float *in_v, float *out_u, float *out_v,
+                                  size_t rows, size_t cols, size_t r, size_t c,
+                                  const gs_oracle_params *p)
+{
+    const float u = in_u[r * cols + c];
+    const float v = in_v[r * cols + c];
+    float acc_u = 0.0f, acc_v = 0.0f;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const long rr = (long)r + i - 1, cc = (long)c + j - 1;
+            const int inside = rr >= 0 && rr < (long)rows && cc >= 0 && cc < (long)cols;
+            const float su = inside ? in_u[(size_t)rr * cols + (size_t)cc] : 0.0f;
+            const float sv = inside ? in_v[(size_t)rr * cols + (size_t)cc] : 0.0f;
+            acc_u = acc_u + p->w[i][j] * (su - u);
+            acc_v = acc_v + p->w[i][j] * (sv - v);
+        }
+    const float uv_square = u * v * v;
+    const float du = p->du * acc_u - uv_square + p->feed * (1.0f - u);
+    const float dv = p->dv * acc_v + uv_square - (p->feed + p->kill) * v;
+    out_u[r * cols + c] = u + du * p->dt;
+    out_v[r * cols + c] = v + dv * p->dt;
+}
+
+static int g_boundary = 0; /* 0 = clipped window (naive), 1 = zero halo; see gs_oracle_set_boundary */
+
+/* Selects the boundary rule of the following steps (test infrastructure: not thread-safe);
+ * returns the previous one. */
+int gs_oracle_set_boundary(int boundary)
+{
+    const int was = g_boundary;
+    g_boundary = boundary ? 1 : 0;
+    return was;
+}
+
 /* One step over output rows [r0, r1) of a dense [rows, cols] array.  Cells of
  * one step are independent, so any row partition (threads, slabs) is bit-exact. */
 void gs_oracle_step_rows(const float *in_u, const float *in_v, float *out_u, float *out_v,
@@ -145,7 +188,8 @@ void gs_oracle_step_rows(const float *in_u, const float *in_v, float *out_u, flo
 #pragma omp for schedule(static)
         for (size_t r = r0; r < r1; ++r)
             for (size_t c = 0; c < cols; ++c)
-                naive_cell(in_u, in_v, out_u, out_v, rows, cols, r, c, p);
+                if (g_boundary) zero_halo_cell(in_u, in_v, out_u, out_v, rows, cols, r, c, p);
+                else naive_cell(in_u, in_v, out_u, out_v, rows, cols, r, c, p);
         gs_oracle_set_ftz(was);
     }
 #else
@@ -153,7 +197,8 @@ void gs_oracle_step_rows(const float *in_u, const float *in_v, float *out_u, flo
     const int was = gs_oracle_set_ftz(ftz);
     for (size_t r = r0; r < r1; ++r)
         for (size_t c = 0; c < cols; ++c)
-            naive_cell(in_u, in_v, out_u, out_v, rows, cols, r, c, p);
+            if (g_boundary) zero_halo_cell(in_u, in_v, out_u, out_v, rows, cols, r, c, p);
+            else naive_cell(in_u, in_v, out_u, out_v, rows, cols, r, c, p);
     gs_oracle_set_ftz(was);
 #endif
 }

@@ -84,3 +84,33 @@ def run(u, v, steps: int, params: dict | None = None):
     for _ in range(steps):
         u, v = step(u, v, params)
     return u, v
+
+
+
+def step_zero_halo(u: np.ndarray, v: np.ndarray, params: dict | None = None):
+    """The reference's other boundary rule -- full window, centred weights, zeros outside the grid
+    (Vulkan sampler: compute/gpu/naive/src/pipeline.rs:105-113, fold main.comp:37-44; SIMD halo:
+    data/src/concentration/simd/mod.rs:281-326) -- with naive's operation order.  Written with a
+    zero-padded copy instead of the C checker's per-tap bounds test."""
+    p = params or default_params()
+    w = np.asarray(p["w"], np.float32)
+    u = np.asarray(u, np.float32)
+    v = np.asarray(v, np.float32)
+    rows, cols = u.shape
+    pu = np.zeros((rows + 2, cols + 2), np.float32)
+    pv = np.zeros((rows + 2, cols + 2), np.float32)
+    pu[1:-1, 1:-1] = u
+    pv[1:-1, 1:-1] = v
+    acc_u = np.zeros_like(u)
+    acc_v = np.zeros_like(v)
+    for i in range(3):
+        for j in range(3):
+            acc_u = acc_u + w[i, j] * (pu[i:i + rows, j:j + cols] - u)
+            acc_v = acc_v + w[i, j] * (pv[i:i + rows, j:j + cols] - v)
+    uv_square = u * v * v
+    du = p["du"] * acc_u - uv_square + p["feed"] * (np.float32(1.0) - u)
+    dv = p["dv"] * acc_v + uv_square - (np.float32(p["feed"]) + np.float32(p["kill"])) * v
+    out_u = u + du * p["dt"]
+    out_v = v + dv * p["dt"]
+    assert out_u.dtype == np.float32 and out_v.dtype == np.float32
+    return out_u, out_v

@@ -30,7 +30,8 @@ pub struct gs_options {
     pub split: i32,
     pub general_kernels: i32,
     pub cols_per_lane: i32,
-    pub reserved: [i32; 7],
+    pub boundary: i32,
+    pub reserved: [i32; 6],
 }
 
 #[repr(C)]

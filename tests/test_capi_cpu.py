@@ -93,3 +93,19 @@ def test_product_path_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "gs_oracle" not in text and "libgs_cpu_parallel" not in text, f
+
+
+def test_named_stencils_match_the_reference_constants():
+    """data/src/parameters.rs:91-122: the f32 constants of each cargo-feature stencil."""
+    import numpy as np
+
+    from grayscott_amd.simulation import STENCILS, Parameters
+
+    f = np.float32
+    pk = Parameters.with_stencil("patrakarttunen").to_c()
+    assert f(pk.w[0][0]) == f(1.0) / f(6.0) and f(pk.w[0][1]) == f(4.0) / f(6.0) and pk.w[1][1] == 0.0
+    assert [[Parameters.with_stencil("pretty").to_c().w[i][j] for j in range(3)] for i in range(3)] == [[1.0] * 3] * 3
+    five = Parameters.with_stencil("5points").to_c()
+    assert [five.w[0][0], five.w[0][1], five.w[1][0], five.w[1][1]] == [0.0, 1.0, 1.0, 0.0]
+    assert Parameters.with_stencil("oono-puri").weights == Parameters().weights
+    assert set(STENCILS) == {"oono-puri", "5points", "patrakarttunen", "pretty"}

@@ -224,6 +224,68 @@ def test_row_bands_on_a_large_grid(split):
 
 
 # ---- non-default parameters (CLI overrides -k -f -t, ui/src/lib.rs:51-63) and weights ------
+# ---- the other boundary rule and the named stencils -------------------------
+@pytest.mark.parametrize("kw", [dict(kernel=capi.GS_KERNEL_SIMPLE), dict(kernel=capi.GS_KERNEL_STREAM),
+                                dict(kernel=capi.GS_KERNEL_LDS),
+                                dict(kernel=capi.GS_KERNEL_TB, fuse_steps=1, cols_per_lane=4),
+                                dict(kernel=capi.GS_KERNEL_TB, fuse_steps=2, cols_per_lane=1),
+                                dict(kernel=capi.GS_KERNEL_TB, fuse_steps=3, cols_per_lane=2),
+                                dict(kernel=capi.GS_KERNEL_TB, fuse_steps=4, cols_per_lane=4),
+                                dict(kernel=capi.GS_KERNEL_TB, fuse_steps=4, cols_per_lane=2),
+                                dict(kernel=capi.GS_KERNEL_TB, fuse_steps=4, cols_per_lane=1),
+                                dict(devices=[0, 0, 0]), dict(split=2, rows_per_block=6), dict(math=capi.GS_MATH_FUSED)])
+def test_zero_halo_boundary_rule(kw):
+    """GS_BOUNDARY_ZERO_HALO (the rule of the reference's Vulkan and SIMD backends) against its
+    checker, every kernel and schedule, bit for bit (fused flavour: tolerance)."""
+    for shape in STRESS_SHAPES + [(9, 257), (40, 1030), (30, 120), (30, 121), (12, 56), (12, 57)]:
+        if len(kw.get("devices", [0])) > shape[0]:
+            continue
+        u0, v0 = stress_fields(shape, 12)
+        for steps in (1, 9):
+            ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True, boundary=oracle.ZERO_HALO)
+            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(rows_per_block=kw.get("rows_per_block", 5),
+                                                                  boundary=capi.GS_BOUNDARY_ZERO_HALO,
+                                                                  **{k: v for k, v in kw.items() if k != "rows_per_block"}))
+            if kw.get("math"):
+                assert np.max(np.abs(got_u - ref_u)) <= REL_TOL * np.max(np.abs(ref_u)), (shape, steps)
+                assert np.max(np.abs(got_v - ref_v)) <= REL_TOL * np.max(np.abs(ref_v)), (shape, steps)
+            else:
+                assert_bits_equal(got_u, ref_u, f"zero halo U {info[0]} {shape} steps {steps}")
+                assert_bits_equal(got_v, ref_v, f"zero halo V {info[0]} {shape} steps {steps}")
+
+
+def test_zero_halo_species_new_1080x1920():
+    """Config-1 shape under the zero-halo rule, 200 steps, and the known answer on the border:
+    U = 1, V = 0 next to an edge loses Du per step at first (0.9 after one step; corner 0.825)."""
+    rows, cols = 1080, 1920
+    sim = Simulation.new(Parameters(), args(boundary=capi.GS_BOUNDARY_ZERO_HALO))
+    species = sim.make_species([rows, cols])
+    sim.perform_step(species)
+    u1 = species.in_out()[0].make_scalar_view(sim.context)
+    assert u1[0, 100] == np.float32(1.0) + np.float32(0.1) * np.float32(-1.0) and abs(float(u1[0, 0]) - 0.825) < 1e-6
+    assert u1[5, 5] == 1.0
+    sim.perform_steps(species, 199)
+    u0, v0 = oracle.init_species(rows, cols)
+    ref_u, ref_v = oracle.run(u0, v0, 200, ftz=True, boundary=oracle.ZERO_HALO)
+    in_u, in_v, _, _ = species.in_out()
+    assert_bits_equal(in_u.make_scalar_view(sim.context), ref_u, "zero halo U 1080x1920")
+    assert_bits_equal(in_v.make_scalar_view(sim.context), ref_v, "zero halo V 1080x1920")
+
+
+@pytest.mark.parametrize("name", ["oono-puri", "5points", "patrakarttunen", "pretty"])
+def test_named_stencils(name):
+    """The reference's cargo-feature stencils (data/Cargo.toml:28-58) as run-time weights."""
+    p = Parameters.with_stencil(name, time_step=0.25 if name == "pretty" else 1.0)   # "pretty" needs a small dt
+    for shape, seed in (((37, 300), 4), ((64, 128), 5)):
+        u0, v0 = stress_fields(shape, seed)
+        ref_u, ref_v = oracle.run(u0, v0, 12, oracle_params(p), ftz=True)
+        for kw in (dict(), dict(kernel=capi.GS_KERNEL_STREAM), dict(cols_per_lane=4, fuse_steps=4)):
+            got_u, got_v, info = gpu_run(u0, v0, 12, params=p, args=args(**kw))
+            assert np.isfinite(ref_u).all()
+            assert_bits_equal(got_u, ref_u, f"{name} U {info[0]}")
+            assert_bits_equal(got_v, ref_v, f"{name} V {info[0]}")
+
+
 # ---- hipGraph replay of pass batches (gs_options.use_graph) -----------------------------------
 def test_graph_replay_bit_exact_and_invalidated_by_every_input():
     """Batches of 16 passes replayed through a hipGraph: same bits; the captured launches carry

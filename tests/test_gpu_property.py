@@ -30,6 +30,7 @@ def cases(draw):
     cpl = draw(st.sampled_from([0, 1, 2, 4]))
     general = draw(st.integers(0, 1))
     graph = draw(st.integers(0, 1))
+    boundary = draw(st.integers(0, 1))
     w = [[draw(st.sampled_from(POW2)) for _ in range(3)] for _ in range(3)]
     if draw(st.booleans()):                       # the default side weights: specialised kernels
         w[0][1] = w[1][0] = w[1][2] = w[2][1] = 0.5
@@ -40,13 +41,13 @@ def cases(draw):
                    kill_rate=draw(st.sampled_from([0.054, 0.06])),
                    time_step=draw(st.sampled_from([1.0, 0.5, 0.75])))
     tiny = draw(st.booleans())  # sprinkle values near the flush-to-zero threshold
-    return rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny, cpl, general, graph
+    return rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny, cpl, general, graph, boundary
 
 
 @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
 @given(cases())
 def test_any_schedule_matches_the_oracle(built, case):
-    rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny, cpl, general, graph = case
+    rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny, cpl, general, graph, boundary = case
     steps = steps * 9 if graph else steps   # long enough for at least one batch of 16 passes
     slabs = min(slabs, rows)
     rng = np.random.default_rng(seed)
@@ -58,11 +59,11 @@ def test_any_schedule_matches_the_oracle(built, case):
         u0[rng.random((rows, cols)) < 0.05] = np.float32(3e-38)
     if kernel in (capi.GS_KERNEL_STREAM, capi.GS_KERNEL_SIMPLE, capi.GS_KERNEL_LDS):
         fuse = 0
-    ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True)
+    ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True, boundary=boundary)
     got_u, got_v, info = gpu_run(u0, v0, steps, params=p,
                                  args=args(kernel=kernel, fuse_steps=fuse, rows_per_block=rpb, split=split,
-                                           devices=[0] * slabs, cols_per_lane=cpl, general_kernels=general, use_graph=graph))
+                                           devices=[0] * slabs, cols_per_lane=cpl, general_kernels=general, use_graph=graph, boundary=boundary))
     what = (f"{rows}x{cols} steps={steps} kernel={info[0]} fuse={fuse} rpb={rpb} split={split} slabs={slabs} "
-            f"cpl={cpl} general={general} graph={graph} {p}")
+            f"cpl={cpl} general={general} graph={graph} boundary={boundary} {p}")
     assert_bits_equal(got_u, ref_u, "U " + what)
     assert_bits_equal(got_v, ref_v, "V " + what)

@@ -209,3 +209,63 @@ def test_golden_stress_and_ftz():
         assert (bits(v) == bits(g[f"v_{steps}"])).all() and (bits(u) == bits(g[f"u_{steps}"])).all()
         u, v = oracle.run(u0, v0, steps, ftz=False)
         assert (bits(v) == bits(g[f"v_{steps}_noftz"])).all()
+
+
+# ---- the reference's other boundary rule (zero halo), checker of GS_BOUNDARY_ZERO_HALO --------
+def test_zero_halo_known_answers():
+    """Uniform U=1, V=0 (KAT 2): a fixed point of the clipped-window rule, but
+    under the zero-halo rule a border cell loses Du * (sum of the weights that fall outside) per
+    step: 1.0 for an edge cell, .25+.5+.25+.5+.25 = 1.75 for a corner."""
+    u = np.ones((5, 6), np.float32)
+    v = np.zeros((5, 6), np.float32)
+    ou, ov = oracle.step(u, v, boundary=oracle.ZERO_HALO)
+    f = np.float32
+    edge = f(1.0) + (f(0.1) * (f(0.0) + f(0.25) * f(-1) + f(0.5) * f(-1) + f(0.25) * f(-1)))
+    assert ou[2, 3] == f(1.0) and ou[0, 2] == edge and ou[2, 0] == edge and ou[4, 3] == edge and ou[1, 5] == edge
+    assert abs(float(ou[0, 0]) - 0.825) < 1e-6 and ou[0, 0] == ou[4, 5] == ou[0, 5] == ou[4, 0]
+    assert (ov == 0).all()
+    cu, cv = oracle.step(u, v)                          # the clipped rule keeps it fixed
+    assert (cu == 1).all() and (cv == 0).all()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 7), (7, 1), (2, 2), (3, 5), (17, 33), (64, 128)])
+def test_zero_halo_c_checker_equals_numpy_restatement(shape):
+    rng = np.random.default_rng(11)
+    u = rng.random(shape, dtype=np.float32)
+    v = (rng.random(shape, dtype=np.float32) * np.float32(0.5)).astype(np.float32)
+    for _ in range(5):
+        cu, cv = oracle.step(u, v, ftz=False, boundary=oracle.ZERO_HALO)
+        nu, nv = numpy_ref.step_zero_halo(u, v)
+        assert cu.tobytes() == nu.tobytes() and cv.tobytes() == nv.tobytes()
+        u, v = cu, cv
+
+
+def test_boundary_rules_agree_away_from_the_border():
+    """The two rules differ on the border only; the difference travels one cell per step."""
+    u0, v0 = oracle.init_species(64, 96)
+    steps = 7
+    a = oracle.run(u0, v0, steps)
+    b = oracle.run(u0, v0, steps, boundary=oracle.ZERO_HALO)
+    k = steps
+    assert a[0][k:-k, k:-k].tobytes() == b[0][k:-k, k:-k].tobytes()
+    assert a[1][k:-k, k:-k].tobytes() == b[1][k:-k, k:-k].tobytes()
+    assert a[0].tobytes() != b[0].tobytes()
+
+
+def test_zero_halo_checker_against_the_parallel_backend_port():
+    """Same boundary rule as the reference's block/parallel family, different association (FMA,
+    three accumulator chains): agreement to rounding on the WHOLE grid, border included."""
+    from oracle import cpu_parallel
+
+    w = cpu_parallel.simd_width()
+    rows, cols = 8 * w, 72
+    sim = cpu_parallel.ParallelSimulation(rows, cols, num_threads=2)
+    sim.perform_steps(60)
+    u0, v0 = oracle.init_species(rows, cols)
+    ref_u, ref_v = oracle.run(u0, v0, 60, boundary=oracle.ZERO_HALO)
+    assert np.max(np.abs(sim.read(0) - ref_u)) <= 1e-5 * np.max(np.abs(ref_u))
+    assert np.max(np.abs(sim.read(1) - ref_v)) <= 1e-5 * max(np.max(np.abs(ref_v)), 1e-3)
+    # ... which the clipped rule does not give (the border differs at the 1e-1 level)
+    clip_u, _ = oracle.run(u0, v0, 60)
+    assert np.max(np.abs(sim.read(0) - clip_u)) > 1e-2
+    sim.close()
