@@ -258,7 +258,8 @@ def main() -> int:
             "launches": passes,
             "steps_per_launch": args.steps / passes,
             "algorithmic_bytes_per_launch": per_launch_bytes,
-            "traffic": measured_traffic(kernel_name),
+            # PMC figure of the committed profile of this kernel on this per-GPU grid (null otherwise)
+            "traffic": measured_traffic(kernel_name) if cells // args.gpus == 16384 * 16384 else None,
         },
     }
     if extra is not None:
