@@ -95,7 +95,7 @@ def measured_traffic(kernel_name: str):
     try:
         with open(path) as f:
             data = json.load(f)
-        return data.get(kernel_name.split("@")[0], data.get("default"))
+        return data.get(kernel_name.split("@")[0])   # None for a configuration that was not profiled
     except (OSError, ValueError):
         return None
 
