@@ -90,7 +90,7 @@ def cpu_baseline(target_seconds: float = 15.0):
 
 def measured_traffic(kernel_name: str):
     """HBM bytes per launch from rocprofv3 PMC passes (profiles/traffic.json, written by
-    tools/profile_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs); None if absent."""
+    tools/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE runs); None if absent."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
