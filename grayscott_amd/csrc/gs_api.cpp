@@ -5,20 +5,23 @@
 // ghost-row exchange schedule, and the small amount of plumbing the reference's
 // Concentration contract needs (fill, fill_slice, finalize, upload, download).
 //
-// Step schedule for a chain of S > 1 slabs (per slab i; p = parity of the step counter):
+// A "pass" advances the state by K <= 4 time steps with one sweep over the planes (K = 1 for
+// gs_step).  Schedule of one pass on a chain of S > 1 slabs (per slab i; p = parity of the pass
+// counter; the same schedule runs on the opt-in row bands of a single slab, without the copies):
 //
 //   halo stream (high priority)                     compute stream
 //   ---------------------------                     --------------
 //   wait done[p^1][i], halo[p^1][local nbrs]        wait halo[p^1][i]
-//   kernel: rows {0, rows-1}        -> out          kernel: rows [1, rows-1)  -> out
-//   out row 0      -> upper nbr's out ghost         record done[p][i]
-//   out row rows-1 -> lower nbr's out ghost
+//   kernel: rows [0,K) and [rows-K,rows) -> out     kernel: rows [K, rows-K)  -> out
+//   out rows [0,K)       -> upper nbr's out ghost   record done[p][i]
+//   out rows [rows-K,..) -> lower nbr's out ghost
 //     (same process: device-to-device copy; other process: ncclSend / ncclRecv pair)
 //   record halo[p][i]
 //
-// so the exchange of step n overlaps the interior update of step n, and step n+1's
-// interior only waits for its own slab's boundary rows.  Every dependency is an event on
-// the consumer's stream; the host never blocks inside gs_step / gs_run.
+// so the exchange of pass n overlaps the interior update of pass n, and pass n+1's interior only
+// waits for its own slab's boundary rows.  Every dependency is an event on the consumer's stream;
+// the host never blocks inside gs_step / gs_run (except while gs_run's on-line tuner reads the
+// timings of a phase of candidate configurations, a few times per context and shape).
 #include "../../include/gs_hip.h"
 #include "gs_kernels.h"
 
