@@ -442,16 +442,28 @@ struct RowT { // [0] = column c-1, [1..CPL] = own columns, [CPL+1] = column c+CP
     float u[CPL + 2], v[CPL + 2];
 };
 
+// Same shifts for the temporally blocked kernel, whose outermost lanes are sacrificial: they may
+// receive anything, so the DPP move runs with bound_ctrl (0 for the lane without a source) and
+// needs no `old` operand -- one v_mov per shift less than from_prev_lane / from_next_lane.
+__device__ __forceinline__ float shift_from_prev_lane(float own)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float shift_from_next_lane(float own)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own), 0x130, 0xf, 0xf, true));
+}
+
 template <int CPL>
 __device__ __forceinline__ RowT<CPL> widen_tb(const float (&u)[CPL], const float (&v)[CPL])
 {
     RowT<CPL> w;
 #pragma unroll
     for (int i = 0; i < CPL; ++i) { w.u[1 + i] = u[i]; w.v[1 + i] = v[i]; }
-    w.u[0] = from_prev_lane(u[CPL - 1], u[CPL - 1]); // lanes 0 / 63 keep a don't-care value
-    w.u[CPL + 1] = from_next_lane(u[0], u[0]);
-    w.v[0] = from_prev_lane(v[CPL - 1], v[CPL - 1]);
-    w.v[CPL + 1] = from_next_lane(v[0], v[0]);
+    w.u[0] = shift_from_prev_lane(u[CPL - 1]);
+    w.u[CPL + 1] = shift_from_next_lane(u[0]);
+    w.v[0] = shift_from_prev_lane(v[CPL - 1]);
+    w.v[CPL + 1] = shift_from_next_lane(v[0]);
     return w;
 }
 
