@@ -224,6 +224,20 @@ def test_row_bands_on_a_large_grid(split):
 
 
 # ---- non-default parameters (CLI overrides -k -f -t, ui/src/lib.rs:51-63) and weights ------
+# ---- extreme aspect ratios ---------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 100003), (3, 70001), (70001, 3), (100003, 1), (2, 32768), (16385, 17)])
+def test_extreme_aspect_ratios(shape):
+    """One very long axis: many strips and one row unit, or many units and one (mostly masked)
+    strip; every kernel family and both lane-layout extremes against the oracle."""
+    u0, v0 = stress_fields(shape, 13)
+    ref_u, ref_v = oracle.run(u0, v0, 6, ftz=True)
+    for kw in (dict(), dict(kernel=capi.GS_KERNEL_STREAM), dict(kernel=capi.GS_KERNEL_LDS), dict(cols_per_lane=4),
+               dict(cols_per_lane=1, fuse_steps=3), dict(devices=[0, 0]) if shape[0] >= 2 else dict(split=2)):
+        got_u, got_v, info = gpu_run(u0, v0, 6, args=args(**kw))
+        assert_bits_equal(got_u, ref_u, f"U {shape} {info[0]} {kw}")
+        assert_bits_equal(got_v, ref_v, f"V {shape} {info[0]} {kw}")
+
+
 # ---- SURVEY 8(f) row 4: the other boundary rule and the named stencils -------------------------
 @pytest.mark.parametrize("kw", [dict(kernel=capi.GS_KERNEL_SIMPLE), dict(kernel=capi.GS_KERNEL_STREAM),
                                 dict(kernel=capi.GS_KERNEL_LDS),
