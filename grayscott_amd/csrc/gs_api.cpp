@@ -1092,7 +1092,7 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
         // passes, event, `reps` passes, event -- and the host waits once per phase: no idle gaps
         // (clock ramps) between the timing windows.  A candidate's time is the shorter of its two
         // windows.
-        struct Trial { int rpu, V, k, cpl; };
+        struct Trial { int rpu, V, k, cpl, reps; };
         // Timestamp "everything enqueued so far has finished" without holding anything back: after
         // a banded pass the event is recorded on the copy stream, which is made to wait for the
         // bands (a record on the compute stream would turn every window boundary into a barrier
@@ -1121,7 +1121,7 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
             int nb = 0;
             int32_t st = GS_OK;
             for (; ctx->tune_next < phase_end[phase] && nb < kMaxBatch && st == GS_OK; ++ctx->tune_next) {
-                Trial t{0, V0, fuse, user_cpl ? user_cpl : 2};
+                Trial t{0, V0, fuse, user_cpl ? user_cpl : 2, reps};
                 const int i = ctx->tune_next - (phase ? phase_end[phase - 1] : 0);
                 if (phase == 0) {
                     t.rpu = cand[i];
@@ -1144,7 +1144,11 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
                         (large && (t.cpl == 1 || t.rpu < 32)))
                         continue;
                 }
-                if ((steps - n) / (uint64_t)t.k < (uint64_t)(2 * reps + 1)) { // continue in the next gs_run
+                // short calls (a driver loop with few steps per image) get shorter windows rather
+                // than no tuning at all; with less than 3 passes left it continues in the next gs_run
+                const uint64_t passes_left = (steps - n) / (uint64_t)t.k;
+                while (t.reps > 1 && passes_left < (uint64_t)(2 * t.reps + 1)) --t.reps;
+                if (passes_left < (uint64_t)(2 * t.reps + 1)) {
                     out_of_steps = true;
                     break;
                 }
@@ -1157,7 +1161,7 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
                 }
                 for (int w = 0; w < 3 && st == GS_OK; ++w) {
                     st = mark(ctx->tune_events[3 * nb + w]);
-                    for (int r = 0; r < reps && w < 2 && st == GS_OK; ++r) st = advance(t.V, t.k);
+                    for (int r = 0; r < t.reps && w < 2 && st == GS_OK; ++r) st = advance(t.V, t.k);
                 }
                 ctx->o.rows_per_block = 0;
                 ctx->o.cols_per_lane = user_cpl;
@@ -1171,7 +1175,7 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
                 if (hipEventElapsedTime(&w0, ctx->tune_events[3 * b], ctx->tune_events[3 * b + 1]) != hipSuccess ||
                     hipEventElapsedTime(&w1, ctx->tune_events[3 * b + 1], ctx->tune_events[3 * b + 2]) != hipSuccess)
                     return fail(GS_ERR_HIP, "timing a tuning pass failed");
-                const float ms = (w0 < w1 ? w0 : w1) / (float)(reps * batch[b].k); // per time step
+                const float ms = (w0 < w1 ? w0 : w1) / (float)(batch[b].reps * batch[b].k); // per time step
                 static const bool trace = std::getenv("GS_HIP_TRACE_TUNER") != nullptr;
                 if (trace)
                     std::fprintf(stderr, "gs_hip tuner %llux%llu: unit %3d rows, %d band(s), %d steps/pass, %d col/lane: "

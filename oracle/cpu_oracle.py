@@ -77,6 +77,29 @@ def _lib():
     return _LIB
 
 
+def usable_cpus() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU
+    box shows 256 CPUs to a container that is allowed 16; OpenMP would start 256 threads)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def _threads(nthreads: int, cells: int) -> int:
+    """0 = automatic: one thread per 16k cells, at most the usable CPUs."""
+    if nthreads > 0:
+        return nthreads
+    return max(1, min(usable_cpus(), cells // 16384))
+
+
 def _fp(a: np.ndarray):
     assert a.dtype == np.float32 and a.flags.c_contiguous
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
@@ -113,7 +136,7 @@ def step_rows(u, v, out_u, out_v, params: Params, r0: int, r1: int, ftz: bool = 
     rows, cols = u.shape
     assert v.shape == u.shape == out_u.shape == out_v.shape
     _lib().gs_oracle_step_rows(_fp(u), _fp(v), _fp(out_u), _fp(out_v), rows, cols,
-                               ctypes.byref(params), r0, r1, int(ftz), nthreads)
+                               ctypes.byref(params), r0, r1, int(ftz), _threads(nthreads, rows * cols))
 
 
 CLIPPED, ZERO_HALO = 0, 1   # boundary rules: naive's clipped window (parity target) / zero halo
@@ -153,5 +176,5 @@ def run(u, v, steps: int, params: Params | None = None, ftz: bool = True, nthrea
     rows, cols = u0.shape
     with _Boundary(boundary):
         slot = _lib().gs_oracle_run(_fp(u0), _fp(u1), _fp(v0), _fp(v1), rows, cols,
-                                    ctypes.byref(params), steps, int(ftz), nthreads)
+                                    ctypes.byref(params), steps, int(ftz), _threads(nthreads, rows * cols))
     return (u1, v1) if slot else (u0, v0)
