@@ -630,6 +630,246 @@ int32_t check_step_fields(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field 
     return GS_OK;
 }
 
+// ---- gs_run: state of one call, on-line tuning, graph replay ---------------------------------
+struct Run {
+    gs_ctx *ctx;
+    gs_field *u[2], *v[2];
+    int in = 0;          // slot that holds the newest state
+    uint64_t n = 0;      // steps done
+    uint64_t steps = 0;  // steps wanted
+
+    // one pass of k fused steps, on V row bands when V > 1
+    int32_t advance(int V, int k)
+    {
+        const int32_t st = V > 1 ? step_bands(ctx, u[in], v[in], u[1 - in], v[1 - in], k, V)
+                                 : step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], k);
+        in = 1 - in;
+        n += (uint64_t)k;
+        return st;
+    }
+};
+
+bool tuned_shape(const gs_ctx *ctx, const gs_field *f, int fuse)
+{
+    return ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse && ctx->tuned_rows == f->rows && ctx->tuned_cols == f->cols;
+}
+
+// On-line choice of unit height, fused steps per pass and columns per lane (single slab, fused
+// passes, unit height not pinned).  The best values depend on how a launch tiles the chip (tail
+// effects vs 2K redundant rows per unit vs occupancy), so the first passes of a run on a new shape
+// are timed with a few candidates -- they are real passes of the simulation, nothing is recomputed
+// -- and the fastest combination is kept for this context and shape.  Continues in the next gs_run
+// when this one is too short.
+//   phase A: unit heights; (phase B, band counts: retired, see bands_for;) phase C: fewer fused
+//   steps per pass (when fuse_steps is not pinned) -- on small, cache-resident grids the 2K
+//   redundant rows per unit can cost more than the extra passes; phase D (columns per lane not
+//   pinned): 1 and 4 columns per lane -- more, narrower waves for small grids; fewer, wider ones
+//   with 16-byte accesses -- with a few unit heights each (large grids skip the candidates that
+//   would only multiply tiny units).  A-C run with 2 columns per lane.
+int32_t tune_online(Run &r, int fuse)
+{
+    gs_ctx *ctx = r.ctx;
+    const gs_field *f = r.u[0];
+    static const int cand[] = {8, 12, 16, 24, 32, 48, 64, 96, 128};
+    static const int altk[] = {3, 2};
+    static const int candn[] = {8, 16, 32, 64, 128};
+    static const int cpls[] = {1, 4};
+    const int ncand = (int)(sizeof cand / sizeof cand[0]);
+    const int nalt = 0; // phase B is empty
+    const int nk = ctx->o.fuse_steps == 0 ? (int)(sizeof altk / sizeof altk[0]) : 0;
+    const uint64_t cells = f->rows * f->cols;
+    const int ncandn = (int)(sizeof candn / sizeof candn[0]);
+    const int nn = ctx->o.cols_per_lane == 0 ? ncandn * (int)(sizeof cpls / sizeof cpls[0]) : 0;
+    const bool large = cells > (1ull << 26);
+    const int user_cpl = ctx->o.cols_per_lane;
+    // timed passes per candidate: short passes need more of them for a stable comparison
+    const int reps = cells >= (1ull << 27) ? 2 : (cells >= (1ull << 24) ? 6 : 8);
+    if (ctx->tune_rows != f->rows || ctx->tune_cols != f->cols || ctx->tune_fuse != fuse) {
+        ctx->tune_rows = f->rows;
+        ctx->tune_cols = f->cols;
+        ctx->tune_fuse = fuse;
+        ctx->tune_next = 0;
+        ctx->tune_best_rpu = 0;
+        ctx->tune_best_split = 0;
+        ctx->tune_best_k = 0;
+        ctx->tune_best_cpl = 0;
+        ctx->tune_best_ms = 0.f;
+    }
+    const int V0 = bands_for(ctx, f, fuse);
+    SlabRt &sl = ctx->slabs[0];
+    GS_HIP(hipSetDevice(sl.device));
+    // Candidates of one phase do not depend on each other, so a whole phase is enqueued back to
+    // back -- per candidate: [an untimed pass when the kernel changes,] event, `reps` passes,
+    // event, `reps` passes, event -- and the host waits once per phase: no idle gaps (clock ramps)
+    // between the timing windows.  A candidate's time is the shorter of its two windows.
+    struct Trial { int rpu, V, k, cpl, reps; };
+    // Timestamp "everything enqueued so far has finished" without holding anything back: after a
+    // banded pass the event is recorded on the copy stream, which is made to wait for the bands (a
+    // record on the compute stream would turn every window boundary into a barrier between passes,
+    // and hide exactly the overlap that bands are for).
+    auto mark = [&](hipEvent_t ev) -> int32_t {
+        hipStream_t ts = sl.compute;
+        if (ctx->bands_active) {
+            ts = sl.copy;
+            GS_TRY(join_bands(ctx, ts));
+        }
+        GS_HIP(hipEventRecord(ev, ts));
+        return GS_OK;
+    };
+    constexpr int kMaxBatch = 10;
+    if (ctx->tune_events.empty()) {
+        ctx->tune_events.resize(3 * kMaxBatch, nullptr);
+        for (auto &e : ctx->tune_events) GS_HIP(hipEventCreate(&e));
+    }
+    const int phase_end[4] = {ncand, ncand + nalt, ncand + nalt + nk, ncand + nalt + nk + nn};
+    int warm_cpl = 0, warm_k = 0; // kernel of the newest pass enqueued by this call
+    bool out_of_steps = false;
+    while (ctx->tune_next < phase_end[3] && !out_of_steps) {
+        int phase = 0;
+        while (ctx->tune_next >= phase_end[phase]) ++phase;
+        Trial batch[kMaxBatch];
+        int nb = 0;
+        int32_t st = GS_OK;
+        for (; ctx->tune_next < phase_end[phase] && nb < kMaxBatch && st == GS_OK; ++ctx->tune_next) {
+            Trial t{0, V0, fuse, user_cpl ? user_cpl : 2, reps};
+            const int i = ctx->tune_next - (phase ? phase_end[phase - 1] : 0);
+            if (phase == 0) {
+                t.rpu = cand[i];
+                if (t.rpu < 2 * fuse || (uint64_t)t.rpu > f->rows) continue;
+            } else if (phase == 2) {
+                t.rpu = ctx->tune_best_rpu;
+                t.V = ctx->tune_best_split;
+                t.k = altk[i];
+                if (t.rpu == 0 || t.k >= fuse) continue;
+            } else { // phase 3 (phase 1 has no candidates)
+                t.cpl = cpls[i / ncandn];
+                t.rpu = candn[i % ncandn];
+                t.V = ctx->tune_best_split;
+                t.k = ctx->tune_best_k;
+                if (ctx->tune_best_rpu == 0 || t.rpu < 2 * t.k || (uint64_t)t.rpu > f->rows ||
+                    (large && (t.cpl == 1 || t.rpu < 32)))
+                    continue;
+            }
+            // short calls (a driver loop with few steps per image) get shorter windows rather
+            // than no tuning at all; with less than 3 passes left it continues in the next gs_run
+            const uint64_t passes_left = (r.steps - r.n) / (uint64_t)t.k;
+            while (t.reps > 1 && passes_left < (uint64_t)(2 * t.reps + 1)) --t.reps;
+            if (passes_left < (uint64_t)(2 * t.reps + 1)) {
+                out_of_steps = true;
+                break;
+            }
+            ctx->o.rows_per_block = t.rpu;
+            ctx->o.cols_per_lane = t.cpl;
+            if (t.cpl != warm_cpl || t.k != warm_k) { // another kernel: one untimed pass first
+                st = r.advance(t.V, t.k);
+                warm_cpl = t.cpl;
+                warm_k = t.k;
+            }
+            for (int w = 0; w < 3 && st == GS_OK; ++w) {
+                st = mark(ctx->tune_events[3 * nb + w]);
+                for (int p = 0; p < t.reps && w < 2 && st == GS_OK; ++p) st = r.advance(t.V, t.k);
+            }
+            ctx->o.rows_per_block = 0;
+            ctx->o.cols_per_lane = user_cpl;
+            batch[nb++] = t;
+        }
+        if (st != GS_OK) return st;
+        if (nb > 0 && hipEventSynchronize(ctx->tune_events[3 * (nb - 1) + 2]) != hipSuccess)
+            return fail(GS_ERR_HIP, "waiting for the tuning passes failed");
+        for (int b = 0; b < nb; ++b) {
+            float w0 = 0.f, w1 = 0.f;
+            if (hipEventElapsedTime(&w0, ctx->tune_events[3 * b], ctx->tune_events[3 * b + 1]) != hipSuccess ||
+                hipEventElapsedTime(&w1, ctx->tune_events[3 * b + 1], ctx->tune_events[3 * b + 2]) != hipSuccess)
+                return fail(GS_ERR_HIP, "timing a tuning pass failed");
+            const float ms = (w0 < w1 ? w0 : w1) / (float)(batch[b].reps * batch[b].k); // per time step
+            static const bool trace = std::getenv("GS_HIP_TRACE_TUNER") != nullptr;
+            if (trace)
+                std::fprintf(stderr, "gs_hip tuner %llux%llu: unit %3d rows, %d band(s), %d steps/pass, %d col/lane: "
+                                     "%.4f ms/step (windows %.3f %.3f ms)\n",
+                             (unsigned long long)f->rows, (unsigned long long)f->cols, batch[b].rpu, batch[b].V,
+                             batch[b].k, batch[b].cpl, ms, w0, w1);
+            // prefer the incumbent unless the newcomer is clearly faster: by 1 %, or by 3 % when it
+            // fuses fewer steps (more HBM traffic, slower remainder passes: a tie is not worth it)
+            const float margin = batch[b].k < ctx->tune_best_k ? 0.97f : 0.99f;
+            if (ctx->tune_best_rpu == 0 || ms < margin * ctx->tune_best_ms) {
+                ctx->tune_best_ms = ms;
+                ctx->tune_best_rpu = batch[b].rpu;
+                ctx->tune_best_split = batch[b].V;
+                ctx->tune_best_k = batch[b].k;
+                ctx->tune_best_cpl = batch[b].cpl;
+            }
+        }
+    }
+    if (ctx->tune_next >= phase_end[3] && ctx->tune_best_rpu > 0) {
+        ctx->tuned_cpl = ctx->tune_best_cpl;
+        ctx->tuned_rpu = ctx->tune_best_rpu;
+        ctx->tuned_split = ctx->tune_best_split;
+        ctx->tuned_k = ctx->tune_best_k;
+        ctx->tuned_fuse = fuse;
+        ctx->tuned_rows = f->rows;
+        ctx->tuned_cols = f->cols;
+        if (std::getenv("GS_HIP_TRACE_TUNER"))
+            std::fprintf(stderr, "gs_hip tuner %llux%llu: chose unit %d rows, %d steps/pass, %d col/lane\n",
+                         (unsigned long long)f->rows, (unsigned long long)f->cols, ctx->tuned_rpu, ctx->tuned_k,
+                         ctx->tuned_cpl);
+    }
+    return GS_OK;
+}
+
+// hipGraph replay (gs_options.use_graph): passes of kk fused steps are captured in batches of
+// kGraphBatch -- an even number, so a batch ends on the planes it started from and can be replayed
+// as is -- and each batch costs one hipGraphLaunch instead of kGraphBatch kernel launches on the
+// host side.  The captured launches carry plane addresses, tuning and parameters: the key holds
+// all of them and a mismatch rebuilds the graph.
+int32_t replay_graph_batches(Run &r, int kk)
+{
+    constexpr int kGraphBatch = 16;
+    gs_ctx *ctx = r.ctx;
+    if ((r.steps - r.n) / (uint64_t)kk < (uint64_t)kGraphBatch) return GS_OK;
+    SlabRt &sl = ctx->slabs[0];
+    GS_HIP(hipSetDevice(sl.device));
+    GS_TRY(join_bands(ctx, sl.compute));
+    ctx->bands_active = false;
+    const gs_field *f = r.u[0];
+    gs_ctx::GraphKey key;
+    std::memset(&key, 0, sizeof key); // padding included: the key is compared with memcmp
+    key.planes[0] = r.u[r.in]->s[0].row0; key.planes[1] = r.v[r.in]->s[0].row0;
+    key.planes[2] = r.u[1 - r.in]->s[0].row0; key.planes[3] = r.v[1 - r.in]->s[0].row0;
+    key.rows = f->rows; key.cols = f->cols;
+    key.k = kk;
+    key.rpu = pick_rows_per_unit(ctx, (int32_t)f->rows, (int32_t)f->cols, kk);
+    key.cpl = pick_cols_per_lane(ctx, (int32_t)f->rows, (int32_t)f->cols, kk);
+    key.batch = kGraphBatch;
+    key.p = ctx->p;
+    if (!ctx->graph_exec || !(ctx->graph_key == key)) {
+        if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+        if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+        const uint64_t n0 = r.n, step0 = ctx->step_no, launches0 = ctx->launches;
+        const int in0 = r.in;
+        GS_HIP(hipStreamBeginCapture(sl.compute, hipStreamCaptureModeThreadLocal));
+        int32_t st = GS_OK;
+        for (int b = 0; b < kGraphBatch && st == GS_OK; ++b) st = r.advance(1, kk);
+        const hipError_t e = hipStreamEndCapture(sl.compute, &ctx->graph);
+        // nothing ran: the captured passes are accounted for when the graph is launched
+        r.n = n0; ctx->step_no = step0; ctx->launches = launches0; r.in = in0;
+        if (st != GS_OK) return st;
+        if (e != hipSuccess) return fail(GS_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        GS_HIP(hipGraphInstantiate(&ctx->graph_exec, ctx->graph, nullptr, nullptr, 0));
+        ctx->graph_key = key;
+    }
+    while ((r.steps - r.n) / (uint64_t)kk >= (uint64_t)kGraphBatch) {
+        GS_HIP(hipGraphLaunch(ctx->graph_exec, sl.compute));
+        r.n += (uint64_t)kGraphBatch * kk;
+        ctx->step_no += kGraphBatch;
+        ctx->launches += kGraphBatch;
+    }
+    for (int i = 0; i < 2; ++i) { // as after the last pass of a batch
+        r.u[i]->ghost_depth = kk;
+        r.v[i]->ghost_depth = kk;
+    }
+    return GS_OK;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -1016,8 +1256,8 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
                int32_t *result_slot)
 {
     GS_TRY(check_step_fields(ctx, u0, v0, u1, v1));
-    gs_field *u[2] = {u0, u1}, *v[2] = {v0, v1};
-    int in = 0;
+    Run r{ctx, {u0, u1}, {v0, v1}};
+    r.steps = steps;
     // Temporal blocking: `fuse` steps per pass over HBM (default 4, the measured optimum);
     // bounded by the ghost depth and by the smallest slab of the partition.
     int fuse = 1;
@@ -1029,244 +1269,20 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     }
     // The short pass (steps % fuse) goes first so that a run ends on a full-depth ghost exchange
     // and the next run can start without a blocking refresh.
-    uint64_t n = 0;
-    if (steps % (uint64_t)fuse) {
-        const int k = (int)(steps % (uint64_t)fuse);
-        GS_TRY(step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], k));
-        in = 1 - in;
-        n += (uint64_t)k;
-    }
-    // On-line choice of the unit height (single slab, fused passes, no explicit setting): the
-    // best value depends on how the launch tiles the chip (tail effects vs 2K redundant rows per
-    // unit), so the first passes of a long run are timed with a few candidates -- they are real
-    // passes of the simulation, nothing is recomputed -- and the fastest is kept for this shape.
-    const bool tunable = ctx->total_slabs() == 1 && fuse > 1 && ctx->o.rows_per_block == 0 &&
-                         !(ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse && ctx->tuned_rows == u0->rows &&
-                           ctx->tuned_cols == u0->cols);
-    auto advance = [&](int V, int k) -> int32_t {
-        const int32_t st = V > 1 ? step_bands(ctx, u[in], v[in], u[1 - in], v[1 - in], k, V)
-                                 : step_impl(ctx, u[in], v[in], u[1 - in], v[1 - in], k);
-        in = 1 - in;
-        n += (uint64_t)k;
-        return st;
-    };
-    if (tunable) {
-        // phase A: unit heights; (phase B, band counts: retired;) phase C: fewer fused steps per pass
-        // with the best of A and B (when fuse_steps is not pinned) -- on small, cache-resident grids
-        // the 2K redundant rows per unit can cost more than the extra passes; phase D (columns per
-        // lane not pinned): 1 and 4 columns per lane -- more, narrower waves for small grids; fewer,
-        // wider ones with 16-byte accesses -- with a few unit heights each (large grids skip the
-        // candidates that would only multiply tiny units).  A-C run with 2 columns per lane.
-        static const int cand[] = {8, 12, 16, 24, 32, 48, 64, 96, 128};
-        static const int alt[] = {1, 2, 3};
-        static const int altk[] = {3, 2};
-        static const int candn[] = {8, 16, 32, 64, 128};
-        static const int cpls[] = {1, 4};
-        const int ncand = (int)(sizeof cand / sizeof cand[0]);
-        const int nalt = 0; // band counts are not explored any more (see bands_for); phase B is empty
-        (void)alt;
-        const int nk = ctx->o.fuse_steps == 0 ? (int)(sizeof altk / sizeof altk[0]) : 0;
-        const uint64_t cells = u0->rows * u0->cols;
-        const int ncandn = (int)(sizeof candn / sizeof candn[0]);
-        const int nn = ctx->o.cols_per_lane == 0 ? ncandn * (int)(sizeof cpls / sizeof cpls[0]) : 0;
-        const bool large = cells > (1ull << 26);
-        const int user_cpl = ctx->o.cols_per_lane;
-        // timed passes per candidate: short passes need more of them for a stable comparison
-        const int reps = cells >= (1ull << 27) ? 2 : (cells >= (1ull << 24) ? 6 : 8);
-        if (ctx->tune_rows != u0->rows || ctx->tune_cols != u0->cols || ctx->tune_fuse != fuse) {
-            ctx->tune_rows = u0->rows;
-            ctx->tune_cols = u0->cols;
-            ctx->tune_fuse = fuse;
-            ctx->tune_next = 0;
-            ctx->tune_best_rpu = 0;
-            ctx->tune_best_split = 0;
-            ctx->tune_best_k = 0;
-            ctx->tune_best_cpl = 0;
-            ctx->tune_best_ms = 0.f;
-        }
-        const int V0 = bands_for(ctx, u0, fuse);
-        SlabRt &sl = ctx->slabs[0];
-        GS_HIP(hipSetDevice(sl.device));
-        // Candidates of one phase do not depend on each other, so a whole phase is enqueued
-        // back to back -- per candidate: [an untimed pass when the kernel changes,] event, `reps`
-        // passes, event, `reps` passes, event -- and the host waits once per phase: no idle gaps
-        // (clock ramps) between the timing windows.  A candidate's time is the shorter of its two
-        // windows.
-        struct Trial { int rpu, V, k, cpl, reps; };
-        // Timestamp "everything enqueued so far has finished" without holding anything back: after
-        // a banded pass the event is recorded on the copy stream, which is made to wait for the
-        // bands (a record on the compute stream would turn every window boundary into a barrier
-        // between passes, and hide exactly the overlap that bands are for).
-        auto mark = [&](hipEvent_t ev) -> int32_t {
-            hipStream_t ts = sl.compute;
-            if (ctx->bands_active) {
-                ts = sl.copy;
-                GS_TRY(join_bands(ctx, ts));
-            }
-            GS_HIP(hipEventRecord(ev, ts));
-            return GS_OK;
-        };
-        constexpr int kMaxBatch = 10;
-        if (ctx->tune_events.empty()) {
-            ctx->tune_events.resize(3 * kMaxBatch, nullptr);
-            for (auto &e : ctx->tune_events) GS_HIP(hipEventCreate(&e));
-        }
-        const int phase_end[4] = {ncand, ncand + nalt, ncand + nalt + nk, ncand + nalt + nk + nn};
-        int warm_cpl = 0, warm_k = 0; // kernel of the newest pass enqueued by this call
-        bool out_of_steps = false;
-        while (ctx->tune_next < phase_end[3] && !out_of_steps) {
-            int phase = 0;
-            while (ctx->tune_next >= phase_end[phase]) ++phase;
-            Trial batch[kMaxBatch];
-            int nb = 0;
-            int32_t st = GS_OK;
-            for (; ctx->tune_next < phase_end[phase] && nb < kMaxBatch && st == GS_OK; ++ctx->tune_next) {
-                Trial t{0, V0, fuse, user_cpl ? user_cpl : 2, reps};
-                const int i = ctx->tune_next - (phase ? phase_end[phase - 1] : 0);
-                if (phase == 0) {
-                    t.rpu = cand[i];
-                    if (t.rpu < 2 * fuse || (uint64_t)t.rpu > u0->rows) continue;
-                } else if (phase == 1) {
-                    t.rpu = ctx->tune_best_rpu;
-                    t.V = clamp_bands(u0, fuse, alt[i]);
-                    if (t.rpu == 0 || t.V == V0 || t.V != alt[i]) continue;
-                } else if (phase == 2) {
-                    t.rpu = ctx->tune_best_rpu;
-                    t.V = ctx->tune_best_split;
-                    t.k = altk[i];
-                    if (t.rpu == 0 || t.k >= fuse) continue;
-                } else {
-                    t.cpl = cpls[i / ncandn];
-                    t.rpu = candn[i % ncandn];
-                    t.V = ctx->tune_best_split;
-                    t.k = ctx->tune_best_k;
-                    if (ctx->tune_best_rpu == 0 || t.rpu < 2 * t.k || (uint64_t)t.rpu > u0->rows ||
-                        (large && (t.cpl == 1 || t.rpu < 32)))
-                        continue;
-                }
-                // short calls (a driver loop with few steps per image) get shorter windows rather
-                // than no tuning at all; with less than 3 passes left it continues in the next gs_run
-                const uint64_t passes_left = (steps - n) / (uint64_t)t.k;
-                while (t.reps > 1 && passes_left < (uint64_t)(2 * t.reps + 1)) --t.reps;
-                if (passes_left < (uint64_t)(2 * t.reps + 1)) {
-                    out_of_steps = true;
-                    break;
-                }
-                ctx->o.rows_per_block = t.rpu;
-                ctx->o.cols_per_lane = t.cpl;
-                if (t.cpl != warm_cpl || t.k != warm_k) { // another kernel: one untimed pass first
-                    st = advance(t.V, t.k);
-                    warm_cpl = t.cpl;
-                    warm_k = t.k;
-                }
-                for (int w = 0; w < 3 && st == GS_OK; ++w) {
-                    st = mark(ctx->tune_events[3 * nb + w]);
-                    for (int r = 0; r < t.reps && w < 2 && st == GS_OK; ++r) st = advance(t.V, t.k);
-                }
-                ctx->o.rows_per_block = 0;
-                ctx->o.cols_per_lane = user_cpl;
-                batch[nb++] = t;
-            }
-            if (st != GS_OK) return st;
-            if (nb > 0 && hipEventSynchronize(ctx->tune_events[3 * (nb - 1) + 2]) != hipSuccess)
-                return fail(GS_ERR_HIP, "waiting for the tuning passes failed");
-            for (int b = 0; b < nb; ++b) {
-                float w0 = 0.f, w1 = 0.f;
-                if (hipEventElapsedTime(&w0, ctx->tune_events[3 * b], ctx->tune_events[3 * b + 1]) != hipSuccess ||
-                    hipEventElapsedTime(&w1, ctx->tune_events[3 * b + 1], ctx->tune_events[3 * b + 2]) != hipSuccess)
-                    return fail(GS_ERR_HIP, "timing a tuning pass failed");
-                const float ms = (w0 < w1 ? w0 : w1) / (float)(batch[b].reps * batch[b].k); // per time step
-                static const bool trace = std::getenv("GS_HIP_TRACE_TUNER") != nullptr;
-                if (trace)
-                    std::fprintf(stderr, "gs_hip tuner %llux%llu: unit %3d rows, %d band(s), %d steps/pass, %d col/lane: "
-                                         "%.4f ms/step (windows %.3f %.3f ms)\n",
-                                 (unsigned long long)u0->rows, (unsigned long long)u0->cols, batch[b].rpu, batch[b].V,
-                                 batch[b].k, batch[b].cpl, ms, w0, w1);
-                // prefer the incumbent unless the newcomer is clearly faster: by 1 %, or by 3 % when it
-                // fuses fewer steps (more HBM traffic, slower remainder passes: a tie is not worth it)
-                const float margin = batch[b].k < ctx->tune_best_k ? 0.97f : 0.99f;
-                if (ctx->tune_best_rpu == 0 || ms < margin * ctx->tune_best_ms) {
-                    ctx->tune_best_ms = ms;
-                    ctx->tune_best_rpu = batch[b].rpu;
-                    ctx->tune_best_split = batch[b].V;
-                    ctx->tune_best_k = batch[b].k;
-                    ctx->tune_best_cpl = batch[b].cpl;
-                }
-            }
-        }
-        if (ctx->tune_next >= ncand + nalt + nk + nn && ctx->tune_best_rpu > 0) {
-            ctx->tuned_cpl = ctx->tune_best_cpl;
-            ctx->tuned_rpu = ctx->tune_best_rpu;
-            ctx->tuned_split = ctx->tune_best_split;
-            ctx->tuned_k = ctx->tune_best_k;
-            ctx->tuned_fuse = fuse;
-            ctx->tuned_rows = u0->rows;
-            ctx->tuned_cols = u0->cols;
-            if (std::getenv("GS_HIP_TRACE_TUNER"))
-                std::fprintf(stderr, "gs_hip tuner %llux%llu: chose unit %d rows, %d steps/pass, %d col/lane\n",
-                             (unsigned long long)u0->rows, (unsigned long long)u0->cols, ctx->tuned_rpu, ctx->tuned_k,
-                             ctx->tuned_cpl);
-        }
-    }
-    const bool tuned = ctx->total_slabs() == 1 && ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse &&
-                       ctx->tuned_rows == u0->rows && ctx->tuned_cols == u0->cols && ctx->tuned_k > 0;
-    const int kk = tuned ? ctx->tuned_k : fuse;
+    if (steps % (uint64_t)fuse) GS_TRY(r.advance(1, (int)(steps % (uint64_t)fuse)));
+    const bool single = ctx->total_slabs() == 1;
+    if (single && fuse > 1 && ctx->o.rows_per_block == 0 && !tuned_shape(ctx, u0, fuse)) GS_TRY(tune_online(r, fuse));
+    const int kk = single && tuned_shape(ctx, u0, fuse) && ctx->tuned_k > 0 ? ctx->tuned_k : fuse;
     const int V = bands_for(ctx, u0, kk);
-    // hipGraph replay (gs_options.use_graph): passes are captured in batches of kGraphBatch -- an
-    // even number, so a batch ends on the planes it started from and can be replayed as is -- and
-    // each batch costs one hipGraphLaunch instead of kGraphBatch kernel launches on the host side.
-    constexpr int kGraphBatch = 16;
-    if (ctx->o.use_graph && ctx->total_slabs() == 1 && V == 1 && kk > 1 &&
-        (steps - n) / (uint64_t)kk >= (uint64_t)kGraphBatch) {
-        SlabRt &sl = ctx->slabs[0];
-        GS_HIP(hipSetDevice(sl.device));
-        GS_TRY(join_bands(ctx, sl.compute));
-        ctx->bands_active = false;
-        gs_ctx::GraphKey key;
-        std::memset(&key, 0, sizeof key); // padding included: the key is compared with memcmp
-        key.planes[0] = u[in]->s[0].row0; key.planes[1] = v[in]->s[0].row0;
-        key.planes[2] = u[1 - in]->s[0].row0; key.planes[3] = v[1 - in]->s[0].row0;
-        key.rows = u0->rows; key.cols = u0->cols;
-        key.k = kk;
-        key.rpu = pick_rows_per_unit(ctx, (int32_t)u0->rows, (int32_t)u0->cols, kk);
-        key.cpl = pick_cols_per_lane(ctx, (int32_t)u0->rows, (int32_t)u0->cols, kk);
-        key.batch = kGraphBatch;
-        key.p = ctx->p;
-        if (!ctx->graph_exec || !(ctx->graph_key == key)) {
-            if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
-            if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
-            const uint64_t n0 = n, step0 = ctx->step_no, launches0 = ctx->launches;
-            const int in0 = in;
-            GS_HIP(hipStreamBeginCapture(sl.compute, hipStreamCaptureModeThreadLocal));
-            int32_t st = GS_OK;
-            for (int b = 0; b < kGraphBatch && st == GS_OK; ++b) st = advance(1, kk);
-            const hipError_t e = hipStreamEndCapture(sl.compute, &ctx->graph);
-            // nothing ran: the captured passes are accounted for when the graph is launched
-            n = n0; ctx->step_no = step0; ctx->launches = launches0; in = in0;
-            if (st != GS_OK) return st;
-            if (e != hipSuccess) return fail(GS_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-            GS_HIP(hipGraphInstantiate(&ctx->graph_exec, ctx->graph, nullptr, nullptr, 0));
-            ctx->graph_key = key;
-        }
-        while ((steps - n) / (uint64_t)kk >= (uint64_t)kGraphBatch) {
-            GS_HIP(hipGraphLaunch(ctx->graph_exec, sl.compute));
-            n += (uint64_t)kGraphBatch * kk;
-            ctx->step_no += kGraphBatch;
-            ctx->launches += kGraphBatch;
-        }
-        u[1 - in]->ghost_depth = kk; // as after the last pass of a batch
-        v[1 - in]->ghost_depth = kk;
-        u[in]->ghost_depth = kk;
-        v[in]->ghost_depth = kk;
-    }
+    if (ctx->o.use_graph && single && V == 1 && kk > 1) GS_TRY(replay_graph_batches(r, kk));
     const char *full_pass = nullptr;
-    while (n < steps) {
-        const int k = (steps - n) >= (uint64_t)kk ? kk : (int)(steps - n);
-        GS_TRY(advance(k == kk ? V : 1, k));
+    while (r.n < steps) {
+        const int k = (steps - r.n) >= (uint64_t)kk ? kk : (int)(steps - r.n);
+        GS_TRY(r.advance(k == kk ? V : 1, k));
         if (k == kk) full_pass = ctx->last_kernel;
     }
     if (full_pass) ctx->last_kernel = full_pass; // gs_ctx_info names the full pass, not a remainder
-    if (result_slot) *result_slot = in;
+    if (result_slot) *result_slot = r.in;
     return GS_OK;
 }
 
