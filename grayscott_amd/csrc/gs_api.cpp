@@ -566,6 +566,10 @@ int32_t step_impl(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, 
 {
     const int n_local = (int)ctx->slabs.size();
     const int S = ctx->total_slabs();
+    if (in_u->rows == 0 || in_u->cols == 0) { // empty grid: every step is a no-op
+        ctx->step_no++;
+        return GS_OK;
+    }
     if (S == 1) {
         SlabRt &sl = ctx->slabs[0];
         GS_HIP(hipSetDevice(sl.device));
@@ -1095,12 +1099,13 @@ int32_t gs_field_create(gs_ctx *ctx, gs_field **out, uint64_t rows, uint64_t col
     if (!ctx || !out) return fail(GS_ERR_INVALID, "null argument");
     *out = nullptr;
     const uint64_t S = (uint64_t)ctx->total_slabs();
-    if (rows == 0 || cols == 0) return fail(GS_ERR_INVALID, "empty shape [%llu, %llu]",
-                                            (unsigned long long)rows, (unsigned long long)cols);
-    if (rows < S) return fail(GS_ERR_INVALID, "%llu rows cannot be split over %llu slabs",
-                              (unsigned long long)rows, (unsigned long long)S);
+    // An empty grid is legal in the reference (ndarray holds zero-sized arrays and every step is a
+    // no-op on them); here it is a single slab with no rows or no columns that no kernel touches.
+    if (rows < S && !(rows == 0 && S == 1))
+        return fail(GS_ERR_INVALID, "%llu rows cannot be split over %llu slabs",
+                    (unsigned long long)rows, (unsigned long long)S);
     const int pad = ctx->o.pitch_pad > 0 ? ((ctx->o.pitch_pad + 3) / 4) * 4 : 0;
-    const uint64_t pitch = ((cols + 63) / 64) * 64 + (uint64_t)pad;
+    const uint64_t pitch = (cols == 0 ? 64 : ((cols + 63) / 64) * 64) + (uint64_t)pad;
     if (pitch > 0x7ffffff0ull) return fail(GS_ERR_UNSUPPORTED, "too many columns");
     gs_field *f = new (std::nothrow) gs_field();
     if (!f) return fail(GS_ERR_NOMEM, "out of host memory");
@@ -1205,7 +1210,9 @@ int32_t gs_field_finalize(gs_ctx *ctx, gs_field *f)
 
 int32_t gs_field_upload(gs_ctx *ctx, gs_field *f, const float *host)
 {
-    if (!ctx || !f || !host || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad argument");
+    if (!ctx || !f || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad argument");
+    if (f->rows == 0 || f->cols == 0) return GS_OK; // nothing to copy (host may be null)
+    if (!host) return fail(GS_ERR_INVALID, "bad argument");
     GS_TRY(sync_all(ctx));
     const uint64_t first = f->s.front().g_row0;
     for (size_t i = 0; i < f->s.size(); ++i) {
@@ -1221,8 +1228,10 @@ int32_t gs_field_upload(gs_ctx *ctx, gs_field *f, const float *host)
 
 int32_t gs_field_download(gs_ctx *ctx, gs_field *f, float *host)
 {
-    if (!ctx || !f || !host || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad argument");
+    if (!ctx || !f || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad argument");
     GS_TRY(sync_all(ctx));
+    if (f->rows == 0 || f->cols == 0) return GS_OK; // nothing to copy (host may be null)
+    if (!host) return fail(GS_ERR_INVALID, "bad argument");
     const uint64_t first = f->s.front().g_row0;
     for (size_t i = 0; i < f->s.size(); ++i) {
         const FieldSlab &fs = f->s[i];
@@ -1311,7 +1320,9 @@ int32_t gs_host_free(void *p)
 
 int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host)
 {
-    if (!ctx || !f || !host || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad argument");
+    if (!ctx || !f || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad argument");
+    if (f->rows == 0 || f->cols == 0) return GS_OK; // nothing to copy (host may be null)
+    if (!host) return fail(GS_ERR_INVALID, "bad argument");
     const uint64_t first = f->s.front().g_row0;
     const int last = (int)((ctx->step_no + 1) & 1); // parity of the most recent pass
     for (size_t i = 0; i < f->s.size(); ++i) {

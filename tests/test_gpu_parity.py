@@ -469,11 +469,25 @@ def test_error_behaviour():
     with pytest.raises(GsError):
         a.fill_slice(ctx, [range(0, 9), range(0, 8)], 1.0)  # out of range, as ndarray slicing panics
     with pytest.raises(GsError):
-        HipConcentration(ctx, (0, 8))
-    with pytest.raises(GsError):
         Simulation.new(Parameters(), HipArgs(devices=[99]))
+    with pytest.raises(GsError):                              # 2 rows cannot be split over 3 slabs
+        Simulation.new(Parameters(), args(devices=[0, 0, 0])).make_species([2, 8])
     a.fill_slice(ctx, [range(2, 2), range(0, 8)], 5.0)  # empty range is fine
     assert float(a.make_scalar_view(ctx).sum()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(0, 0), (0, 7), (5, 0)])
+def test_empty_grids_are_legal_no_ops(shape):
+    """ndarray holds zero-sized arrays, so Species::new, perform_steps and the result view all work
+    on an empty grid in the reference (and do nothing); same here."""
+    sim = Simulation.new(Parameters(), args())
+    species = sim.make_species(list(shape))
+    sim.perform_steps(species, 9)
+    sim.perform_step(species)
+    view = species.make_result_view()
+    assert view.shape == shape and view.dtype == np.float32
+    u, v = oracle.run(*oracle.init_species(*shape), 10)
+    assert u.shape == shape and v.shape == shape
 
 
 # ---- in-process row slabs with ghost rows (the multi-GPU data path on one GPU) --------------
