@@ -6,11 +6,12 @@ with buffer recycling (main.rs:73-121), shared CLI flags of ui/src/lib.rs:18-46.
 reference's ``async-gpu`` path (main.rs:99-106) the steps and the download of the result are
 enqueued together: the download of image i overlaps the steps of image i+1.
 
-    python -m grayscott_amd.simulate -n 100 -r 1080 -c 1920 -o out.npy
+    python -m grayscott_amd.simulate -n 100 -r 1080 -c 1920 -o out.h5
 
 Output: the reference writes an HDF5 dataset ``matrix[nbimage, rows, cols]`` f32
-(data/src/hdf5.rs:36-63); libhdf5/h5py are not in this image, so the same array is written as
-a ``.npy`` file (numpy format 1.0, C order) -- same shape, dtype and row order.
+(data/src/hdf5.rs:36-63).  ``-o name.h5`` (or ``.hdf5``) writes that dataset through the minimal
+HDF5 writer of ``grayscott_amd/hdf5_min.py`` (libhdf5 / h5py are not in this image: see the status
+note there); any other name gives a ``.npy`` file (numpy format 1.0, C order) with the same array.
 """
 from __future__ import annotations
 
@@ -22,6 +23,7 @@ import time
 
 import numpy as np
 
+from . import hdf5_min
 from .simulation import HipArgs, Parameters, Simulation, pinned_empty
 
 
@@ -34,7 +36,7 @@ def parse(argv=None):
     ap.add_argument("-c", "--nbcol", type=int, default=1920)             # :36-38
     ap.add_argument("-t", "--deltat", type=float, default=None)          # :40-42
     ap.add_argument("-n", "--nbimage", type=int, default=1000)           # main.rs:29-31
-    ap.add_argument("-o", "--output", default="output.npy")              # main.rs:33-35
+    ap.add_argument("-o", "--output", default="output.h5")               # main.rs:33-35, ui/src/lib.rs:72-75
     ap.add_argument("--output-buffer", type=int, default=2)              # main.rs:37-43
     return ap.parse_args(argv)
 
@@ -59,7 +61,9 @@ def run(args, hip_args: HipArgs | None = None, out=None) -> dict:
     sim = Simulation.new(simulation_parameters(args), hip_args)
     species = sim.make_species(shape)
     ctx = sim.context
-    if out is None:
+    if out is None and args.output.lower().endswith((".h5", ".hdf5")):
+        out = hdf5_min.create(args.output, (args.nbimage,) + shape)       # dataset "matrix" (hdf5.rs:24)
+    elif out is None:
         out = np.lib.format.open_memmap(args.output, mode="w+", dtype=np.float32,
                                         shape=(args.nbimage,) + shape)
 

@@ -47,7 +47,34 @@ def test_driver_loop_matches_oracle(built, tmp_path):
         assert_bits_equal(data[i], v, f"image {i}")
 
 
+def test_driver_loop_writes_the_reference_container(built, tmp_path):
+    """-o *.h5: dataset "matrix" [nbimage, rows, cols] f32 in [1, rows, cols] chunks (data/src/hdf5.rs:36-63),
+    read back with our parser and, where an HDF5 installation exists, with the real h5dump."""
+    import os
+    import subprocess
+
+    from grayscott_amd import hdf5_min
+
+    out = tmp_path / "out.h5"
+    info = driver.run(driver.parse(["-n", "70", "-e", "5", "-r", "64", "-c", "200", "-o", str(out)]))
+    assert info["images"] == 70
+    data = hdf5_min.read(str(out))
+    assert data.shape == (70, 64, 200)
+    u, v = oracle.init_species(64, 200)
+    for i in range(70):
+        u, v = oracle.run(u, v, 5)
+        assert_bits_equal(np.asarray(data[i]), v, f"image {i}")
+    h5dump = os.path.join(os.environ.get("HDF5_DIR", "/opt/conda"), "bin", "h5dump")
+    if os.path.exists(h5dump):
+        header = subprocess.run([h5dump, "-p", "-H", str(out)], capture_output=True, text=True, check=True).stdout
+        assert "CHUNKED ( 1, 64, 200 )" in header and "( 70, 64, 200 )" in header and "H5T_IEEE_F32LE" in header
+        dump = tmp_path / "dump.bin"
+        subprocess.run([h5dump, "-d", "/matrix", "-b", "LE", "-o", str(dump), str(out)], capture_output=True, check=True)
+        assert np.array_equal(np.fromfile(dump, "<f4").reshape(70, 64, 200), np.asarray(data))
+
+
 def test_driver_defaults_match_reference_cli():
     a = driver.parse([])
+    assert a.output == "output.h5"                                                  # ui/src/lib.rs:72-75
     assert (a.nbrow, a.nbcol, a.nbimage, a.output_buffer) == (1080, 1920, 1000, 2)  # ui/src/lib.rs:32-38, main.rs:29-43
     assert a.nbextrastep is None and driver.simulation_parameters(a) == Parameters()
