@@ -176,7 +176,7 @@ struct gs_ctx {
         uint64_t rows = 0, cols = 0;
         int k = 0, rpu = 0, cpl = 0, batch = 0;
         gs_params p{};
-        bool operator==(const GraphKey &o) const { return std::memcmp(this, &o, sizeof *this) == 0; }
+        bool operator==(const GraphKey &other) const { return std::memcmp(this, &other, sizeof *this) == 0; }
     } graph_key;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -478,13 +478,6 @@ int32_t join_bands(gs_ctx *ctx, hipStream_t stream)
             GS_HIP(hipStreamWaitEvent(stream, b.halod[k], 0));
         }
     return GS_OK;
-}
-
-int clamp_bands(const gs_field *f, int fuse, int V)
-{
-    if (V > 8) V = 8;
-    while (V > 1 && f->rows / (uint64_t)V < (uint64_t)(8 * fuse)) --V;
-    return V < 1 ? 1 : V;
 }
 
 int bands_for(const gs_ctx *ctx, const gs_field *f, int fuse)
