@@ -10,6 +10,9 @@ Contents (float32 bit patterns; FTZ on, as under the reference's DenormalsFlushe
   ftz_front_64x128.npz     Species::new([64,128]) after 30 and 40 steps, with FTZ and without: V's
                            diffusion front is in the sub-normal range there (hundreds of cells
                            differ between the two), which pins the flush-to-zero rule
+  zero_halo_64x128.npz     the other boundary rule (GS_BOUNDARY_ZERO_HALO): Species::new([64,128])
+                           after 1, 10, 100 steps and a 17x33 stress field after 1 and 20 steps
+  stencils_37x60.npz       a stress field after 12 steps with each of the reference's named stencils
 """
 import os
 import sys
@@ -59,6 +62,29 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ftz_front_64x128.npz"), **out)
     print("cells differing between FTZ and no-FTZ runs:", ndiff)
     assert ndiff > 1000
+
+    u0, v0 = oracle.init_species(64, 128)
+    out = {}
+    for steps in (1, 10, 100):
+        u, v = oracle.run(u0, v0, steps, p, ftz=True, boundary=oracle.ZERO_HALO)
+        out[f"u_{steps}"], out[f"v_{steps}"] = u, v
+    su, sv = stress_fields((17, 33), 2)
+    out["stress_u0"], out["stress_v0"] = su, sv
+    for steps in (1, 20):
+        u, v = oracle.run(su, sv, steps, p, ftz=True, boundary=oracle.ZERO_HALO)
+        out[f"stress_u_{steps}"], out[f"stress_v_{steps}"] = u, v
+    np.savez_compressed(os.path.join(HERE, "zero_halo_64x128.npz"), **out)
+
+    from grayscott_amd.simulation import STENCILS   # the weight tables only; no GPU involved
+    su, sv = stress_fields((37, 60), 4)
+    out = {"u0": su, "v0": sv}
+    for name, w in STENCILS.items():
+        q = oracle.default_params()
+        q.set_weights(w)
+        q.dt = 0.25 if name == "pretty" else 1.0
+        u, v = oracle.run(su, sv, 12, q, ftz=True)
+        out[f"u_{name}"], out[f"v_{name}"] = u, v
+    np.savez_compressed(os.path.join(HERE, "stencils_37x60.npz"), **out)
 
 if __name__ == "__main__":
     main()

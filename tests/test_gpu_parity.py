@@ -73,6 +73,32 @@ def test_golden_vectors():
         assert_bits_equal(in_v.make_scalar_view(sim.context), g[f"v_{steps}"], f"species_new V {steps}")
 
 
+def test_golden_vectors_zero_halo_and_stencils():
+    """The committed fixtures of the widened rows, without the oracle at run time."""
+    from grayscott_amd.simulation import STENCILS
+
+    g = np.load(os.path.join(GOLDEN, "zero_halo_64x128.npz"))
+    sim = Simulation.new(Parameters(), args(boundary=capi.GS_BOUNDARY_ZERO_HALO))
+    species = sim.make_species([64, 128])
+    done = 0
+    for steps in (1, 10, 100):
+        sim.perform_steps(species, steps - done)
+        done = steps
+        in_u, in_v, _, _ = species.in_out()
+        assert_bits_equal(in_u.make_scalar_view(sim.context), g[f"u_{steps}"], f"zero halo U {steps}")
+        assert_bits_equal(in_v.make_scalar_view(sim.context), g[f"v_{steps}"], f"zero halo V {steps}")
+    for steps in (1, 20):
+        got_u, got_v, _ = gpu_run(g["stress_u0"], g["stress_v0"], steps, args=args(boundary=capi.GS_BOUNDARY_ZERO_HALO))
+        assert_bits_equal(got_u, g[f"stress_u_{steps}"], f"zero halo stress U {steps}")
+        assert_bits_equal(got_v, g[f"stress_v_{steps}"], f"zero halo stress V {steps}")
+    g = np.load(os.path.join(GOLDEN, "stencils_37x60.npz"))
+    for name in STENCILS:
+        p = Parameters.with_stencil(name, time_step=0.25 if name == "pretty" else 1.0)
+        got_u, got_v, _ = gpu_run(g["u0"], g["v0"], 12, params=p)
+        assert_bits_equal(got_u, g[f"u_{name}"], f"stencil {name} U")
+        assert_bits_equal(got_v, g[f"v_{name}"], f"stencil {name} V")
+
+
 def test_ftz_rule_matches_cpu_flush_to_zero():
     """Strict flavour = MXCSR.FTZ semantics (flush results, keep inputs): V's sub-normal front."""
     g = np.load(os.path.join(GOLDEN, "ftz_front_64x128.npz"))

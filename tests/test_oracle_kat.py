@@ -269,3 +269,26 @@ def test_zero_halo_checker_against_the_parallel_backend_port():
     clip_u, _ = oracle.run(u0, v0, 60)
     assert np.max(np.abs(sim.read(0) - clip_u)) > 1e-2
     sim.close()
+
+
+def test_golden_zero_halo_and_stencils():
+    """Fixtures of the widened rows (the other boundary rule, the named stencils)."""
+    from grayscott_amd.simulation import STENCILS
+
+    g = np.load(os.path.join(GOLDEN, "zero_halo_64x128.npz"))
+    u0, v0 = oracle.init_species(64, 128)
+    for steps in (1, 10, 100):
+        u, v = oracle.run(u0, v0, steps, ftz=True, boundary=oracle.ZERO_HALO)
+        assert u.tobytes() == g[f"u_{steps}"].tobytes() and v.tobytes() == g[f"v_{steps}"].tobytes()
+    for steps in (1, 20):
+        u, v = oracle.run(g["stress_u0"], g["stress_v0"], steps, ftz=True, boundary=oracle.ZERO_HALO)
+        assert u.tobytes() == g[f"stress_u_{steps}"].tobytes() and v.tobytes() == g[f"stress_v_{steps}"].tobytes()
+    g = np.load(os.path.join(GOLDEN, "stencils_37x60.npz"))
+    for name, w in STENCILS.items():
+        q = oracle.default_params()
+        q.set_weights(w)
+        q.dt = 0.25 if name == "pretty" else 1.0
+        u, v = oracle.run(g["u0"], g["v0"], 12, q, ftz=True)
+        assert u.tobytes() == g[f"u_{name}"].tobytes() and v.tobytes() == g[f"v_{name}"].tobytes()
+        assert np.isfinite(u).all() and np.isfinite(v).all()
+
