@@ -164,6 +164,9 @@ struct gs_ctx {
     uint64_t tuned_rows = 0, tuned_cols = 0;
     int tuned_fuse = 0, tuned_rpu = 0, tuned_split = 0, tuned_k = 0; // tuned_k: fused steps per pass chosen
     int tuned_cpl = 0;                                               // columns per lane chosen
+    // earlier choices for other shapes (a context that alternates between grids does not re-tune)
+    struct Tuned { uint64_t rows, cols; int fuse, rpu, split, k, cpl; };
+    std::vector<Tuned> tuned_cache;
     // tuning in progress (may span several gs_run calls): next candidate, best so far
     uint64_t tune_rows = 0, tune_cols = 0;
     int tune_fuse = 0, tune_next = 0, tune_best_rpu = 0, tune_best_split = 0, tune_best_k = 0, tune_best_cpl = 0;
@@ -651,6 +654,18 @@ bool tuned_shape(const gs_ctx *ctx, const gs_field *f, int fuse)
     return ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse && ctx->tuned_rows == f->rows && ctx->tuned_cols == f->cols;
 }
 
+// Make the remembered choice for this shape (if any) the active one.
+void recall_tuned(gs_ctx *ctx, const gs_field *f, int fuse)
+{
+    if (tuned_shape(ctx, f, fuse)) return;
+    for (const gs_ctx::Tuned &t : ctx->tuned_cache)
+        if (t.rows == f->rows && t.cols == f->cols && t.fuse == fuse) {
+            ctx->tuned_rows = t.rows; ctx->tuned_cols = t.cols; ctx->tuned_fuse = t.fuse;
+            ctx->tuned_rpu = t.rpu; ctx->tuned_split = t.split; ctx->tuned_k = t.k; ctx->tuned_cpl = t.cpl;
+            return;
+        }
+}
+
 // On-line choice of unit height, fused steps per pass and columns per lane (single slab, fused
 // passes, unit height not pinned).  The best values depend on how a launch tiles the chip (tail
 // effects vs 2K redundant rows per unit vs occupancy), so the first passes of a run on a new shape
@@ -805,6 +820,8 @@ int32_t tune_online(Run &r, int fuse)
         ctx->tuned_fuse = fuse;
         ctx->tuned_rows = f->rows;
         ctx->tuned_cols = f->cols;
+        if (ctx->tuned_cache.size() >= 64) ctx->tuned_cache.erase(ctx->tuned_cache.begin());
+        ctx->tuned_cache.push_back({f->rows, f->cols, fuse, ctx->tuned_rpu, ctx->tuned_split, ctx->tuned_k, ctx->tuned_cpl});
         if (std::getenv("GS_HIP_TRACE_TUNER"))
             std::fprintf(stderr, "gs_hip tuner %llux%llu: chose unit %d rows, %d steps/pass, %d col/lane\n",
                          (unsigned long long)f->rows, (unsigned long long)f->cols, ctx->tuned_rpu, ctx->tuned_k,
@@ -1273,6 +1290,7 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     // and the next run can start without a blocking refresh.
     if (steps % (uint64_t)fuse) GS_TRY(r.advance(1, (int)(steps % (uint64_t)fuse)));
     const bool single = ctx->total_slabs() == 1;
+    if (single) recall_tuned(ctx, u0, fuse);
     if (single && fuse > 1 && ctx->o.rows_per_block == 0 && !tuned_shape(ctx, u0, fuse)) GS_TRY(tune_online(r, fuse));
     const int kk = single && tuned_shape(ctx, u0, fuse) && ctx->tuned_k > 0 ? ctx->tuned_k : fuse;
     const int V = bands_for(ctx, u0, kk);

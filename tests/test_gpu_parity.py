@@ -250,6 +250,29 @@ def test_row_bands_on_a_large_grid(split):
 
 
 # ---- non-default parameters (CLI overrides -k -f -t, ui/src/lib.rs:51-63) and weights ------
+# ---- one context, several grids ------------------------------------------------------------------
+def test_alternating_shapes_on_one_context_keep_their_tuning():
+    """The on-line choice is remembered per shape: going back to a grid does not tune again, and the
+    results stay bit-exact throughout."""
+    sim = Simulation.new(Parameters(), args())
+    shapes = [(96, 200), (64, 700)]
+    state = {s: stress_fields(s, 15) for s in shapes}
+    species = {s: species_from_arrays(sim, *state[s]) for s in shapes}
+    labels = {}
+    for round_ in range(3):
+        for s in shapes:
+            steps = 2400 if round_ == 0 else 40
+            sim.perform_steps(species[s], steps)
+            state[s] = oracle.run(state[s][0], state[s][1], steps, ftz=True)
+            iu, iv, _, _ = species[s].in_out()
+            assert_bits_equal(iu.make_scalar_view(sim.context), state[s][0], f"U {s} round {round_}")
+            assert_bits_equal(iv.make_scalar_view(sim.context), state[s][1], f"V {s} round {round_}")
+            label = sim.context.info()[0]
+            assert "@" in label, label                      # a tuned configuration is active
+            assert labels.setdefault(s, label) == label     # ... and it is the one chosen the first time
+    assert labels[shapes[0]] is not None
+
+
 # ---- extreme aspect ratios ---------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(1, 100003), (3, 70001), (70001, 3), (100003, 1), (2, 32768), (16385, 17)])
 def test_extreme_aspect_ratios(shape):
