@@ -682,7 +682,7 @@ int32_t tune_online(Run &r, int fuse)
 {
     gs_ctx *ctx = r.ctx;
     const gs_field *f = r.u[0];
-    static const int cand[] = {8, 12, 16, 24, 32, 48, 64, 96, 128};
+    static const int cand[] = {8, 12, 16, 24, 32, 48, 64, 96, 128, 192};
     static const int altk[] = {3, 2};
     static const int candn[] = {8, 16, 32, 64, 128};
     static const int cpls[] = {1, 4};
