@@ -1286,10 +1286,36 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
         if (ctx->total_slabs() > 1 && fuse > min_slab_rows(ctx, u0)) fuse = min_slab_rows(ctx, u0);
         if (fuse < 1) fuse = 1;
     }
+    const bool single = ctx->total_slabs() == 1;
+    // Small grids (single slab, kernel = auto): the whole run is one launch with the grid resident
+    // in LDS (gs_run_resident_k).
+    if (single && ctx->o.kernel == GS_KERNEL_AUTO && u0->rows * u0->cols > 0 &&
+        u0->rows * u0->cols <= (uint64_t)kGsResidentCells && steps > 0) {
+        SlabRt &sl = ctx->slabs[0];
+        GS_HIP(hipSetDevice(sl.device));
+        GS_TRY(join_bands(ctx, sl.compute));
+        ctx->bands_active = false;
+        uint64_t left = steps;
+        int slot = 0;
+        while (left > 0) { // the step count is an int in the kernel
+            const int n = left > 0x40000000ull ? 0x40000000 : (int)left;
+            GsStepArgs a = make_args(ctx, r.u[slot], r.v[slot], r.u[1 - slot], r.v[1 - slot], 0, 1);
+            const char *name = nullptr;
+            const hipError_t e = ctx->o.math == GS_MATH_FUSED ? gs_launch_resident_fused(a, n, sl.compute, &name)
+                                                               : gs_launch_resident_strict(a, n, sl.compute, &name);
+            if (e != hipSuccess) return fail(GS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+            ctx->last_kernel = name;
+            ctx->launches++;
+            ctx->step_no += (uint64_t)n;
+            slot ^= n & 1;
+            left -= (uint64_t)n;
+        }
+        if (result_slot) *result_slot = slot;
+        return GS_OK;
+    }
     // The short pass (steps % fuse) goes first so that a run ends on a full-depth ghost exchange
     // and the next run can start without a blocking refresh.
     if (steps % (uint64_t)fuse) GS_TRY(r.advance(1, (int)(steps % (uint64_t)fuse)));
-    const bool single = ctx->total_slabs() == 1;
     if (single) recall_tuned(ctx, u0, fuse);
     if (single && fuse > 1 && ctx->o.rows_per_block == 0 && !tuned_shape(ctx, u0, fuse)) GS_TRY(tune_online(r, fuse));
     const int kk = single && tuned_shape(ctx, u0, fuse) && ctx->tuned_k > 0 ? ctx->tuned_k : fuse;

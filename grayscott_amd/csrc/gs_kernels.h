@@ -8,6 +8,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Largest grid (cells) gs_launch_resident_* takes: 4 planes x 4 B x cells = 64 KB of LDS.  Still 19 %
+// faster than the temporally blocked kernel there (profiles/r01_sweeps.md, run 118); at 8192 cells
+// (4 more cells per thread) it would not be.
+constexpr int kGsResidentCells = 4096;
+
 struct GsStepArgs {
     const float *in_u, *in_v; // local row 0, col 0 of the input planes
     float *out_u, *out_v;     // same for the output planes
@@ -43,6 +48,7 @@ struct GsStepArgs {
 #define GS_DECLARE_LAUNCHERS(SUFFIX)                                                           \
     hipError_t gs_launch_simple_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name); \
     hipError_t gs_launch_stream_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name); \
+    hipError_t gs_launch_resident_##SUFFIX(const GsStepArgs &a, int steps, hipStream_t s, const char **name); \
     hipError_t gs_launch_tb_##SUFFIX(const GsStepArgs &a, int k, hipStream_t s, const char **name); \
     hipError_t gs_launch_lds_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name);
 

@@ -295,6 +295,87 @@ __device__ __forceinline__ void cell(const GsStepArgs &a, const Row &m, const Ro
     react<(FAST & 2) != 0>(a, u, v, acc_u, acc_v, out_u, out_v);
 }
 
+#if !GS_TB_OP_ONLY
+// ------------------------------------------------------------------------------------
+// Small grids: the whole run in ONE launch, the grid resident in LDS.
+//
+// A grid of up to kResidentCells cells is loaded once by one 1024-thread workgroup, advanced
+// `steps` times LDS -> LDS with a barrier per step, and stored once.  For such grids a pass of the
+// kernels above is a dependent launch of a few microseconds per 1-4 steps and nothing else -- the
+// reference's criterion grid starts at 8 x 16 cells; here a step is one sweep of 4 waves per SIMD
+// over LDS.  Per-cell code = the general (edge) flavour of cell(): every thread builds its 3 x 3
+// window from LDS with clamped indices and passes per-thread presence flags / masks.
+// ------------------------------------------------------------------------------------
+constexpr int kResidentCells = kGsResidentCells;
+constexpr int kResidentThreads = 1024;
+
+struct Row3 { float u[3], v[3]; }; // [0] = column c-1, [1] = c, [2] = c+1
+
+__global__ __launch_bounds__(kResidentThreads) void GS_SUFFIX(gs_run_resident_k)(GsStepArgs a, int steps, int to_out)
+{
+    extern __shared__ float lds[];
+    const int cells = a.rows * a.cols, cols = a.cols;
+    float *pu[2] = {lds, lds + cells}, *pv[2] = {lds + 2 * cells, lds + 3 * cells};
+    constexpr int CPT = (kResidentCells + kResidentThreads - 1) / kResidentThreads; // cells per thread, at most
+    int idx[CPT], up[CPT], down[CPT], lt[CPT], rt[CPT], grow[CPT], gcol[CPT];
+    bool mrow[CPT], prow[CPT];
+    uint32_t la[CPT], ra[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        idx[k] = (int)threadIdx.x + k * kResidentThreads;
+        const bool live = idx[k] < cells;
+        const int r = live ? idx[k] / cols : 0, c = live ? idx[k] - r * cols : 0;
+        grow[k] = r;
+        gcol[k] = c;
+        mrow[k] = r > 0;                       // the row above / below exists
+        prow[k] = r + 1 < a.rows;
+        la[k] = c == 0 ? 0xffffffffu : 0u;     // the left / right neighbour column is absent
+        ra[k] = c + 1 >= cols ? 0xffffffffu : 0u;
+        up[k] = mrow[k] ? -cols : 0;           // clamped offsets: absent neighbours read a valid word
+        down[k] = prow[k] ? cols : 0;
+        lt[k] = c > 0 ? -1 : 0;
+        rt[k] = c + 1 < cols ? 1 : 0;
+        if (live) {
+            pu[0][idx[k]] = a.in_u[(ptrdiff_t)r * a.pitch + c];
+            pv[0][idx[k]] = a.in_v[(ptrdiff_t)r * a.pitch + c];
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int s = 0; s < steps; ++s) {
+        const float *iu = pu[cur], *iv = pv[cur];
+        float *ou = pu[cur ^ 1], *ov = pv[cur ^ 1];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            if (idx[k] >= cells) continue;
+            const int o = idx[k];
+            Row3 m, z, p;
+            const int rows3[3] = {o + up[k], o, o + down[k]};
+            Row3 *dst[3] = {&m, &z, &p};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                dst[i]->u[0] = iu[rows3[i] + lt[k]]; dst[i]->u[1] = iu[rows3[i]]; dst[i]->u[2] = iu[rows3[i] + rt[k]];
+                dst[i]->v[0] = iv[rows3[i] + lt[k]]; dst[i]->v[1] = iv[rows3[i]]; dst[i]->v[2] = iv[rows3[i] + rt[k]];
+            }
+            float nu, nv;
+            cell<true, 0, Row3>(a, m, z, p, 1, mrow[k], prow[k], la[k], ra[k], nu, nv);
+            ou[o] = nu;
+            ov[o] = nv;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    float *gu = to_out ? a.out_u : const_cast<float *>(a.in_u);
+    float *gv = to_out ? a.out_v : const_cast<float *>(a.in_v);
+#pragma unroll
+    for (int k = 0; k < CPT; ++k)
+        if (idx[k] < cells) {
+            gu[(ptrdiff_t)grow[k] * a.pitch + gcol[k]] = pu[cur][idx[k]];
+            gv[(ptrdiff_t)grow[k] * a.pitch + gcol[k]] = pv[cur][idx[k]];
+        }
+}
+#endif // !GS_TB_OP_ONLY
+
 template <int G, bool EDGE>
 __device__ __forceinline__ void march(const GsStepArgs &a, int ur0, int ur1, int c0, int lane)
 {
@@ -783,6 +864,21 @@ hipError_t GS_SUFFIX(gs_launch_simple)(const GsStepArgs &a, hipStream_t s, const
     void *kargs[] = {&args};
     return hipLaunchKernel(reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_simple_k)),
                            dim3((unsigned)blocks), dim3(256), kargs, 0, s);
+}
+
+// `steps` time steps of a grid of at most kResidentCells cells in one launch (gs_run_resident_k);
+// the result is stored in the out-planes when steps is odd, else back in the in-planes.
+hipError_t GS_SUFFIX(gs_launch_resident)(const GsStepArgs &a, int steps, hipStream_t s, const char **name)
+{
+    if (name) *name = "resident-lds/" GS_MATH_NAME;
+    const long cells = (long)a.rows * a.cols;
+    if (a.rows <= 0 || a.cols <= 0 || cells > kResidentCells || steps < 0 || a.top_present || a.bottom_present)
+        return hipErrorInvalidValue;
+    GsStepArgs args = a;
+    int to_out = steps & 1;
+    void *kargs[] = {&args, &steps, &to_out};
+    return hipLaunchKernel(reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_resident_k)), dim3(1), dim3(kResidentThreads),
+                           kargs, (size_t)cells * 4 * sizeof(float), s);
 }
 
 hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const char **name)

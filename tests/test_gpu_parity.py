@@ -250,6 +250,49 @@ def test_row_bands_on_a_large_grid(split):
 
 
 # ---- non-default parameters (CLI overrides -k -f -t, ui/src/lib.rs:51-63) and weights ------
+# ---- small grids: the whole run in one launch, LDS-resident ----------------------------------------
+@pytest.mark.parametrize("boundary", [capi.GS_BOUNDARY_CLIPPED, capi.GS_BOUNDARY_ZERO_HALO])
+def test_resident_kernel_small_grids(boundary):
+    """Grids of at most 4096 cells run gs_run as ONE launch (gs_run_resident_k); every shape class,
+    odd and even step counts (the result lands in the other slot), long runs, both boundary rules."""
+    for shape in [(1, 1), (1, 7), (7, 1), (2, 2), (3, 5), (8, 16), (16, 32), (17, 33), (32, 64), (64, 64), (1, 4096),
+                  (4096, 1), (5, 819)]:
+        u0, v0 = stress_fields(shape, 16)
+        for steps in (1, 2, 9, 256):
+            ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True, boundary=boundary)
+            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(boundary=boundary))
+            assert info[0].startswith("resident-lds/") and info[1] == 1, info      # one launch
+            assert_bits_equal(got_u, ref_u, f"resident U {shape} steps {steps}")
+            assert_bits_equal(got_v, ref_v, f"resident V {shape} steps {steps}")
+    # just above the limit the ordinary kernels take over
+    u0, v0 = stress_fields((64, 65), 16)
+    assert not gpu_run(u0, v0, 8, args=args(boundary=boundary))[2][0].startswith("resident")
+
+
+def test_resident_kernel_species_new_and_mixed_entry_points():
+    """Species::new on a 32 x 64 grid through 1000 steps in uneven calls, single steps in between
+    (gs_step uses the stream kernel), parameters changed on the way, fused flavour within tolerance."""
+    sim = Simulation.new(Parameters(), args())
+    species = sim.make_species([32, 64])
+    u, v = oracle.init_species(32, 64)
+    p = Parameters()
+    for steps in (1, 7, 256, 333, 403):
+        sim.perform_steps(species, steps)
+        sim.perform_step(species)
+        u, v = oracle.run(u, v, steps + 1, oracle_params(p), ftz=True)
+        iu, iv, _, _ = species.in_out()
+        assert_bits_equal(iu.make_scalar_view(sim.context), u, f"U after +{steps}+1")
+        assert_bits_equal(iv.make_scalar_view(sim.context), v, f"V after +{steps}+1")
+        p = Parameters(feed_rate=0.03, kill_rate=0.06, time_step=0.5) if steps == 7 else p
+        sim.context.set_params(p)
+    u0, v0 = stress_fields((40, 100), 17)
+    ref_u, ref_v = oracle.run(u0, v0, 50, ftz=True)
+    got_u, got_v, info = gpu_run(u0, v0, 50, args=args(math=capi.GS_MATH_FUSED))
+    assert info[0] == "resident-lds/fused"
+    assert np.max(np.abs(got_u - ref_u)) <= REL_TOL * np.max(np.abs(ref_u))
+    assert np.max(np.abs(got_v - ref_v)) <= REL_TOL * np.max(np.abs(ref_v))
+
+
 # ---- one context, several grids ------------------------------------------------------------------
 def test_alternating_shapes_on_one_context_keep_their_tuning():
     """The on-line choice is remembered per shape: going back to a grid does not tune again, and the
