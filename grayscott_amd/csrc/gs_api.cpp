@@ -682,9 +682,9 @@ int32_t tune_online(Run &r, int fuse)
 {
     gs_ctx *ctx = r.ctx;
     const gs_field *f = r.u[0];
-    static const int cand[] = {8, 12, 16, 24, 32, 48, 64, 96, 128, 192};
+    static const int cand[] = {2, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192};
     static const int altk[] = {3, 2};
-    static const int candn[] = {8, 16, 32, 64, 128};
+    static const int candn[] = {2, 4, 8, 16, 32, 64, 128};
     static const int cpls[] = {1, 4};
     const int ncand = (int)(sizeof cand / sizeof cand[0]);
     const int nalt = 0; // phase B is empty
@@ -728,7 +728,7 @@ int32_t tune_online(Run &r, int fuse)
         GS_HIP(hipEventRecord(ev, ts));
         return GS_OK;
     };
-    constexpr int kMaxBatch = 10;
+    constexpr int kMaxBatch = 16;
     if (ctx->tune_events.empty()) {
         ctx->tune_events.resize(3 * kMaxBatch, nullptr);
         for (auto &e : ctx->tune_events) GS_HIP(hipEventCreate(&e));
@@ -747,7 +747,9 @@ int32_t tune_online(Run &r, int fuse)
             const int i = ctx->tune_next - (phase ? phase_end[phase - 1] : 0);
             if (phase == 0) {
                 t.rpu = cand[i];
-                if (t.rpu < 2 * fuse || (uint64_t)t.rpu > f->rows) continue;
+                // units shorter than 2K rows recompute more rows than they produce: only worth it
+                // where a pass is latency-bound, i.e. on small grids
+                if ((t.rpu < 2 * fuse && cells > (1ull << 21)) || (uint64_t)t.rpu > f->rows) continue;
             } else if (phase == 2) {
                 t.rpu = ctx->tune_best_rpu;
                 t.V = ctx->tune_best_split;
@@ -758,7 +760,7 @@ int32_t tune_online(Run &r, int fuse)
                 t.rpu = candn[i % ncandn];
                 t.V = ctx->tune_best_split;
                 t.k = ctx->tune_best_k;
-                if (ctx->tune_best_rpu == 0 || t.rpu < 2 * t.k || (uint64_t)t.rpu > f->rows ||
+                if (ctx->tune_best_rpu == 0 || (t.rpu < 2 * t.k && cells > (1ull << 21)) || (uint64_t)t.rpu > f->rows ||
                     (large && (t.cpl == 1 || t.rpu < 32)))
                     continue;
             }
