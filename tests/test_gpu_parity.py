@@ -293,6 +293,40 @@ def test_resident_kernel_species_new_and_mixed_entry_points():
     assert np.max(np.abs(got_v - ref_v)) <= REL_TOL * np.max(np.abs(ref_v))
 
 
+def test_unusual_call_sequences():
+    """Zero steps, a fill_slice between runs, an overlapped download on the LDS-resident path, a very
+    long run on a tiny grid (the uniform state is a fixed point, so the answer is known)."""
+    from grayscott_amd import pinned_empty
+
+    for shape in ((24, 40), (96, 200)):                  # resident path / temporally blocked path
+        sim = Simulation.new(Parameters(), args())
+        species = sim.make_species(list(shape))
+        sim.perform_steps(species, 0)                    # no-op, result stays in the input slot
+        u, v = oracle.init_species(*shape)
+        assert_bits_equal(species.make_result_view(), v, f"V after 0 steps {shape}")
+        sim.perform_steps(species, 13)
+        u, v = oracle.run(u, v, 13)
+        in_u, in_v, _, _ = species.in_out()
+        in_v.fill_slice(sim.context, [range(2, 5), range(3, 9)], 0.75)          # edit the state, carry on
+        v[2:5, 3:9] = 0.75
+        img = pinned_empty(shape)
+        sim.perform_steps(species, 22)
+        species.write_result_view_after(img)             # overlapped with ...
+        sim.perform_steps(species, 5)                    # ... the next steps
+        sim.context.download_wait()
+        u, v = oracle.run(u, v, 22)
+        assert_bits_equal(np.array(img), v, f"async image {shape}")
+        u, v = oracle.run(u, v, 5)
+        assert_bits_equal(species.make_result_view(), v, f"V after the overlapped download {shape}")
+        sim.context.close()
+    sim = Simulation.new(Parameters(), args())
+    ones = np.ones((8, 16), np.float32)
+    species = species_from_arrays(sim, ones, np.zeros((8, 16), np.float32))
+    sim.perform_steps(species, 3_000_001)                # one launch, three million barriers
+    in_u, in_v, _, _ = species.in_out()
+    assert (in_u.make_scalar_view(sim.context) == 1).all() and (in_v.make_scalar_view(sim.context) == 0).all()
+
+
 # ---- one context, several grids ------------------------------------------------------------------
 def test_alternating_shapes_on_one_context_keep_their_tuning():
     """The on-line choice is remembered per shape: going back to a grid does not tune again, and the
