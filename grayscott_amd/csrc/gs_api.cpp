@@ -372,7 +372,9 @@ int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fu
     const long want = fuse > 1 ? 32L * fuse : 16;
     long rpu = ((long)rows * strips + 16383) / 16384; // keep >= 16384 waves per launch when possible
     if (rpu > want) rpu = want;
-    if (rpu < 2L * fuse) rpu = 2L * fuse;
+    // small grids are bound by the length of a wave's march: units of K rows there (runs 120-122)
+    const long least = (long)rows * cols <= (1L << 19) ? fuse : 2L * fuse;
+    if (rpu < least) rpu = least;
     if (rpu < 4) rpu = 4;
     return (int32_t)rpu;
 }
