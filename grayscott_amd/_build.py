@@ -65,16 +65,18 @@ def up_to_date() -> bool:
     return all(os.path.getmtime(s) <= t for s in _sources())
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP translation unit and link ``libgs_hip.so``; returns its path."""
-    if not force and up_to_date():
+def build(force: bool = False, verbose: bool = False, lib: str = LIB, build_dir: str = BUILD,
+          extra_flags=()) -> str:
+    """Compile every HIP translation unit and link ``libgs_hip.so``; returns its path.
+    ``lib`` / ``build_dir`` / ``extra_flags`` build a variant next to it (tools/ab_build.py)."""
+    if lib == LIB and not force and up_to_date():
         return LIB
-    os.makedirs(BUILD, exist_ok=True)
+    os.makedirs(build_dir, exist_ok=True)
     cc = hipcc()
     procs = []
     for src, obj, extra in UNITS:
-        flags = list(COMMON) + (EXTRA if src.endswith(".hip") else [])
-        cmd = [cc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(BUILD, obj)]
+        flags = list(COMMON) + ((EXTRA + list(extra_flags)) if src.endswith(".hip") else [])
+        cmd = [cc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(build_dir, obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -84,12 +86,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
         if verbose and out:
             sys.stderr.write(out.decode(errors="replace"))
-    objs = [os.path.join(BUILD, obj) for _, obj, _ in UNITS]
-    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    objs = [os.path.join(build_dir, obj) for _, obj, _ in UNITS]
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stdout.decode(errors="replace")))
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -10,7 +10,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgs_hip.so")
+# GS_HIP_LIBRARY names another build of the same ABI (A/B timing of kernel variants, tools/ab_build.py);
+# it is loaded instead of, never as a fallback for, the in-tree library.
+LIB_PATH = os.environ.get("GS_HIP_LIBRARY") or os.path.join(_HERE, "libgs_hip.so")
 
 GS_OK = 0
 GS_ERR_INVALID = -1

@@ -160,18 +160,27 @@ struct gs_ctx {
     ncclComm_t comm = nullptr;
     const char *last_kernel = "none";
     uint64_t launches = 0;
-    // rows-per-unit tuned on line for (rows, cols, fuse) of the last single-slab gs_run
+    // Configuration of the temporally blocked kernel in force (tuned_rpu > 0): unit height, fused steps
+    // per pass and columns per lane for slabs of tuned_rows x tuned_cols -- chosen by gs_run's on-line
+    // tuner (single-slab contexts) or handed in through gs_ctx_set_tuned (slab chains).
     uint64_t tuned_rows = 0, tuned_cols = 0;
     int tuned_fuse = 0, tuned_rpu = 0, tuned_split = 0, tuned_k = 0; // tuned_k: fused steps per pass chosen
     int tuned_cpl = 0;                                               // columns per lane chosen
-    // earlier choices for other shapes (a context that alternates between grids does not re-tune)
+    // every finished choice (a context that alternates between grids does not re-tune)
     struct Tuned { uint64_t rows, cols; int fuse, rpu, split, k, cpl; };
     std::vector<Tuned> tuned_cache;
-    // tuning in progress (may span several gs_run calls): next candidate, best so far
-    uint64_t tune_rows = 0, tune_cols = 0;
-    int tune_fuse = 0, tune_next = 0, tune_best_rpu = 0, tune_best_split = 0, tune_best_k = 0, tune_best_cpl = 0;
-    float tune_best_ms = 0.f;
-    std::vector<hipEvent_t> tune_events; // timing windows of one tuning phase (created on first use)
+    // Tunings in progress, one per shape (each may span several gs_run calls; two grids driven
+    // alternately advance independently).  `batch` / `nb`: timing windows enqueued but not read yet.
+    struct Trial { int rpu, V, k, cpl, reps; };
+    struct Tuning {
+        uint64_t rows = 0, cols = 0;
+        int fuse = 0, next = 0, best_rpu = 0, best_split = 0, best_k = 0, best_cpl = 0;
+        float best_ms = 0.f;
+        Trial batch[16];
+        int nb = 0;
+        std::vector<hipEvent_t> events; // 3 per window (created on first use)
+    };
+    std::vector<Tuning> tunings;
     // gs_options.use_graph: a batch of passes captured once and replayed (single slab, no bands).
     // The captured launches carry plane addresses and parameters, so the key holds all of them.
     struct GraphKey {
@@ -345,10 +354,12 @@ long tb_strips(int32_t cols, int fuse, int cpl)
     return (cols + w - 1) / w;
 }
 
+// `rows` = rows of one slab.  Slabs of an uneven partition differ by one row: same configuration.
 bool tuned_for(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse)
 {
-    return ctx->tuned_rpu > 0 && ctx->tuned_k == fuse && ctx->tuned_rows == (uint64_t)rows &&
-           ctx->tuned_cols == (uint64_t)cols && ctx->total_slabs() == 1;
+    const uint64_t r = (uint64_t)rows;
+    return ctx->tuned_rpu > 0 && ctx->tuned_k == fuse && ctx->tuned_cols == (uint64_t)cols &&
+           (ctx->tuned_rows == r || (ctx->total_slabs() > 1 && (ctx->tuned_rows == r + 1 || ctx->tuned_rows + 1 == r)));
 }
 
 // Columns per lane of the temporally blocked kernel when nothing was tuned on line: 2 (measured
@@ -651,21 +662,35 @@ struct Run {
     }
 };
 
+// Rows of the slabs of `f` as the tuning tables key them (the first local slab's; the others differ by
+// at most one row).
+uint64_t slab_rows_of(const gs_field *f) { return f->s.empty() ? f->rows : (uint64_t)f->s.front().rows; }
+
 bool tuned_shape(const gs_ctx *ctx, const gs_field *f, int fuse)
 {
-    return ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse && ctx->tuned_rows == f->rows && ctx->tuned_cols == f->cols;
+    return ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse && ctx->tuned_rows == slab_rows_of(f) && ctx->tuned_cols == f->cols;
 }
 
 // Make the remembered choice for this shape (if any) the active one.
 void recall_tuned(gs_ctx *ctx, const gs_field *f, int fuse)
 {
     if (tuned_shape(ctx, f, fuse)) return;
+    const uint64_t rows = slab_rows_of(f);
     for (const gs_ctx::Tuned &t : ctx->tuned_cache)
-        if (t.rows == f->rows && t.cols == f->cols && t.fuse == fuse) {
+        if (t.rows == rows && t.cols == f->cols && t.fuse == fuse) {
             ctx->tuned_rows = t.rows; ctx->tuned_cols = t.cols; ctx->tuned_fuse = t.fuse;
             ctx->tuned_rpu = t.rpu; ctx->tuned_split = t.split; ctx->tuned_k = t.k; ctx->tuned_cpl = t.cpl;
             return;
         }
+}
+
+void remember_tuned(gs_ctx *ctx, const gs_ctx::Tuned &t)
+{
+    for (auto it = ctx->tuned_cache.begin(); it != ctx->tuned_cache.end(); ++it)
+        if (it->rows == t.rows && it->cols == t.cols && it->fuse == t.fuse) { ctx->tuned_cache.erase(it); break; }
+    if (ctx->tuned_cache.size() >= 64) ctx->tuned_cache.erase(ctx->tuned_cache.begin());
+    ctx->tuned_cache.push_back(t);
+    if (ctx->tuned_rows == t.rows && ctx->tuned_cols == t.cols && ctx->tuned_fuse == t.fuse) ctx->tuned_rpu = 0; // re-recall
 }
 
 // On-line choice of unit height, fused steps per pass and columns per lane (single slab, fused

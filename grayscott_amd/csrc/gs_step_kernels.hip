@@ -523,9 +523,29 @@ struct RowT { // [0] = column c-1, [1..CPL] = own columns, [CPL+1] = column c+CP
     float u[CPL + 2], v[CPL + 2];
 };
 
-// Same shifts for the temporally blocked kernel, whose outermost lanes are sacrificial: they may
-// receive anything, so the DPP move runs with bound_ctrl (0 for the lane without a source) and
-// needs no `old` operand -- one v_mov per shift less than from_prev_lane / from_next_lane.
+// Neighbour-lane reads of the temporally blocked kernel, whose outermost lanes are sacrificial (they
+// may receive anything).  Measured on MI355X (tools/ubench/valu_rate2.hip, profiles/r02_sweeps.md): a
+// DPP instruction issues at half the VALU rate and, mixed into ordinary VALU code, costs the wave 3-5
+// issue slots; ds_bpermute_b32 goes through the LDS crossbar (no LDS memory, ~6 cycles per CU and
+// wave-instruction) and takes no VALU slot at all.  At 4 exchanges per row and level the crossbar is
+// ~40 % busy, so the exchange is free: +7 % at 16384^2 over the DPP form (GS_TB_XLANE=0, kept for A/B).
+#ifndef GS_TB_XLANE
+#define GS_TB_XLANE 1
+#endif
+#if GS_TB_XLANE
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// lane i receives lane i-1's `own` (lane 0: lane 63's)
+__device__ __forceinline__ float shift_from_prev_lane(float own)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane_id() - 1) & 63) << 2, __builtin_bit_cast(int, own)));
+}
+// lane i receives lane i+1's `own` (lane 63: lane 0's)
+__device__ __forceinline__ float shift_from_next_lane(float own)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane_id() + 1) & 63) << 2, __builtin_bit_cast(int, own)));
+}
+#else
+// DPP wave shifts with bound_ctrl (0 for the lane without a source), no `old` operand.
 __device__ __forceinline__ float shift_from_prev_lane(float own)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own), 0x138, 0xf, 0xf, true));
@@ -534,6 +554,7 @@ __device__ __forceinline__ float shift_from_next_lane(float own)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own), 0x130, 0xf, 0xf, true));
 }
+#endif
 
 template <int CPL>
 __device__ __forceinline__ RowT<CPL> widen_tb(const float (&u)[CPL], const float (&v)[CPL])

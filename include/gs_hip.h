@@ -23,7 +23,10 @@
  *   - Calls on one gs_ctx must be externally serialised (the reference takes
  *     `&mut Species` in perform_steps); a context may be moved between threads: every
  *     entry point selects its own device(s).
- *   - gs_step / gs_run only enqueue work; gs_sync (or a download) waits for it.
+ *   - gs_step / gs_run only enqueue work; gs_sync (or a download) waits for it.  A host-side
+ *     Simulate::perform_steps is gs_run + gs_sync (every backend of the reference returns from
+ *     perform_steps with the steps done: compute/shared/src/gpu/mod.rs:77-91); gs_run alone is
+ *     the asynchronous SimulateGpu::prepare_steps (:70-75).
  *   - Shapes are [rows, cols] in scalar units, as in Concentration::shape()
  *     (data/src/concentration/mod.rs:191-221).  Storage is row-major f32 (`Precision`,
  *     data/src/lib.rs:11).
@@ -48,7 +51,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 1
+#define GS_ABI_VERSION 2
 
 typedef enum gs_status {
     GS_OK = 0,
@@ -123,7 +126,10 @@ typedef struct gs_options {
                               * large grids), 2 or 1 (more, narrower waves for small grids);   *
                               * 0 = chosen on line by gs_run                                   */
     int32_t boundary;        /* gs_boundary; default CLIPPED                                     */
-    int32_t reserved[6];
+    int32_t no_tune;         /* 1 = gs_run never times candidate configurations: it runs the pinned *
+                              * values above, a configuration set with gs_ctx_set_tuned, or the     *
+                              * untuned defaults                                                   */
+    int32_t reserved[5];
 } gs_options;
 
 typedef struct gs_ctx gs_ctx;     /* devices, streams, row partition, RCCL communicator    */

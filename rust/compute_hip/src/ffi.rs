@@ -1,4 +1,4 @@
-//! `extern "C"` view of include/gs_hip.h (ABI version 1).  Field order and widths must match
+//! `extern "C"` view of include/gs_hip.h (ABI version 2).  Field order and widths must match
 //! the header exactly; `tests/test_capi_cpu.py::test_struct_layouts` pins the C side.
 #![allow(non_camel_case_types)]
 
@@ -31,7 +31,8 @@ pub struct gs_options {
     pub general_kernels: i32,
     pub cols_per_lane: i32,
     pub boundary: i32,
-    pub reserved: [i32; 6],
+    pub no_tune: i32,
+    pub reserved: [i32; 5],
 }
 
 #[repr(C)]
@@ -91,4 +92,6 @@ extern "C" {
         result_slot: *mut i32,
     ) -> i32;
     pub fn gs_sync(ctx: *mut gs_ctx) -> i32;
+    pub fn gs_field_download_async(ctx: *mut gs_ctx, f: *mut gs_field, host: *mut f32) -> i32;
+    pub fn gs_download_wait(ctx: *mut gs_ctx) -> i32;
 }

@@ -1,10 +1,17 @@
 //! MI355X (gfx950) HIP implementation of Gray-Scott simulation
 //!
 //! Thin shim over libgs_hip.so (hand-written HIP kernels behind a C ABI).  Storage lives in
-//! HBM as plain row-major f32 planes; `perform_steps` enqueues all steps asynchronously with
-//! one `gs_run` call (the Vulkan backends batch the same way: one command buffer for N steps,
-//! compute/gpu/naive/src/lib.rs:99-131).  Results match `compute_naive` bit
-//! for bit (clipped-window boundary rule, FTZ-without-DAZ denormal handling).
+//! HBM as plain row-major f32 planes.  As in the Vulkan backends (compute/shared/src/gpu/mod.rs:
+//! 70-91) there are two forms of the step call: `prepare_steps` enqueues all steps with one
+//! asynchronous `gs_run` (the Vulkan backends batch the same way: one command buffer for N steps,
+//! compute/gpu/naive/src/lib.rs:99-131) and `Simulate::perform_steps` is that plus a wait, so the
+//! reference's criterion "compute" workload (compute/shared/src/benchmark.rs:77-83) times finished
+//! steps.  Results match `compute_naive` bit for bit (clipped-window boundary rule,
+//! FTZ-without-DAZ denormal handling).
+//!
+//! `HipContext` is an `Rc`, so `Species<HipConcentration>` is `!Send`: fine for `simulate`, whose
+//! compute stays on the main thread (simulate/src/main.rs:73-121); `HipError` is `Send + Sync`
+//! as `SimulateBase::Error` requires.
 
 mod ffi;
 
@@ -42,17 +49,30 @@ fn check(code: i32) -> Result<(), HipError> {
 /// compute/shared/src/lib.rs:20-25 requires)
 #[derive(Args, Clone, Debug)]
 pub struct HipArgs {
-    /// HIP device that runs the simulation
-    #[arg(long, env = "GS_HIP_DEVICE", default_value_t = 0)]
-    pub hip_device: i32,
+    /// HIP devices that run the simulation, one row slab each, top to bottom (ids may repeat)
+    #[arg(long, env = "GS_HIP_DEVICES", value_delimiter = ',', default_value = "0")]
+    pub hip_devices: Vec<i32>,
 
     /// Arithmetic flavour: 0 = strict (bit-identical to compute_naive), 1 = fused taps
     #[arg(long, env = "GS_HIP_MATH", default_value_t = 0)]
     pub hip_math: i32,
 
-    /// Rows each wavefront marches over (0 = automatic)
+    /// Rows each wavefront marches over (0 = chosen on line)
     #[arg(long, env = "GS_HIP_ROWS_PER_BLOCK", default_value_t = 0)]
     pub hip_rows_per_block: i32,
+
+    /// Time steps fused per pass over HBM, 1..4 (0 = chosen on line)
+    #[arg(long, env = "GS_HIP_FUSE_STEPS", default_value_t = 0)]
+    pub hip_fuse_steps: i32,
+
+    /// Columns per lane of the temporally blocked kernel: 4, 2 or 1 (0 = chosen on line)
+    #[arg(long, env = "GS_HIP_COLS_PER_LANE", default_value_t = 0)]
+    pub hip_cols_per_lane: i32,
+
+    /// 1 = never time candidate configurations inside perform_steps (untuned defaults, or the
+    /// three pinned values above)
+    #[arg(long, env = "GS_HIP_NO_TUNE", default_value_t = 0)]
+    pub hip_no_tune: i32,
 }
 
 /// Owner of the `gs_ctx` (devices, streams); shared by the simulation and its species
@@ -193,18 +213,38 @@ impl SimulateCreate for Simulation {
         unsafe { ffi::gs_default_options(&mut opts) };
         opts.math = args.hip_math;
         opts.rows_per_block = args.hip_rows_per_block;
+        opts.fuse_steps = args.hip_fuse_steps;
+        opts.cols_per_lane = args.hip_cols_per_lane;
+        opts.no_tune = args.hip_no_tune;
         let mut ctx = ptr::null_mut();
+        // one process, `hip_devices.len()` row slabs with ghost-row exchange by peer copies
         check(unsafe {
-            ffi::gs_ctx_create(&mut ctx, &c_params, &opts, &args.hip_device, 1, 0, 1, ptr::null())
+            ffi::gs_ctx_create(
+                &mut ctx, &c_params, &opts, args.hip_devices.as_ptr(), args.hip_devices.len() as i32, 0, 1,
+                ptr::null(),
+            )
         })?;
         Ok(Self { context: Rc::new(HipContextInner(ctx)) })
     }
 }
 //
 impl Simulate for Simulation {
+    /// Synchronous, like every backend of the reference: the Vulkan ones end `perform_steps_impl`
+    /// with `.then_signal_fence_and_flush()?.wait(None)?` (compute/shared/src/gpu/mod.rs:77-91).
     fn perform_steps(&self, species: &mut Species<HipConcentration>, steps: usize) -> Result<(), HipError> {
-        // One call enqueues every step: the library ping-pongs between the two slots and fuses up
-        // to 4 time steps per pass over HBM (temporal blocking); nothing blocks here.
+        self.prepare_steps(species, steps)?;
+        // SAFETY: plain FFI call on a live context
+        check(unsafe { ffi::gs_sync(self.context.0) })
+    }
+}
+
+impl Simulation {
+    /// Asynchronous form, the counterpart of `SimulateGpu::prepare_steps`
+    /// (compute/shared/src/gpu/mod.rs:70-75): one call enqueues every step -- the library ping-pongs
+    /// between the two slots and fuses up to 4 time steps per pass over HBM -- and returns.  HIP
+    /// streams order the work, so there is no future to thread through: whatever is enqueued next
+    /// on this context (more steps, `write_scalar_view_after`) runs behind it.
+    pub fn prepare_steps(&self, species: &mut Species<HipConcentration>, steps: usize) -> Result<(), HipError> {
         let mut slot = 0i32;
         {
             let (in_u, in_v, out_u, out_v) = species.in_out();
@@ -220,13 +260,36 @@ impl Simulate for Simulation {
         }
         Ok(())
     }
-}
 
-impl Simulation {
     /// `SimulateStep`-style single step (compute/shared/src/cpu.rs:21-28): enqueue, then flip
     pub fn perform_step(&self, species: &mut Species<HipConcentration>) -> Result<(), HipError> {
         let (in_u, in_v, out_u, out_v) = species.in_out();
         check(unsafe { ffi::gs_step(self.context.0, in_u.field, in_v.field, out_u.field, out_v.field) })?;
         species.flip()
+    }
+
+    /// Wait for the downloads enqueued by `write_scalar_view_after` (not for later steps)
+    pub fn download_wait(&self) -> Result<(), HipError> {
+        check(unsafe { ffi::gs_download_wait(self.context.0) })
+    }
+}
+
+impl HipConcentration {
+    /// Counterpart of `ImageConcentration::write_scalar_view_after`
+    /// (data/src/concentration/gpu/image/mod.rs:196-206), used with `prepare_steps` by a driver loop
+    /// like simulate/src/main.rs:99-106: enqueue the download of this plane behind the steps already
+    /// enqueued and return at once.
+    ///
+    /// # Safety
+    /// `target` must be dense row-major and must stay alive and untouched until
+    /// `Simulation::download_wait` (or any synchronous call on the context) has returned.
+    pub unsafe fn write_scalar_view_after(
+        &mut self,
+        context: &mut HipContext,
+        mut target: ArrayViewMut2<Precision>,
+    ) -> Result<(), HipError> {
+        Self::validate_write(self, &target);
+        let slice = target.as_slice_mut().expect("write_scalar_view_after needs a dense row-major target");
+        check(ffi::gs_field_download_async(context.0, self.field, slice.as_mut_ptr()))
     }
 }
