@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the Gray-Scott step path on MI355X (contract: see the task statement).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--grid RxC]
 
 One "step" = one simulation time step of the whole grid (the reference's own throughput
 unit is cells x steps, compute/shared/src/benchmark.rs:55-59; its "compute" workload is
 perform_steps only, :77-83).  Inputs are resident in HBM before the timed region starts.
 
 N = 1 : BASELINE.json's headline workload, 16384 x 16384 f32 (config 3), Species::new init,
-        default feed/kill.  Rank 0 also times the CPU port of the reference's
-        parallel(block(autovec)) backend on the host cores on a bounded sample.
-N > 1 : launched by torchrun, one process per GPU; weak scaling with 2^28 cells per GPU:
-        rows = 16384 * N over 16384 columns (N = 8: 65536 x 32768, BASELINE config 5), row
-        slabs with ghost-row exchange through RCCL send/recv inside libgs_hip.so.
+        default feed/kill.  Rank 0 also times the same kernel on a developed spot pattern, the
+        fused-tap flavour, and the CPU ports on the host cores on a bounded sample.
+N > 1 : launched by torchrun, one process per GPU, row slabs with ghost-row exchange through RCCL
+        send/recv inside libgs_hip.so.
+        --scaling weak (default): 2^28 cells per GPU -- rows = 16384 * N over 16384 columns
+            (N = 2: 32768 x 16384, BASELINE config 4; N = 8: 65536 x 32768, config 5);
+        --scaling strong: one grid for every N -- 32768 x 16384 (config 4 "across 2 then 4") for
+            N <= 4, 65536 x 32768 (config 5) for N = 8; --grid overrides it.
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,12 +33,20 @@ sys.path.insert(0, ROOT)
 BYTES_PER_CELL_STEP = 16          # read U,V + write U,V, 4 B each
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip table)
 HBM_COPY_CEILING_GBS = 6290.0     # measured float4-copy ceiling, same table
+# VALU issue roof for plain f32 ops: 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz (half the
+# 157.3 TFLOP/s FMA peak of the same table: the strict kernel issues no FMA)
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+# arithmetic the reference's update needs per cell-step when each op is one instruction (taps:
+# 4 corners x (sub, mul, add) + 4 sides x (sub with div:2, add), two species; reaction: 13)
+USEFUL_VALU_PER_CELL_STEP = 53
 
 
-def grid_for(n_gpus: int):
+def grid_for(n_gpus: int, scaling: str):
+    if scaling == "strong":
+        return (65536, 32768) if n_gpus > 4 else (32768, 16384)   # BASELINE configs 5 / 4
     if n_gpus == 8:
         return 65536, 32768       # BASELINE config 5
-    return 16384 * n_gpus, 16384  # config 3 (N=1), config 4 shape (N=2), same cells per GPU
+    return 16384 * n_gpus, 16384  # config 3 (N=1), config 4 (N=2), same cells per GPU
 
 
 def usable_cpus() -> int:
@@ -59,9 +70,14 @@ def usable_cpus() -> int:
     return n
 
 
-def cpu_baseline(target_seconds: float = 15.0):
-    """Times the CPU port (oracle/gs_cpu_parallel.c) of the reference's parallel backend on a
-    bounded sample of the SAME workload: 16384 x 16384, Species::new init, a few steps."""
+def cpu_baseline(target_seconds: float = 12.0):
+    """Times the CPU side on a bounded sample of the SAME workload (16384 x 16384, Species::new
+    init, a few steps) on every core this process may use: the port of the reference's
+    parallel(block(autovec)) backend (oracle/gs_cpu_parallel.c) -- the reported baseline -- and
+    the strict restatement of its naive backend (oracle/gs_oracle.c, OpenMP over rows) beside it."""
+    import numpy as np
+
+    import oracle
     from oracle import cpu_parallel
 
     rows, cols = 16384, 16384
@@ -83,21 +99,63 @@ def cpu_baseline(target_seconds: float = 15.0):
         "sample": f"{rows}x{cols} f32, Species::new init, {n} steps of the parallel(block(autovec)) "
                   f"port (oracle/gs_cpu_parallel.c), SIMD width {cpu_parallel.simd_width()}, FTZ on, "
                   f"L1/L2 block {sim.l1_block_size}/{sim.l2_block_size} B, {dt:.1f} s",
+        "logical_cpus": os.cpu_count(),
     }
     sim.close()
+    # the strict naive restatement (the parity oracle) on the same cores, a few steps
+    u, v = oracle.init_species(rows, cols)
+    t0 = time.perf_counter()
+    u, v = oracle.run(u, v, 1, ftz=True, nthreads=threads)
+    one = time.perf_counter() - t0
+    m = max(1, min(20, int(6.0 / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    oracle.run(u, v, m, ftz=True, nthreads=threads)
+    dt = time.perf_counter() - t0
+    info["naive"] = {"value": rows * cols * m / dt / 1e6, "unit": "Mcells×steps/s", "cores": threads,
+                     "sample": f"{m} steps of the strict naive restatement (oracle/gs_oracle.c), {dt:.1f} s"}
+    del u, v, np
     return info
 
 
-def measured_traffic(kernel_name: str):
-    """HBM bytes per launch from rocprofv3 PMC passes (profiles/traffic.json, written by
-    tools/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE runs); None if absent."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def measured_counters(kernel_name: str):
+    """Per-launch PMC figures of the committed rocprofv3 profile of this kernel at 2^28 cells per GPU
+    (profiles/counters.json, written by tools/summarize_profile.py from separate --pmc passes):
+    {"traffic": HBM bytes, "valu_insts": SQ_INSTS_VALU wave-instructions, "source": ...}; {} if absent."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
     try:
         with open(path) as f:
             data = json.load(f)
-        return data.get(kernel_name.split("@")[0])   # None for a configuration that was not profiled
+        return data.get(kernel_name.split("@")[0]) or {}
     except (OSError, ValueError):
-        return None
+        return {}
+
+
+def developed_species(sim, rows, cols, develop_steps=4000):
+    """A pattern-forming state instead of the reference's benchmark input: U = 1, V = 0 with one
+    12 x 12 seed (U = 0.5, V = 0.25) per 40 000 cells and 1 % noise, advanced `develop_steps` steps
+    (tools/pattern_rate.py, profiles/r01_soak.md: spots replicate until they fill the grid)."""
+    import numpy as np
+
+    from grayscott_amd import Evolving, HipConcentration, Species
+
+    rng = np.random.default_rng(2024)
+    u0 = np.ones((rows, cols), np.float32)
+    v0 = np.zeros((rows, cols), np.float32)
+    for _ in range(max(4, rows * cols // 40000)):
+        r, c = int(rng.integers(0, max(1, rows - 12))), int(rng.integers(0, max(1, cols - 12)))
+        u0[r:r + 12, c:c + 12] = 0.5
+        v0[r:r + 12, c:c + 12] = 0.25
+    u0 += rng.random(u0.shape, dtype=np.float32) * np.float32(0.01)
+    v0 += rng.random(v0.shape, dtype=np.float32) * np.float32(0.01)
+    ctx = sim.context
+    u = Evolving([HipConcentration(ctx, u0.shape), HipConcentration(ctx, u0.shape)])
+    v = Evolving([HipConcentration(ctx, u0.shape), HipConcentration(ctx, u0.shape)])
+    u.in_out()[0].upload(ctx, u0)
+    v.in_out()[0].upload(ctx, v0)
+    del u0, v0
+    species = Species(ctx, u, v)
+    sim.perform_steps(species, develop_steps)
+    return species
 
 
 def main() -> int:
@@ -105,10 +163,13 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--grid", default="", help="ROWSxCOLS: override the grid of the chosen scaling mode")
     ap.add_argument("--rows", type=int, default=0, help="override the grid (diagnostics only)")
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the informational fused-flavour leg")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the informational legs (fused flavour, developed pattern)")
     ap.add_argument("--rehearsal", action="store_true",
                     help="N > 1 on a 1-GPU box: all ranks share GPU 0 and torch.distributed uses gloo; needs "
                          "GS_RCCL_LIBRARY to name a transport that accepts several ranks per device "
@@ -119,6 +180,7 @@ def main() -> int:
     import torch.distributed as dist
 
     from grayscott_amd import HipArgs, Parameters, Simulation, capi
+    from grayscott_amd import dist as gsd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +216,9 @@ def main() -> int:
         dist.broadcast(buf, src=0)
         unique_id = bytes(buf.cpu().numpy().tobytes())
 
-    rows, cols = grid_for(args.gpus)
+    rows, cols = grid_for(args.gpus, args.scaling)
+    if args.grid:
+        rows, cols = (int(x) for x in args.grid.lower().split("x"))
     if args.rows and args.cols:
         rows, cols = args.rows, args.cols
     # The library's defaults, nothing pinned: one kernel launch per pass, so "launch" in the roofline
@@ -162,70 +226,127 @@ def main() -> int:
     hip_args = HipArgs(devices=[local_rank], rank=rank, world=world, unique_id=unique_id)
     sim = Simulation.new(Parameters(), hip_args)
     ctx = sim.context
+    tuned = (0, 0, 0)
     if world == 1:
         # gs_run chooses unit height / fused steps / columns per lane on line, from timed passes of
         # the simulation itself (per context and shape).  Let it finish on a scratch set of planes,
         # so that neither the W warm-up steps nor the K timed ones contain tuning passes whatever
-        # W and K are.  (Multi-process contexts do not tune.)
+        # W and K are.
         scratch = sim.make_species([rows, cols])
-        sim.perform_steps(scratch, 400)
-        ctx.sync()
+        for _ in range(8):
+            sim.perform_steps(scratch, 400)
+            tuned = ctx.get_tuned(rows, cols)
+            if tuned[0] > 0:
+                break
         del scratch
+    else:
+        # A slab chain does not tune on line: rank 0 tunes on a throw-away single slab of the slab's
+        # shape and every rank is handed the same configuration (grayscott_amd/dist.py).
+        tuned = gsd.share_tuning(sim, rows // world, cols, rank, world, device=red_dev, local_device=local_rank)
     species = sim.make_species([rows, cols])        # Species::new on the device, HBM-resident
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    def timed_run(sp, steps):
+        """(wall seconds, HIP-event ms, kernel launches) of `steps` steps bracketed as the contract says."""
+        ctx.sync()
+        barrier()
+        torch.cuda.synchronize()
+        _, n0 = ctx.info()
+        t0 = time.perf_counter()
+        ctx.timer_start()                               # HIP events on the library's own stream
+        sim.prepare_steps(sp, steps)
+        ms = ctx.timer_stop()
+        _, n1 = ctx.info()
+        ctx.sync()
+        torch.cuda.synchronize()
+        barrier()
+        return time.perf_counter() - t0, ms, n1 - n0
+
     sim.perform_steps(species, args.warmup)
-    ctx.sync()
-    barrier()
-    torch.cuda.synchronize()
-    _, launches0 = ctx.info()
-    t0 = time.perf_counter()
-    ctx.timer_start()                               # HIP events on the library's own stream
-    sim.perform_steps(species, args.steps)
-    event_ms = ctx.timer_stop()
-    _, launches1 = ctx.info()
-    ctx.sync()
-    torch.cuda.synchronize()
-    barrier()
-    wall = time.perf_counter() - t0
+    wall, event_ms, launches = timed_run(species, args.steps)
 
     if world > 1:
         t = torch.tensor([wall, event_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, event_ms = float(t[0]), float(t[1])
+        # what RCCL itself says about the communicator, and where every rank runs
+        mine = torch.tensor(list(ctx.comm_info()) + [local_rank], dtype=torch.int32, device=red_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        comm = [[int(x) for x in r.cpu()] for r in allr]
+    else:
+        comm = []
 
     kernel_name, _ = ctx.info()
     cells = rows * cols
     value = cells * args.steps / wall / 1e6
-    # roofline of the dominant kernel: algorithmic bytes per launch / average launch duration.
-    # One pass = one launch of the step kernel over one GPU's slab (plus, on a slab chain, the
-    # small boundary-band launch); it advances `steps / passes` time steps (temporal blocking).
-    launches = launches1 - launches0
+    # The dominant kernel: one launch of the step kernel per pass over one GPU's slab (plus, on a slab
+    # chain, the small boundary-band launch); a pass advances `steps / passes` time steps (temporal
+    # blocking).
     passes = launches if args.gpus == 1 else launches // 2
-    extra = None
+    extra, developed = None, None
     if args.gpus == 1 and not args.no_extra:
+        # informational: the same kernel, same context, on a developed spot pattern (the chip sustains
+        # a lower clock on non-trivial operands; BASELINE.md asks for "random/real data not zeros")
+        sp_dev = developed_species(sim, rows, cols)
+        w_dev, _, _ = timed_run(sp_dev, args.steps)
+        developed = cells * args.steps / w_dev / 1e6
+        del sp_dev
         # informational: the fused-tap flavour (GS_MATH_FUSED: bit-identical wherever no sub-normal
         # intermediate occurs, |diff| <= 1e-37 elsewhere -- inside north_star's 1e-5 tolerance)
         sim_c = Simulation.new(Parameters(), HipArgs(devices=[local_rank], math=capi.GS_MATH_FUSED))
         species_c = sim_c.make_species([rows, cols])
         sim_c.perform_steps(species_c, max(args.warmup, 400))
-        sim_c.context.sync()
         tc = time.perf_counter()
         sim_c.perform_steps(species_c, args.steps)
-        sim_c.context.sync()
         tc = time.perf_counter() - tc
         extra = {"kernel": sim_c.context.info()[0], "value": rows * cols * args.steps / tc / 1e6}
         sim_c.context.close()
         del species_c, sim_c
-    launch_ms = event_ms / passes
-    per_launch_bytes = BYTES_PER_CELL_STEP * (cells / args.gpus) * args.steps / passes
-    achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9
+    launch_s = event_ms * 1e-3 / passes
+    steps_per_launch = args.steps / passes
+    cells_per_gpu = cells / args.gpus
+    algo_bytes = BYTES_PER_CELL_STEP * cells_per_gpu * steps_per_launch
+    algo_gbs = algo_bytes / launch_s / 1e9
+    pmc = measured_counters(kernel_name) if cells // args.gpus == 16384 * 16384 else {}
+    traffic, valu_insts = pmc.get("traffic"), pmc.get("valu_insts")
+    hbm_physical = traffic / launch_s / 1e9 / HBM_PEAK_GBS if traffic else None
+    valu_rate = valu_insts * 64 / launch_s / 1e12 if valu_insts else None
+    useful_rate = USEFUL_VALU_PER_CELL_STEP * cells_per_gpu * steps_per_launch / launch_s / 1e12
+    # Which roof binds: with K >= 3 steps fused per HBM pass the kernel moves ~16 B per cell for K
+    # steps and is bound by VALU issue; a single-step pass is bound by HBM.
+    valu_bound = steps_per_launch >= 3
+    roofline = {
+        "bound": "valu-issue" if valu_bound else "hbm",
+        # the binding roof: issued VALU lane-instructions (PMC SQ_INSTS_VALU x 64, committed profile)
+        # per launch time against the chip's plain-f32 issue rate; HBM bytes (PMC) against 8 TB/s
+        "achieved": (valu_rate if valu_bound else (traffic / launch_s / 1e9 if traffic else algo_gbs)),
+        "peak": VALU_PEAK_TLANEOPS if valu_bound else HBM_PEAK_GBS,
+        "unit": "T lane-ops/s" if valu_bound else "GB/s",
+        "frac": ((valu_rate / VALU_PEAK_TLANEOPS if valu_rate else None) if valu_bound
+                 else (hbm_physical if hbm_physical else algo_gbs / HBM_PEAK_GBS)),
+        "valu": valu_rate / VALU_PEAK_TLANEOPS if valu_rate else None,
+        "useful_valu": useful_rate / VALU_PEAK_TLANEOPS,
+        "hbm_physical": hbm_physical,
+        # SURVEY section 8(d)'s algorithmic figure (16 B per cell-step): a throughput in GB/s-equivalents,
+        # NOT a fraction of the HBM roof once K steps share one HBM pass (it exceeds the peak by design)
+        "algorithmic_GBps": algo_gbs,
+        "algorithmic_frac": algo_gbs / HBM_PEAK_GBS,
+        "algorithmic_frac_of_copy_ceiling": algo_gbs / HBM_COPY_CEILING_GBS,
+        "launch_ms": launch_s * 1e3,
+        "launches": passes,
+        "steps_per_launch": steps_per_launch,
+        "algorithmic_bytes_per_launch": algo_bytes,
+        "traffic": traffic,                      # HBM bytes per launch, PMC (null: not profiled)
+        "valu_insts_per_launch": valu_insts,     # SQ_INSTS_VALU per launch, PMC (null: not profiled)
+        "counters_source": pmc.get("source"),
+    }
     result = {
         # BASELINE.json's metric, verbatim; `value` is its first quantity, the `roofline` object
-        # carries the second (achieved GB/s and fraction of the HBM roof)
+        # carries the second
         "metric": "Mcells×steps/s and achieved HBM GB/s (% of roofline), 16384² f32 grid",
         "value": value,
         "unit": "Mcells×steps/s",
@@ -234,7 +355,7 @@ def main() -> int:
         "warmup": args.warmup,
         "ms_per_step": wall * 1e3 / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic" if not args.rehearsal else "synthetic (REHEARSAL: ranks share one GPU, not a measurement)",
@@ -243,25 +364,18 @@ def main() -> int:
                         f"double-buffered U/V in HBM",
             "cells_per_gpu": cells // args.gpus,
             "kernel": kernel_name,
+            "tuned": {"rows_per_unit": tuned[0], "steps_per_pass": tuned[1], "cols_per_lane": tuned[2]},
             "launches_per_pass": 1 if args.gpus == 1 else 2,
             "partition": "single GPU" if args.gpus == 1 else
                          f"{args.gpus} row slabs, RCCL send/recv ghost rows",
         },
-        "roofline": {
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
-            "launch_ms": launch_ms,
-            "launches": passes,
-            "steps_per_launch": args.steps / passes,
-            "algorithmic_bytes_per_launch": per_launch_bytes,
-            # PMC figure of the committed profile of this kernel on this per-GPU grid (null otherwise)
-            "traffic": measured_traffic(kernel_name) if cells // args.gpus == 16384 * 16384 else None,
-        },
+        "roofline": roofline,
     }
+    if comm:
+        result["rccl_ranks"] = comm[0][0]
+        result["ranks"] = [{"rccl_rank": c[1], "rccl_device": c[2], "local_rank": c[3]} for c in comm]
+    if developed is not None:
+        result["value_developed_pattern"] = developed
     if extra is not None:
         result["fused_flavour"] = extra
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:

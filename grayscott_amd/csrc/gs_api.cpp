@@ -83,6 +83,10 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // introspection (gs_ctx_comm_info); optional
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
 };
 
 Rccl *rccl()
@@ -118,6 +122,9 @@ Rccl *rccl()
             r.handle = nullptr;
             return nullptr;
         }
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.handle, "ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.handle, "ncclCommUserRank"));
+        r.CommCuDevice = reinterpret_cast<decltype(r.CommCuDevice)>(dlsym(r.handle, "ncclCommCuDevice"));
         return &r;
     }();
     return instance;
@@ -666,9 +673,18 @@ struct Run {
 // at most one row).
 uint64_t slab_rows_of(const gs_field *f) { return f->s.empty() ? f->rows : (uint64_t)f->s.front().rows; }
 
+// Same slab shape as far as tuning goes: the slabs of an uneven partition differ by one row and must
+// all run the same configuration (the steps per pass above all: the exchange is that many rows deep).
+bool same_slab_shape(const gs_ctx *ctx, uint64_t rows_a, uint64_t cols_a, uint64_t rows_b, uint64_t cols_b)
+{
+    if (cols_a != cols_b) return false;
+    return rows_a == rows_b || (ctx->total_slabs() > 1 && (rows_a + 1 == rows_b || rows_b + 1 == rows_a));
+}
+
 bool tuned_shape(const gs_ctx *ctx, const gs_field *f, int fuse)
 {
-    return ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse && ctx->tuned_rows == slab_rows_of(f) && ctx->tuned_cols == f->cols;
+    return ctx->tuned_rpu > 0 && ctx->tuned_fuse == fuse &&
+           same_slab_shape(ctx, ctx->tuned_rows, ctx->tuned_cols, slab_rows_of(f), f->cols);
 }
 
 // Make the remembered choice for this shape (if any) the active one.
@@ -677,7 +693,7 @@ void recall_tuned(gs_ctx *ctx, const gs_field *f, int fuse)
     if (tuned_shape(ctx, f, fuse)) return;
     const uint64_t rows = slab_rows_of(f);
     for (const gs_ctx::Tuned &t : ctx->tuned_cache)
-        if (t.rows == rows && t.cols == f->cols && t.fuse == fuse) {
+        if (same_slab_shape(ctx, t.rows, t.cols, rows, f->cols) && t.fuse == fuse) {
             ctx->tuned_rows = t.rows; ctx->tuned_cols = t.cols; ctx->tuned_fuse = t.fuse;
             ctx->tuned_rpu = t.rpu; ctx->tuned_split = t.split; ctx->tuned_k = t.k; ctx->tuned_cpl = t.cpl;
             return;
@@ -723,25 +739,34 @@ int32_t tune_online(Run &r, int fuse)
     const int user_cpl = ctx->o.cols_per_lane;
     // timed passes per candidate: short passes need more of them for a stable comparison
     const int reps = cells >= (1ull << 27) ? 2 : (cells >= (1ull << 24) ? 6 : 8);
-    if (ctx->tune_rows != f->rows || ctx->tune_cols != f->cols || ctx->tune_fuse != fuse) {
-        ctx->tune_rows = f->rows;
-        ctx->tune_cols = f->cols;
-        ctx->tune_fuse = fuse;
-        ctx->tune_next = 0;
-        ctx->tune_best_rpu = 0;
-        ctx->tune_best_split = 0;
-        ctx->tune_best_k = 0;
-        ctx->tune_best_cpl = 0;
-        ctx->tune_best_ms = 0.f;
+    constexpr int kMaxBatch = (int)(sizeof(gs_ctx::Tuning::batch) / sizeof(gs_ctx::Trial));
+    // A call with at least this many passes still to come is a batch job: it waits for each phase's
+    // windows, so a long first run is tuned when it returns.  Shorter calls -- a driver loop with a
+    // few passes per image -- never wait: their windows are read by a later gs_run.
+    constexpr uint64_t kWaitPasses = 16;
+
+    gs_ctx::Tuning *tu = nullptr;
+    for (auto &t : ctx->tunings)
+        if (t.rows == f->rows && t.cols == f->cols && t.fuse == fuse) tu = &t;
+    if (!tu) {
+        if (ctx->tunings.size() >= 16) { // the oldest unfinished tuning makes room
+            for (auto e : ctx->tunings.front().events)
+                if (e) (void)hipEventDestroy(e);
+            ctx->tunings.erase(ctx->tunings.begin());
+        }
+        ctx->tunings.emplace_back();
+        tu = &ctx->tunings.back();
+        tu->rows = f->rows;
+        tu->cols = f->cols;
+        tu->fuse = fuse;
     }
     const int V0 = bands_for(ctx, f, fuse);
     SlabRt &sl = ctx->slabs[0];
     GS_HIP(hipSetDevice(sl.device));
     // Candidates of one phase do not depend on each other, so a whole phase is enqueued back to
     // back -- per candidate: [an untimed pass when the kernel changes,] event, `reps` passes,
-    // event, `reps` passes, event -- and the host waits once per phase: no idle gaps (clock ramps)
-    // between the timing windows.  A candidate's time is the shorter of its two windows.
-    struct Trial { int rpu, V, k, cpl, reps; };
+    // event, `reps` passes, event -- and read once: no idle gaps (clock ramps) between the timing
+    // windows.  A candidate's time is the shorter of its two windows.
     // Timestamp "everything enqueued so far has finished" without holding anything back: after a
     // banded pass the event is recorded on the copy stream, which is made to wait for the bands (a
     // record on the compute stream would turn every window boundary into a barrier between passes,
@@ -755,44 +780,76 @@ int32_t tune_online(Run &r, int fuse)
         GS_HIP(hipEventRecord(ev, ts));
         return GS_OK;
     };
-    constexpr int kMaxBatch = 16;
-    if (ctx->tune_events.empty()) {
-        ctx->tune_events.resize(3 * kMaxBatch, nullptr);
-        for (auto &e : ctx->tune_events) GS_HIP(hipEventCreate(&e));
+    if (tu->events.empty()) {
+        tu->events.resize(3 * kMaxBatch, nullptr);
+        for (auto &e : tu->events) GS_HIP(hipEventCreate(&e));
+    }
+    // read the windows of the batch in flight
+    auto evaluate = [&]() -> int32_t {
+        for (int b = 0; b < tu->nb; ++b) {
+            const gs_ctx::Trial &t = tu->batch[b];
+            float w0 = 0.f, w1 = 0.f;
+            if (hipEventElapsedTime(&w0, tu->events[3 * b], tu->events[3 * b + 1]) != hipSuccess ||
+                hipEventElapsedTime(&w1, tu->events[3 * b + 1], tu->events[3 * b + 2]) != hipSuccess)
+                return fail(GS_ERR_HIP, "timing a tuning pass failed");
+            const float ms = (w0 < w1 ? w0 : w1) / (float)(t.reps * t.k); // per time step
+            static const bool trace = std::getenv("GS_HIP_TRACE_TUNER") != nullptr;
+            if (trace)
+                std::fprintf(stderr, "gs_hip tuner %llux%llu: unit %3d rows, %d band(s), %d steps/pass, %d col/lane: "
+                                     "%.4f ms/step (windows %.3f %.3f ms)\n",
+                             (unsigned long long)f->rows, (unsigned long long)f->cols, t.rpu, t.V, t.k, t.cpl, ms, w0, w1);
+            // prefer the incumbent unless the newcomer is clearly faster: by 1 %, or by 3 % when it
+            // fuses fewer steps (more HBM traffic, slower remainder passes: a tie is not worth it)
+            const float margin = t.k < tu->best_k ? 0.97f : 0.99f;
+            if (tu->best_rpu == 0 || ms < margin * tu->best_ms) {
+                tu->best_ms = ms;
+                tu->best_rpu = t.rpu;
+                tu->best_split = t.V;
+                tu->best_k = t.k;
+                tu->best_cpl = t.cpl;
+            }
+        }
+        tu->nb = 0;
+        return GS_OK;
+    };
+    if (tu->nb > 0) { // windows of an earlier call
+        const hipError_t q = hipEventQuery(tu->events[3 * (tu->nb - 1) + 2]);
+        if (q == hipErrorNotReady) return GS_OK; // still running: this call runs the incumbent
+        if (q != hipSuccess) return fail(GS_ERR_HIP, "a tuning pass failed: %s", hipGetErrorString(q));
+        GS_TRY(evaluate());
     }
     const int phase_end[4] = {ncand, ncand + nalt, ncand + nalt + nk, ncand + nalt + nk + nn};
     int warm_cpl = 0, warm_k = 0; // kernel of the newest pass enqueued by this call
     bool out_of_steps = false;
-    while (ctx->tune_next < phase_end[3] && !out_of_steps) {
+    while (tu->next < phase_end[3] && !out_of_steps) {
         int phase = 0;
-        while (ctx->tune_next >= phase_end[phase]) ++phase;
-        Trial batch[kMaxBatch];
+        while (tu->next >= phase_end[phase]) ++phase;
         int nb = 0;
         int32_t st = GS_OK;
-        for (; ctx->tune_next < phase_end[phase] && nb < kMaxBatch && st == GS_OK; ++ctx->tune_next) {
-            Trial t{0, V0, fuse, user_cpl ? user_cpl : 2, reps};
-            const int i = ctx->tune_next - (phase ? phase_end[phase - 1] : 0);
+        for (; tu->next < phase_end[phase] && nb < kMaxBatch && st == GS_OK; ++tu->next) {
+            gs_ctx::Trial t{0, V0, fuse, user_cpl ? user_cpl : 2, reps};
+            const int i = tu->next - (phase ? phase_end[phase - 1] : 0);
             if (phase == 0) {
                 t.rpu = cand[i];
                 // units shorter than 2K rows recompute more rows than they produce: only worth it
                 // where a pass is latency-bound, i.e. on small grids
                 if ((t.rpu < 2 * fuse && cells > (1ull << 21)) || (uint64_t)t.rpu > f->rows) continue;
             } else if (phase == 2) {
-                t.rpu = ctx->tune_best_rpu;
-                t.V = ctx->tune_best_split;
+                t.rpu = tu->best_rpu;
+                t.V = tu->best_split;
                 t.k = altk[i];
                 if (t.rpu == 0 || t.k >= fuse) continue;
             } else { // phase 3 (phase 1 has no candidates)
                 t.cpl = cpls[i / ncandn];
                 t.rpu = candn[i % ncandn];
-                t.V = ctx->tune_best_split;
-                t.k = ctx->tune_best_k;
-                if (ctx->tune_best_rpu == 0 || (t.rpu < 2 * t.k && cells > (1ull << 21)) || (uint64_t)t.rpu > f->rows ||
+                t.V = tu->best_split;
+                t.k = tu->best_k;
+                if (tu->best_rpu == 0 || (t.rpu < 2 * t.k && cells > (1ull << 21)) || (uint64_t)t.rpu > f->rows ||
                     (large && (t.cpl == 1 || t.rpu < 32)))
                     continue;
             }
-            // short calls (a driver loop with few steps per image) get shorter windows rather
-            // than no tuning at all; with less than 3 passes left it continues in the next gs_run
+            // short calls get shorter windows rather than no tuning at all; with less than 3 passes
+            // left the candidate waits for the next gs_run
             const uint64_t passes_left = (r.steps - r.n) / (uint64_t)t.k;
             while (t.reps > 1 && passes_left < (uint64_t)(2 * t.reps + 1)) --t.reps;
             if (passes_left < (uint64_t)(2 * t.reps + 1)) {
@@ -807,54 +864,31 @@ int32_t tune_online(Run &r, int fuse)
                 warm_k = t.k;
             }
             for (int w = 0; w < 3 && st == GS_OK; ++w) {
-                st = mark(ctx->tune_events[3 * nb + w]);
+                st = mark(tu->events[3 * nb + w]);
                 for (int p = 0; p < t.reps && w < 2 && st == GS_OK; ++p) st = r.advance(t.V, t.k);
             }
             ctx->o.rows_per_block = 0;
             ctx->o.cols_per_lane = user_cpl;
-            batch[nb++] = t;
+            tu->batch[nb++] = t;
         }
         if (st != GS_OK) return st;
-        if (nb > 0 && hipEventSynchronize(ctx->tune_events[3 * (nb - 1) + 2]) != hipSuccess)
+        tu->nb = nb;
+        if (nb == 0) continue;
+        if ((r.steps - r.n) / (uint64_t)fuse < kWaitPasses) break; // short call: read them next time
+        if (hipEventSynchronize(tu->events[3 * (nb - 1) + 2]) != hipSuccess)
             return fail(GS_ERR_HIP, "waiting for the tuning passes failed");
-        for (int b = 0; b < nb; ++b) {
-            float w0 = 0.f, w1 = 0.f;
-            if (hipEventElapsedTime(&w0, ctx->tune_events[3 * b], ctx->tune_events[3 * b + 1]) != hipSuccess ||
-                hipEventElapsedTime(&w1, ctx->tune_events[3 * b + 1], ctx->tune_events[3 * b + 2]) != hipSuccess)
-                return fail(GS_ERR_HIP, "timing a tuning pass failed");
-            const float ms = (w0 < w1 ? w0 : w1) / (float)(batch[b].reps * batch[b].k); // per time step
-            static const bool trace = std::getenv("GS_HIP_TRACE_TUNER") != nullptr;
-            if (trace)
-                std::fprintf(stderr, "gs_hip tuner %llux%llu: unit %3d rows, %d band(s), %d steps/pass, %d col/lane: "
-                                     "%.4f ms/step (windows %.3f %.3f ms)\n",
-                             (unsigned long long)f->rows, (unsigned long long)f->cols, batch[b].rpu, batch[b].V,
-                             batch[b].k, batch[b].cpl, ms, w0, w1);
-            // prefer the incumbent unless the newcomer is clearly faster: by 1 %, or by 3 % when it
-            // fuses fewer steps (more HBM traffic, slower remainder passes: a tie is not worth it)
-            const float margin = batch[b].k < ctx->tune_best_k ? 0.97f : 0.99f;
-            if (ctx->tune_best_rpu == 0 || ms < margin * ctx->tune_best_ms) {
-                ctx->tune_best_ms = ms;
-                ctx->tune_best_rpu = batch[b].rpu;
-                ctx->tune_best_split = batch[b].V;
-                ctx->tune_best_k = batch[b].k;
-                ctx->tune_best_cpl = batch[b].cpl;
-            }
-        }
+        GS_TRY(evaluate());
     }
-    if (ctx->tune_next >= phase_end[3] && ctx->tune_best_rpu > 0) {
-        ctx->tuned_cpl = ctx->tune_best_cpl;
-        ctx->tuned_rpu = ctx->tune_best_rpu;
-        ctx->tuned_split = ctx->tune_best_split;
-        ctx->tuned_k = ctx->tune_best_k;
-        ctx->tuned_fuse = fuse;
-        ctx->tuned_rows = f->rows;
-        ctx->tuned_cols = f->cols;
-        if (ctx->tuned_cache.size() >= 64) ctx->tuned_cache.erase(ctx->tuned_cache.begin());
-        ctx->tuned_cache.push_back({f->rows, f->cols, fuse, ctx->tuned_rpu, ctx->tuned_split, ctx->tuned_k, ctx->tuned_cpl});
+    if (tu->next >= phase_end[3] && tu->nb == 0 && tu->best_rpu > 0) {
+        const gs_ctx::Tuned done{f->rows, f->cols, fuse, tu->best_rpu, tu->best_split, tu->best_k, tu->best_cpl};
+        remember_tuned(ctx, done);
+        recall_tuned(ctx, f, fuse);
         if (std::getenv("GS_HIP_TRACE_TUNER"))
             std::fprintf(stderr, "gs_hip tuner %llux%llu: chose unit %d rows, %d steps/pass, %d col/lane\n",
-                         (unsigned long long)f->rows, (unsigned long long)f->cols, ctx->tuned_rpu, ctx->tuned_k,
-                         ctx->tuned_cpl);
+                         (unsigned long long)f->rows, (unsigned long long)f->cols, done.rpu, done.k, done.cpl);
+        for (auto e : tu->events)
+            if (e) (void)hipEventDestroy(e);
+        ctx->tunings.erase(ctx->tunings.begin() + (tu - ctx->tunings.data()));
     }
     return GS_OK;
 }
@@ -1008,9 +1042,10 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     if (ctx->band_join) (void)hipEventDestroy(ctx->band_join);
-    if (!ctx->tune_events.empty() && !ctx->slabs.empty() && hipSetDevice(ctx->slabs[0].device) == hipSuccess)
-        for (auto e : ctx->tune_events)
-            if (e) (void)hipEventDestroy(e);
+    if (!ctx->tunings.empty() && !ctx->slabs.empty() && hipSetDevice(ctx->slabs[0].device) == hipSuccess)
+        for (auto &t : ctx->tunings)
+            for (auto e : t.events)
+                if (e) (void)hipEventDestroy(e);
     (void)hipGetLastError(); // teardown failures must not leak into later calls' status
     delete ctx;
     return GS_OK;
@@ -1218,6 +1253,9 @@ int32_t gs_field_fill_slice(gs_ctx *ctx, gs_field *f, uint64_t r0, uint64_t r1, 
         return fail(GS_ERR_INVALID, "slice [%llu..%llu, %llu..%llu] outside [%llu, %llu]",
                     (unsigned long long)r0, (unsigned long long)r1, (unsigned long long)c0,
                     (unsigned long long)c1, (unsigned long long)f->rows, (unsigned long long)f->cols);
+    // After an asynchronous run on a slab chain (or on row bands) the last pass's boundary kernels and
+    // ghost pushes may still be in flight on the halo / band streams: the fill below must not race them.
+    GS_TRY(sync_all(ctx));
     for (size_t i = 0; i < f->s.size(); ++i) {
         const FieldSlab &fs = f->s[i];
         const uint64_t lo = r0 > fs.g_row0 ? r0 : fs.g_row0;
@@ -1345,9 +1383,12 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     // The short pass (steps % fuse) goes first so that a run ends on a full-depth ghost exchange
     // and the next run can start without a blocking refresh.
     if (steps % (uint64_t)fuse) GS_TRY(r.advance(1, (int)(steps % (uint64_t)fuse)));
-    if (single) recall_tuned(ctx, u0, fuse);
-    if (single && fuse > 1 && ctx->o.rows_per_block == 0 && !tuned_shape(ctx, u0, fuse)) GS_TRY(tune_online(r, fuse));
-    const int kk = single && tuned_shape(ctx, u0, fuse) && ctx->tuned_k > 0 ? ctx->tuned_k : fuse;
+    recall_tuned(ctx, u0, fuse);
+    if (single && fuse > 1 && ctx->o.rows_per_block == 0 && !ctx->o.no_tune && !tuned_shape(ctx, u0, fuse))
+        GS_TRY(tune_online(r, fuse));
+    // Steps per full pass: the tuned value -- on a slab chain every process must have been given the
+    // same one (gs_ctx_set_tuned), since the ghost-row exchange is K rows deep.
+    const int kk = tuned_shape(ctx, u0, fuse) && ctx->tuned_k > 0 && ctx->tuned_k <= fuse ? ctx->tuned_k : fuse;
     const int V = bands_for(ctx, u0, kk);
     if (ctx->o.use_graph && single && V == 1 && kk > 1) GS_TRY(replay_graph_batches(r, kk));
     const char *full_pass = nullptr;
@@ -1461,6 +1502,51 @@ int32_t gs_timer_stop(gs_ctx *ctx, float *elapsed_ms)
         if (ms > worst) worst = ms;
     }
     *elapsed_ms = worst;
+    return GS_OK;
+}
+
+int32_t gs_ctx_get_tuned(const gs_ctx *ctx, uint64_t slab_rows, uint64_t cols, int32_t *rows_per_block,
+                         int32_t *fuse_steps, int32_t *cols_per_lane)
+{
+    if (!ctx) return fail(GS_ERR_INVALID, "null context");
+    int rpu = 0, k = 0, cpl = 0;
+    for (const gs_ctx::Tuned &t : ctx->tuned_cache)
+        if (t.rows == slab_rows && t.cols == cols) { rpu = t.rpu; k = t.k; cpl = t.cpl; } // the newest entry wins
+    if (rows_per_block) *rows_per_block = rpu;
+    if (fuse_steps) *fuse_steps = k;
+    if (cols_per_lane) *cols_per_lane = cpl;
+    return GS_OK;
+}
+
+int32_t gs_ctx_set_tuned(gs_ctx *ctx, uint64_t slab_rows, uint64_t cols, int32_t rows_per_block, int32_t fuse_steps,
+                         int32_t cols_per_lane)
+{
+    if (!ctx) return fail(GS_ERR_INVALID, "null context");
+    if (rows_per_block < 1 || fuse_steps < 1 || fuse_steps > kGhostRows ||
+        (cols_per_lane != 1 && cols_per_lane != 2 && cols_per_lane != 4))
+        return fail(GS_ERR_INVALID, "bad configuration (unit %d rows, %d steps per pass, %d columns per lane)",
+                    rows_per_block, fuse_steps, cols_per_lane);
+    // keyed like gs_run's own choices: by the steps per pass it was asked to fuse
+    const int fuse = ctx->o.fuse_steps > 0 ? (ctx->o.fuse_steps > kGhostRows ? kGhostRows : ctx->o.fuse_steps) : kGhostRows;
+    if (fuse_steps > fuse) return fail(GS_ERR_INVALID, "%d steps per pass exceed fuse_steps = %d", fuse_steps, fuse);
+    remember_tuned(ctx, gs_ctx::Tuned{slab_rows, cols, fuse, rows_per_block, 1, fuse_steps, cols_per_lane});
+    return GS_OK;
+}
+
+int32_t gs_ctx_comm_info(const gs_ctx *ctx, int32_t *rccl_ranks, int32_t *rccl_rank, int32_t *rccl_device)
+{
+    if (!ctx) return fail(GS_ERR_INVALID, "null context");
+    int n = 0, r = -1, d = -1;
+    if (ctx->comm) {
+        Rccl *R = rccl();
+        if (!R) return fail(GS_ERR_RCCL, "RCCL is not loaded");
+        if (R->CommCount) GS_NCCL(R, R->CommCount(ctx->comm, &n));
+        if (R->CommUserRank) GS_NCCL(R, R->CommUserRank(ctx->comm, &r));
+        if (R->CommCuDevice) GS_NCCL(R, R->CommCuDevice(ctx->comm, &d));
+    }
+    if (rccl_ranks) *rccl_ranks = n;
+    if (rccl_rank) *rccl_rank = r;
+    if (rccl_device) *rccl_device = d;
     return GS_OK;
 }
 

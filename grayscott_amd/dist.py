@@ -90,6 +90,44 @@ def bootstrap(backend: Optional[str] = None, id_source: Optional[Callable[[], by
     return RankInfo(rank, world, local_rank, bytes(buf.cpu().numpy().tobytes()))
 
 
+def share_tuning(sim, slab_rows: int, cols: int, rank: int, world: int, device: str = "cpu",
+                 tune_steps: int = 400, local_device: int = 0) -> Tuple[int, int, int]:
+    """Give every process of a slab chain the same tuned kernel configuration.
+
+    Multi-process contexts do not tune on line (a timing window would have to be collective).
+    Rank 0 lets a throw-away single-slab context of the slab's shape run ``tune_steps`` steps, reads
+    what ``gs_run`` chose (``gs_ctx_get_tuned``) and broadcasts the three integers; every rank hands them
+    to its own context (``gs_ctx_set_tuned``).  They must agree: the exchange is ``fuse_steps`` rows deep.
+    Returns (rows per unit, steps per pass, columns per lane); zeros mean "nothing chosen, defaults".
+    """
+    from .simulation import HipArgs, Parameters, Simulation
+
+    choice = [0, 0, 0]
+    if rank == 0:
+        args = sim.context.args
+        scratch = Simulation.new(sim.params, HipArgs(devices=[local_device], math=args.math, kernel=args.kernel,
+                                                     fuse_steps=args.fuse_steps, boundary=args.boundary,
+                                                     general_kernels=args.general_kernels))
+        species = scratch.make_species([slab_rows, cols])
+        for _ in range(8):                       # long calls wait for their tuning phases
+            scratch.perform_steps(species, tune_steps)
+            choice = list(scratch.context.get_tuned(slab_rows, cols))
+            if choice[0] > 0:
+                break
+        del species
+        scratch.context.close()
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor(choice, dtype=torch.int32, device=device)
+        dist.broadcast(t, src=0)
+        choice = [int(x) for x in t.cpu()]
+    if choice[0] > 0:
+        sim.context.set_tuned(slab_rows, cols, *choice)
+    return tuple(choice)
+
+
 def exchange_ghost_rows(planes: Sequence, rank: int, world: int) -> None:
     """Protocol statement: refresh the ghost rows of row-distributed planes.
 

@@ -73,6 +73,7 @@ def run(args, hip_args: HipArgs | None = None, out=None) -> dict:
     for _ in range(args.output_buffer + 1):            # +1: the image being downloaded
         free.put(pinned_empty(shape))
     errors = []
+    failed = threading.Event()
 
     def writer():
         try:
@@ -84,27 +85,38 @@ def run(args, hip_args: HipArgs | None = None, out=None) -> dict:
                 out[index] = image
                 index += 1
                 free.put(image)
-        except Exception as e:  # pragma: no cover - surfaced below
+        except Exception as e:
+            # The reference's main loop fails as soon as the writer is gone (`image_send.send(image)?`,
+            # main.rs:120).  Here: flag it, wake a main loop that waits for a buffer, and keep draining
+            # so that its full.put() never blocks; the loop below stops at its next iteration.
             errors.append(e)
+            failed.set()
+            free.put(None)
+            while full.get() is not None:
+                pass
 
     thread = threading.Thread(target=writer, daemon=True)
     thread.start()
     t0 = time.perf_counter()
     pending = None
-    for _ in range(args.nbimage):
-        image = free.get()
-        sim.perform_steps(species, steps_per_image)     # enqueued behind the previous staging copy
-        if pending is not None:
-            ctx.download_wait()                         # previous image is complete ...
-            full.put(pending)                           # ... hand it to the I/O thread
-        species.write_result_view_after(image)          # this image: staged + copied while we go on
-        pending = image
-    if pending is not None:
-        ctx.download_wait()
-        full.put(pending)
-    full.put(None)
-    thread.join()
-    ctx.sync()
+    try:
+        for _ in range(args.nbimage):
+            image = free.get()
+            if failed.is_set() or image is None:
+                break
+            sim.prepare_steps(species, steps_per_image)     # enqueued behind the previous staging copy
+            if pending is not None:
+                ctx.download_wait()                         # previous image is complete ...
+                full.put(pending)                           # ... hand it to the I/O thread
+            species.write_result_view_after(image)          # this image: staged + copied while we go on
+            pending = image
+        if pending is not None and not failed.is_set():
+            ctx.download_wait()
+            full.put(pending)
+    finally:
+        full.put(None)
+        thread.join()
+        ctx.sync()
     elapsed = time.perf_counter() - t0
     if errors:
         raise errors[0]

@@ -92,6 +92,7 @@ class HipArgs:
     general_kernels: int = field(default_factory=lambda: _env_int("GS_HIP_GENERAL_KERNELS", 0))
     cols_per_lane: int = field(default_factory=lambda: _env_int("GS_HIP_COLS_PER_LANE", 0))
     boundary: int = field(default_factory=lambda: _env_int("GS_HIP_BOUNDARY", capi.GS_BOUNDARY_CLIPPED))
+    no_tune: int = field(default_factory=lambda: _env_int("GS_HIP_NO_TUNE", 0))
     rank: int = 0
     world: int = 1
     unique_id: Optional[bytes] = None
@@ -105,6 +106,7 @@ class HipArgs:
         o.general_kernels = self.general_kernels
         o.cols_per_lane = self.cols_per_lane
         o.boundary = self.boundary
+        o.no_tune = self.no_tune
         return o
 
 
@@ -149,6 +151,25 @@ class HipContext:
         ms = ctypes.c_float(0)
         capi.check(self._lib.gs_timer_stop(self.handle, ctypes.byref(ms)))
         return float(ms.value)
+
+    def get_tuned(self, slab_rows: int, cols: int) -> Tuple[int, int, int]:
+        """(rows per unit, steps fused per pass, columns per lane) chosen for slabs of this shape;
+        zeros when nothing was chosen yet (``gs_ctx_get_tuned``)."""
+        a, b, c = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        capi.check(self._lib.gs_ctx_get_tuned(self.handle, slab_rows, cols, ctypes.byref(a), ctypes.byref(b),
+                                              ctypes.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
+    def set_tuned(self, slab_rows: int, cols: int, rows_per_block: int, fuse_steps: int, cols_per_lane: int) -> None:
+        capi.check(self._lib.gs_ctx_set_tuned(self.handle, slab_rows, cols, rows_per_block, fuse_steps,
+                                              cols_per_lane))
+
+    def comm_info(self) -> Tuple[int, int, int]:
+        """(ranks, rank, device) as RCCL reports them for this context's communicator; (0, -1, -1)
+        for a single process."""
+        a, b, c = ctypes.c_int32(0), ctypes.c_int32(-1), ctypes.c_int32(-1)
+        capi.check(self._lib.gs_ctx_comm_info(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
 
     def info(self) -> Tuple[str, int]:
         buf = ctypes.create_string_buffer(64)
@@ -390,10 +411,18 @@ class Simulation:
         return Species.new(self.context, shape)
 
     def perform_steps(self, species: Species, steps: int) -> None:
-        """``Simulate::perform_steps`` (lib.rs:48-58): enqueue ``steps`` steps; on return the
-        input slots of ``species`` hold (handles to) the final state.  Asynchronous, like the
-        reference's GPU backends (compute/gpu/naive/src/lib.rs:99-131): a later download or
-        ``context.sync()`` waits."""
+        """``Simulate::perform_steps`` (lib.rs:48-58): ``steps`` steps; on return they are DONE and
+        the input slots of ``species`` hold the final state.  Synchronous like every backend of the
+        reference -- its GPU backends end ``perform_steps_impl`` with
+        ``.then_signal_fence_and_flush()?.wait(None)?`` (compute/shared/src/gpu/mod.rs:77-91)."""
+        self.prepare_steps(species, steps)
+        self.context.sync()
+
+    def prepare_steps(self, species: Species, steps: int) -> None:
+        """The asynchronous form, ``SimulateGpu::prepare_steps`` (compute/shared/src/gpu/mod.rs:
+        70-75): enqueue ``steps`` steps and return; whatever is enqueued next on this context (more
+        steps, ``write_result_view_after``) runs behind them, a download or ``context.sync()`` waits.
+        HIP streams order the work, so there is no future object to pass along."""
         in_u, in_v, out_u, out_v = species.in_out()
         slot = ctypes.c_int32(0)
         lib = self.context._lib

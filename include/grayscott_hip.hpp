@@ -71,8 +71,8 @@ struct Parameters {
 // Backend CLI arguments (every field defaulted, compute/shared/src/lib.rs:20-25).
 struct HipArgs {
     std::vector<int32_t> devices{0};
-    int32_t math = GS_MATH_STRICT, kernel = GS_KERNEL_AUTO, rows_per_block = 0;
-    int32_t boundary = GS_BOUNDARY_CLIPPED;
+    int32_t math = GS_MATH_STRICT, kernel = GS_KERNEL_AUTO, rows_per_block = 0, fuse_steps = 0, cols_per_lane = 0;
+    int32_t boundary = GS_BOUNDARY_CLIPPED, no_tune = 0;
 };
 
 // Concentration::Context: owner of the gs_ctx.
@@ -86,7 +86,10 @@ class HipContext {
         o.math = args.math;
         o.kernel = args.kernel;
         o.rows_per_block = args.rows_per_block;
+        o.fuse_steps = args.fuse_steps;
+        o.cols_per_lane = args.cols_per_lane;
         o.boundary = args.boundary;
+        o.no_tune = args.no_tune;
         check(gs_ctx_create(&ctx_, &p, &o, args.devices.data(), (int32_t)args.devices.size(), 0, 1, nullptr));
     }
     ~HipContext() { gs_ctx_destroy(ctx_); }
@@ -278,8 +281,16 @@ class Simulation {
     }
     // SimulateBase::make_species
     Species make_species(Shape shape) const { return Species::new_(context_, shape); }
-    // Simulate::perform_steps: asynchronous; results end up in the input slots
+    // Simulate::perform_steps: the steps are DONE on return (as in every backend of the reference:
+    // compute/shared/src/gpu/mod.rs:77-91 ends in a fence wait); results end up in the input slots
     void perform_steps(Species &species, std::size_t steps) const
+    {
+        prepare_steps(species, steps);
+        check(gs_sync(context_->get()));
+    }
+    // SimulateGpu::prepare_steps (compute/shared/src/gpu/mod.rs:70-75): enqueue only; a download or
+    // gs_sync waits.  HIP streams order the work, so no future object is passed along.
+    void prepare_steps(Species &species, std::size_t steps) const
     {
         int32_t slot = 0;
         check(gs_run(context_->get(), species.u().in().raw(), species.v().in().raw(), species.u().out().raw(),

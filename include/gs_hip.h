@@ -192,9 +192,12 @@ int32_t gs_step(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs
 /* Simulate::perform_steps (compute/shared/src/lib.rs:48-58): `steps` steps ping-ponging
  * between slot 0 (u0, v0: input on entry) and slot 1.  *result_slot receives the slot that
  * holds the newest state (steps odd -> 1); the caller swaps its handles accordingly so that
- * "the input concentrations contain the final results" (:51-52).  Asynchronous, except that
- * the first long run on a given shape times a few passes to choose the unit height (they are
- * real passes of the simulation; set gs_options.rows_per_block to skip the tuning). */
+ * "the input concentrations contain the final results" (:51-52).  Asynchronous.  The first runs on
+ * a shape time a few candidate configurations (unit height, steps per pass, columns per lane) on
+ * passes of the simulation itself -- nothing is recomputed.  A call with fewer than 64 steps still
+ * to go never waits for those timings (it reads them in a later call); a longer one waits for each
+ * phase, so that a long first run is tuned when it returns.  gs_options.no_tune (or pinning
+ * rows_per_block) switches the tuning off. */
 int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *v1,
                uint64_t steps, int32_t *result_slot);
 
@@ -221,6 +224,21 @@ int32_t gs_download_wait(gs_ctx *ctx);
  * bracket enqueued work; elapsed is the maximum over local slabs, in milliseconds. */
 int32_t gs_timer_start(gs_ctx *ctx);
 int32_t gs_timer_stop(gs_ctx *ctx, float *elapsed_ms);
+
+/* The configuration gs_run uses for slabs of `slab_rows` x `cols` cells: unit height, steps fused per
+ * pass, columns per lane (zeros from _get_ when nothing was chosen yet).  Single-slab contexts find it
+ * themselves (on-line tuning inside gs_run); a slab chain takes what it is given: one process tunes on a
+ * single slab of the slab's shape, reads the result with _get_ and every process of the chain sets it
+ * with _set_ -- all of them the same values, since the ghost-row exchange is fuse_steps rows deep
+ * (grayscott_amd/dist.py: share_tuning). */
+int32_t gs_ctx_get_tuned(const gs_ctx *ctx, uint64_t slab_rows, uint64_t cols, int32_t *rows_per_block,
+                         int32_t *fuse_steps, int32_t *cols_per_lane);
+int32_t gs_ctx_set_tuned(gs_ctx *ctx, uint64_t slab_rows, uint64_t cols, int32_t rows_per_block,
+                         int32_t fuse_steps, int32_t cols_per_lane);
+
+/* What RCCL itself reports for this context's communicator (ncclCommCount / ncclCommUserRank /
+ * ncclCommCuDevice): the number of ranks, this rank and its device; 0, -1, -1 for a single process. */
+int32_t gs_ctx_comm_info(const gs_ctx *ctx, int32_t *rccl_ranks, int32_t *rccl_rank, int32_t *rccl_device);
 
 /* Introspection for tests and the bench: name of the kernel variant last launched
  * ("tb-k4/strict@32x2" = 4 fused steps, strict math, tuned: 32-row units, 2 row bands) and the number of

@@ -20,9 +20,14 @@
  *   corrected weights, -(F+k)       data/src/parameters.rs:57-69
  *
  * Deviations, all timing-neutral or in the CPU's favour:
- *   - rayon's adaptive splitter is replaced by OpenMP tasks that always split
- *     down to the sequential threshold (compute/parallel/src/lib.rs:103-117
- *     gives the same leaves whenever rayon does split all the way);
+ *   - rayon's fork-join over an adaptive splitter is replaced by a persistent team with a
+ *     static partition: the leaves that compute/parallel/src/lib.rs:103-117 produces when
+ *     it splits all the way down to the sequential threshold are listed once, in row order,
+ *     and thread t of T takes the t-th contiguous share of them every step (one OpenMP
+ *     parallel region per perform_steps call, two barriers per step).  rayon keeps a hot
+ *     pool and steals; a fork/join per step with OpenMP tasks does neither, and under a
+ *     cgroup CPU quota its idle spinning throttled the whole process (round 1: the port ran
+ *     10x SLOWER than the naive restatement at 1080x1920 on the GPU box);
  *   - FTZ is set on every worker thread when `ftz` is non-zero; the reference's
  *     DenormalsFlusher only covers the calling thread
  *     (compute/shared/src/lib.rs:112-113), so its rayon workers run unflushed.
@@ -86,6 +91,8 @@ typedef struct {
     int in;           /* which slot is the input */
     size_t max_values_per_line, max_values_per_block, seq_len_threshold;
     int nthreads, ftz;
+    void *leaves; /* leaf_t[n_leaves]: the parallel decomposition, built once */
+    size_t n_leaves;
 } gs_par_sim;
 
 int gs_par_width(void) { return GSW; }
@@ -137,12 +144,11 @@ static void conc_fill_slice(gs_par_conc *c, size_t r0, size_t r1, size_t c0, siz
 /* finalize (simd/mod.rs:281-326) for a stencil offset of 1: the bottom halo row is the
  * first centre row shifted one lane towards lane 0, the top halo row is the last centre
  * row shifted one lane away from lane 0; zeros are shifted in. */
-static void conc_finalize(gs_par_conc *c)
+static void conc_finalize(gs_par_conc *c, size_t j0, size_t j1) /* columns [j0, j1) */
 {
     vf *top = c->simd + 1, *bottom = c->simd + (c->L + 1) * c->stride + 1;
     const vf *first = c->simd + 1 * c->stride + 1, *last = c->simd + c->L * c->stride + 1;
-#pragma omp parallel for schedule(static)
-    for (size_t j = 0; j < c->cols; ++j) {
+    for (size_t j = j0; j < j1; ++j) {
         vlanes s, d;
         s.v = first[j];
         for (int l = 0; l < GSW - 1; ++l) d.f[l] = s.f[l + 1];
@@ -260,23 +266,43 @@ static void block_step(const gs_par_sim *s, const grid_t *g)
     }
 }
 
-/* ParallelSimulation::unchecked_step_impl, compute/parallel/src/lib.rs:100-120. */
-static void parallel_step(const gs_par_sim *s, grid_t g)
+/* ParallelSimulation::unchecked_step_impl, compute/parallel/src/lib.rs:100-120: the leaves of
+ * rayon::iter::split -- a sub-grid is a leaf when grid_len <= the sequential threshold (or it is a
+ * single element), else it is bisected along the rows while more than one row is left, then along
+ * the columns.  Leaves are rectangles of the output grid, listed top to bottom, left to right. */
+typedef struct {
+    size_t r0, rows, c0, cols;
+} leaf_t;
+
+static int collect_leaves(const gs_par_sim *s, leaf_t g, leaf_t **list, size_t *n, size_t *cap)
 {
-    if (grid_len(&g) <= s->seq_len_threshold || (g.out_rows <= 1 && g.out_cols <= 1)) {
-        block_step(s, &g);
-        return;
+    const grid_t probe = {NULL, NULL, NULL, NULL, g.rows, g.cols, 0};
+    if (grid_len(&probe) <= s->seq_len_threshold || (g.rows <= 1 && g.cols <= 1)) {
+        if (*n == *cap) {
+            size_t ncap = *cap ? 2 * *cap : 1024;
+            leaf_t *nl = realloc(*list, ncap * sizeof **list);
+            if (!nl) return -1;
+            *list = nl;
+            *cap = ncap;
+        }
+        (*list)[(*n)++] = g;
+        return 0;
     }
-    grid_t h[2];
-    split_grid(&g, g.out_rows > 1 ? 0 : 1, h);
-#pragma omp task firstprivate(h)
-    parallel_step(s, h[0]);
-#pragma omp task firstprivate(h)
-    parallel_step(s, h[1]);
-#pragma omp taskwait
+    leaf_t a = g, b = g;
+    if (g.rows > 1) { /* split_grid(axis 0), cpu.rs:111-154 */
+        a.rows = g.rows / 2;
+        b.r0 = g.r0 + a.rows;
+        b.rows = g.rows - a.rows;
+    } else {
+        a.cols = g.cols / 2;
+        b.c0 = g.c0 + a.cols;
+        b.cols = g.cols - a.cols;
+    }
+    return collect_leaves(s, a, list, n, cap) || collect_leaves(s, b, list, n, cap);
 }
 
 /* ---- public C entry points (bound from Python with ctypes) ------------------------- */
+void gs_par_destroy(gs_par_sim *s);
 
 /* SimulateCreate::new for parallel(block(autovec)): block sizes in BYTES as the reference's
  * CLI takes them (block/src/args.rs:65-108, parallel/src/args.rs:10-23); defaults are the
@@ -310,9 +336,19 @@ gs_par_sim *gs_par_create(const gs_par_params *p, size_t rows, size_t cols, size
     r1 = r1 > 4 ? r1 - 4 : 0;
     conc_fill_slice(&s->c[1], r0, r1, cols * 7 / 16, cols * 8 / 16, 0.0f);
     conc_fill_slice(&s->c[3], r0, r1, cols * 7 / 16, cols * 8 / 16, 1.0f);
-    conc_finalize(&s->c[1]);
-    conc_finalize(&s->c[3]);
+    conc_finalize(&s->c[1], 0, cols);
+    conc_finalize(&s->c[3], 0, cols);
     s->in = 1;
+    leaf_t *list = NULL;
+    size_t n = 0, cap = 0;
+    const leaf_t whole = {0, s->c[0].L, 0, cols};
+    if (collect_leaves(s, whole, &list, &n, &cap)) {
+        free(list);
+        gs_par_destroy(s);
+        return NULL;
+    }
+    s->leaves = list;
+    s->n_leaves = n;
     return s;
 }
 
@@ -320,36 +356,48 @@ void gs_par_destroy(gs_par_sim *s)
 {
     if (!s) return;
     for (int k = 0; k < 4; ++k) free(s->c[k].simd);
+    free(s->leaves);
     free(s);
 }
 
-/* perform_steps (compute/shared/src/cpu.rs:30-42): step; flip (= finalize output; swap). */
+/* perform_steps (compute/shared/src/cpu.rs:30-42): step; flip (= finalize output; swap).  One
+ * team for the whole call; per step every thread runs its share of the leaves through the block
+ * recursion, then (barrier) rebuilds its share of the halo rows, then (barrier) the slots swap. */
 void gs_par_perform_steps(gs_par_sim *s, size_t steps)
 {
-    /* libgomp keeps its worker team between regions of equal size, so the MXCSR state set
-     * here is the one the task regions below run under; it is put back before returning. */
-    int was_main = 0;
+    const leaf_t *leaves = s->leaves;
+    const int in0 = s->in;
 #pragma omp parallel num_threads(s->nthreads)
     {
-        const int was = set_ftz(s->ftz);
-#pragma omp master
-        was_main = was;
+        const int was = set_ftz(s->ftz); /* every worker, see the header */
+#ifdef _OPENMP
+        const size_t t = (size_t)omp_get_thread_num(), T = (size_t)omp_get_num_threads();
+#else
+        const size_t t = 0, T = 1;
+#endif
+        const size_t l0 = s->n_leaves * t / T, l1 = s->n_leaves * (t + 1) / T;
+        const size_t j0 = s->c[0].cols * t / T, j1 = s->c[0].cols * (t + 1) / T;
+        int in = in0;
+        for (size_t n = 0; n < steps; ++n) {
+            gs_par_conc *iu = &s->c[in], *ou = &s->c[1 - in];
+            gs_par_conc *iv = &s->c[2 + in], *ov = &s->c[3 - in];
+            const size_t st = iu->stride;
+            for (size_t k = l0; k < l1; ++k) {
+                const leaf_t *l = &leaves[k];
+                const size_t off = l->r0 * st + l->c0;
+                const grid_t g = {iu->simd + off, iv->simd + off, ou->simd + st + 1 + off, ov->simd + st + 1 + off,
+                                  l->rows, l->cols, st};
+                block_step(s, &g);
+            }
+#pragma omp barrier
+            conc_finalize(ou, j0, j1);
+            conc_finalize(ov, j0, j1);
+#pragma omp barrier
+            in = 1 - in;
+        }
+        set_ftz(was);
     }
-    for (size_t n = 0; n < steps; ++n) {
-        gs_par_conc *iu = &s->c[s->in], *ou = &s->c[1 - s->in];
-        gs_par_conc *iv = &s->c[2 + s->in], *ov = &s->c[3 - s->in];
-        grid_t g = {iu->simd, iv->simd, ou->simd + ou->stride + 1, ov->simd + ov->stride + 1,
-                    iu->L, iu->cols, iu->stride};
-#pragma omp parallel num_threads(s->nthreads)
-#pragma omp single
-        parallel_step(s, g);
-        conc_finalize(ou);
-        conc_finalize(ov);
-        s->in = 1 - s->in;
-    }
-#pragma omp parallel num_threads(s->nthreads)
-    set_ftz(0);
-    set_ftz(was_main);
+    s->in = (int)((in0 + steps) & 1);
 }
 
 /* write_scalar_view of species k (0 = U, 1 = V) input slot into a dense [rows, cols] array

@@ -197,6 +197,29 @@ ncclResult_t ncclGroupEnd()
     return --g_depth == 0 ? run_ops() : ncclSuccess;
 }
 
+// what gs_ctx_comm_info reads
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count)
+{
+    const Comm *c = reinterpret_cast<const Comm *>(comm);
+    if (!c || !count) return ncclInvalidArgument;
+    *count = c->n;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int *rank)
+{
+    const Comm *c = reinterpret_cast<const Comm *>(comm);
+    if (!c || !rank) return ncclInvalidArgument;
+    *rank = c->rank;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommCuDevice(const ncclComm_t comm, int *device)
+{
+    if (!comm || !device) return ncclInvalidArgument;
+    return hipGetDevice(device) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+}
+
 const char *ncclGetErrorString(ncclResult_t r)
 {
     switch (r) {

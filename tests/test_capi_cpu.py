@@ -27,7 +27,7 @@ def test_header_symbols_all_exported(built):
     assert set(names) == set(capi.EXPORTS)
     for n in names:
         assert hasattr(lib, n), f"libgs_hip.so does not export {n}"
-    assert lib.gs_abi_version() == 1
+    assert lib.gs_abi_version() == 2
 
 
 def test_library_has_gfx950_code_object_and_no_oracle(built):

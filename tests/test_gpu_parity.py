@@ -327,6 +327,86 @@ def test_unusual_call_sequences():
     assert (in_u.make_scalar_view(sim.context) == 1).all() and (in_v.make_scalar_view(sim.context) == 0).all()
 
 
+@pytest.mark.parametrize("kw", [dict(devices=[0, 0]), dict(devices=[0, 0, 0]), dict(split=2), dict()])
+def test_fill_slice_between_asynchronous_runs(kw):
+    """A fill_slice right behind an ASYNCHRONOUS run on a slab chain / on row bands: the last pass's
+    boundary kernels and ghost pushes are still in flight on the side streams when the fill arrives; it
+    must wait for them (rows 2..5 lie in slab 0's boundary rows, 46..50 straddle a seam of 2 slabs /
+    bands, 63..66 one of 3 slabs)."""
+    shape = (96, 200)
+    sim = Simulation.new(Parameters(), args(**kw))
+    species = sim.make_species(list(shape))
+    u, v = oracle.init_species(*shape)
+    for rows_, cols_, value, steps in ((range(2, 5), range(3, 9), 0.75, 13), (range(46, 50), range(0, 200), 0.5, 16),
+                                       (range(63, 66), range(100, 180), 0.25, 9)):
+        sim.prepare_steps(species, steps)                # enqueue only
+        u, v = oracle.run(u, v, steps)
+        in_u, in_v, _, _ = species.in_out()
+        in_v.fill_slice(sim.context, [rows_, cols_], value)
+        v[rows_.start:rows_.stop, cols_.start:cols_.stop] = value
+        in_u.fill_slice(sim.context, [rows_, cols_], 1.0 - value)
+        u[rows_.start:rows_.stop, cols_.start:cols_.stop] = np.float32(1.0 - value)
+    sim.perform_steps(species, 21)
+    u, v = oracle.run(u, v, 21)
+    in_u, in_v, _, _ = species.in_out()
+    assert_bits_equal(in_u.make_scalar_view(sim.context), u, f"U after edits between runs {kw}")
+    assert_bits_equal(in_v.make_scalar_view(sim.context), v, f"V after edits between runs {kw}")
+    sim.context.close()
+
+
+def test_short_alternating_runs_finish_tuning_without_restarting():
+    """A driver loop with 32 steps per image on TWO grids in turn: each shape's tuning advances in its
+    own state (it used to restart whenever the other shape ran), short calls never wait for their
+    timing windows, and both shapes end up tuned; the bits stay those of the oracle throughout."""
+    sim = Simulation.new(Parameters(), args())
+    shapes = [(96, 200), (64, 700)]
+    state = {s: stress_fields(s, 23) for s in shapes}
+    species = {s: species_from_arrays(sim, *state[s]) for s in shapes}
+    total = {s: 0 for s in shapes}
+    tuned = {}
+    for it in range(400):
+        for s in shapes:
+            sim.prepare_steps(species[s], 32)
+            total[s] += 32
+            if sim.context.get_tuned(*s)[0] > 0:
+                tuned.setdefault(s, it)
+        if len(tuned) == len(shapes):
+            break
+    assert len(tuned) == len(shapes), f"not tuned after 400 short calls each: {tuned}"
+    for s in shapes:
+        ref_u, ref_v = oracle.run(state[s][0], state[s][1], total[s], ftz=True)
+        iu, iv, _, _ = species[s].in_out()
+        assert_bits_equal(iu.make_scalar_view(sim.context), ref_u, f"U {s}")
+        assert_bits_equal(iv.make_scalar_view(sim.context), ref_v, f"V {s}")
+    sim.context.close()
+
+
+def test_no_tune_option_and_handed_in_configuration():
+    """no_tune: gs_run never times candidates; a configuration handed in with set_tuned is what runs
+    (single slab and slab chain, incl. fewer steps per pass than the default 4)."""
+    shape = (200, 300)
+    u0, v0 = stress_fields(shape, 3)
+    ref_u, ref_v = oracle.run(u0, v0, 47, ftz=True)
+    for kw in (dict(), dict(devices=[0, 0, 0])):
+        sim = Simulation.new(Parameters(), args(no_tune=1, **kw))
+        sp = species_from_arrays(sim, u0, v0)
+        sim.perform_steps(sp, 30)
+        assert "@" not in sim.context.info()[0]
+        slab_rows = shape[0] // len(kw.get("devices", [0]))
+        assert sim.context.get_tuned(slab_rows, shape[1]) == (0, 0, 0)
+        sim.context.set_tuned(slab_rows, shape[1], 16, 3, 1)
+        assert sim.context.get_tuned(slab_rows, shape[1]) == (16, 3, 1)
+        sim.perform_steps(sp, 17)
+        label = sim.context.info()[0]
+        assert label.startswith("tb-k3c1/") and "@16x" in label, label
+        iu, iv, _, _ = sp.in_out()
+        assert_bits_equal(iu.make_scalar_view(sim.context), ref_u, f"U {kw}")
+        assert_bits_equal(iv.make_scalar_view(sim.context), ref_v, f"V {kw}")
+        with pytest.raises(GsError):
+            sim.context.set_tuned(slab_rows, shape[1], 16, 5, 1)
+        sim.context.close()
+
+
 # ---- one context, several grids ------------------------------------------------------------------
 def test_alternating_shapes_on_one_context_keep_their_tuning():
     """The on-line choice is remembered per shape: going back to a grid does not tune again, and the

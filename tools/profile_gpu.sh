@@ -3,6 +3,7 @@
 #   1. --kernel-trace --stats          per-kernel time (average launch duration)
 #   2. --pmc FETCH_SIZE                HBM read traffic   (its own pass: TCC has 4 slots,
 #   3. --pmc WRITE_SIZE                HBM write traffic   FETCH_SIZE costs 3, WRITE_SIZE 2)
+#   4. --pmc SQ_INSTS_VALU ...         issued VALU wave-instructions, wave cycles, stall shares (8 SQ slots)
 # PMC passes use --kernel-trace only (no sys/hip/hsa tracing), as the pool requires.
 # Raw CSVs land under gpurun_out/prof_$TAG/; tools/summarize_profile.py turns them into the
 # summaries committed under profiles/.
@@ -25,4 +26,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o
     python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-extra $EXTRA > "$OUT/bench_fetch.json" 2> "$OUT/fetch.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o bench -- \
     python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-extra $EXTRA > "$OUT/bench_write.json" 2> "$OUT/write.log"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES \
+    --output-format csv -d "$OUT/sq" -o bench -- \
+    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-extra $EXTRA > "$OUT/bench_sq.json" 2> "$OUT/sq.log"
 find "$OUT" -name '*.csv' | head -20

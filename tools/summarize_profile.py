@@ -4,7 +4,8 @@ summaries committed under profiles/:
 
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
   profiles/<tag>_summary.md         per-kernel time + HBM traffic per launch of the step kernel
-  profiles/traffic.json             {"<bench kernel label>": bytes per launch, ...} read by bench.py
+  profiles/counters.json            {"<bench kernel label>": {"traffic": HBM bytes per launch, "valu_insts":
+                                    SQ_INSTS_VALU per launch, "source": ...}, ...} read by bench.py
 
 HBM bytes per launch follow MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE come from
 separate --pmc passes, both are in KiB, and on gfx950 FETCH_SIZE reports exactly half of the
@@ -79,16 +80,55 @@ def main():
         f"* algorithmic rate under the profiler: {algo/avg_ms/1e6:.0f} GB/s; HBM-side rate {total/avg_ms/1e6:.0f} GB/s",
         "",
     ]
+    # SQ counters (their own pass): issued VALU instructions, wave cycles, stall shares
+    entry = {"traffic": total, "valu_insts": None, "source": f"profiles/{tag}_summary.md"}
+    sq_csv = os.path.join(src, "sq", "bench_counter_collection.csv")
+    if os.path.exists(sq_csv):
+        med = {}
+        for name in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY",
+                     "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVES"):
+            vals = counter_values(sq_csv, needle, name)
+            if vals:
+                med[name] = statistics.median(vals)
+        if "SQ_INSTS_VALU" in med:
+            entry["valu_insts"] = med["SQ_INSTS_VALU"]
+            cell_steps = bench["config"]["cells_per_gpu"] * bench["roofline"].get("steps_per_launch", 1)
+            sq_bench = json.loads(open(os.path.join(src, "bench_sq.json")).read().strip().splitlines()[-1])
+            sq_ms = sq_bench["roofline"]["launch_ms"]
+            lines += [
+                f"## SQ counters of `{needle}` (separate pass: `--pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES "
+                "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES`), medians per launch",
+                "",
+                "| counter | per launch | reading |",
+                "|---|---|---|",
+                f"| SQ_WAVES | {med.get('SQ_WAVES', 0):.0f} | waves per launch |",
+                f"| SQ_INSTS_VALU | {med['SQ_INSTS_VALU']/1e6:.1f} M wave-instructions | "
+                f"{med['SQ_INSTS_VALU']*64/cell_steps:.1f} instruction-lanes per cell-step (53 are the reference's arithmetic) |",
+            ]
+            if "GRBM_GUI_ACTIVE" in med:
+                cyc = med["GRBM_GUI_ACTIVE"] / 8.0
+                lines.append(f"| GRBM_GUI_ACTIVE | {med['GRBM_GUI_ACTIVE']/1e6:.2f} M (sum over 8 XCDs) | {cyc/1e6:.2f} M cycles per launch = "
+                             f"{cyc/(sq_ms*1e-3)/1e9:.2f} GHz effective over the {sq_ms:.4f} ms that pass measured |")
+                lines.append(f"| VALU issue | one instruction per {cyc*1024/med['SQ_INSTS_VALU']:.2f} cycles per SIMD | "
+                             f"{200.0*med['SQ_INSTS_VALU']/(cyc*1024):.0f} % of the issue slots (a wave64 f32 op holds a SIMD-32 for 2 cycles); "
+                             f"{med['SQ_INSTS_VALU']*64/(sq_ms*1e-3)/1e12:.1f} T lane-ops/s in that pass, "
+                             f"{med['SQ_INSTS_VALU']*64/(avg_ms*1e-3)/1e12:.1f} T at the kernel-trace pass's launch time |")
+            if "SQ_WAVE_CYCLES" in med:
+                for k, what in (("SQ_WAIT_INST_ANY", "issue-side stalls (dependencies, pipe busy)"),
+                                ("SQ_WAIT_ANY", "waves parked on `s_waitcnt` (memory, LDS crossbar)")):
+                    if k in med:
+                        lines.append(f"| {k} / SQ_WAVE_CYCLES | {100*med[k]/med['SQ_WAVE_CYCLES']:.0f} % | {what} |")
+            lines.append("")
     open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))
-    tpath = os.path.join(dst, "traffic.json")
+    cpath = os.path.join(dst, "counters.json")
     try:
-        traffic = json.load(open(tpath))
+        counters = json.load(open(cpath))
     except (OSError, ValueError):
-        traffic = {}
-    traffic[bench["config"]["kernel"]] = total
-    traffic[label] = total
-    traffic["_source"] = f"profiles/{tag}_summary.md"
-    json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
+        counters = {}
+    counters[bench["config"]["kernel"].split("@")[0]] = entry
+    if label != "default":
+        counters[label] = entry
+    json.dump(counters, open(cpath, "w"), indent=1, sort_keys=True)
     print("\n".join(lines))
 
 
