@@ -370,6 +370,8 @@ def test_short_alternating_runs_finish_tuning_without_restarting():
             total[s] += 32
             if sim.context.get_tuned(*s)[0] > 0:
                 tuned.setdefault(s, it)
+        sim.context.download_wait()                     # a driver waits for its image, not for the steps ...
+        sim.context.sync()                              # ... (here: for everything, to keep the queue short)
         if len(tuned) == len(shapes):
             break
     assert len(tuned) == len(shapes), f"not tuned after 400 short calls each: {tuned}"
