@@ -23,7 +23,7 @@ GS_ERR_UNSUPPORTED = -5
 GS_ERR_NOMEM = -6
 
 GS_MATH_STRICT, GS_MATH_FUSED = 0, 1
-GS_KERNEL_AUTO, GS_KERNEL_SIMPLE, GS_KERNEL_STREAM, GS_KERNEL_TB, GS_KERNEL_LDS = 0, 1, 2, 3, 4
+GS_KERNEL_AUTO, GS_KERNEL_SIMPLE, GS_KERNEL_STREAM, GS_KERNEL_TB, GS_KERNEL_LDS, GS_KERNEL_TILE = 0, 1, 2, 3, 4, 5
 GS_BOUNDARY_CLIPPED, GS_BOUNDARY_ZERO_HALO = 0, 1
 GS_UNIQUE_ID_BYTES = 128
 
@@ -75,7 +75,8 @@ class GsOptions(ctypes.Structure):
         ("cols_per_lane", ctypes.c_int32),
         ("boundary", ctypes.c_int32),
         ("no_tune", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 5),
+        ("tile_shape", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 4),
     ]
 
 

@@ -400,7 +400,7 @@ int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fu
 int32_t launch_rows(gs_ctx *ctx, const GsStepArgs &a, hipStream_t stream, int fuse)
 {
     int32_t kernel = ctx->o.kernel;
-    if (kernel == GS_KERNEL_AUTO) kernel = fuse > 1 ? GS_KERNEL_TB : GS_KERNEL_STREAM;
+    if (kernel == GS_KERNEL_AUTO || kernel == GS_KERNEL_TILE) kernel = fuse > 1 ? GS_KERNEL_TB : GS_KERNEL_STREAM;
     if (fuse > 1 && kernel != GS_KERNEL_TB)
         return fail(GS_ERR_UNSUPPORTED, "only the temporally blocked kernel fuses steps");
     const bool fused = ctx->o.math == GS_MATH_FUSED;
@@ -1078,6 +1078,8 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
     if (st == GS_OK && ctx->o.cols_per_lane != 0 && ctx->o.cols_per_lane != 1 && ctx->o.cols_per_lane != 2 &&
         ctx->o.cols_per_lane != 4)
         st = fail(GS_ERR_INVALID, "cols_per_lane must be 0 (auto), 1, 2 or 4, not %d", ctx->o.cols_per_lane);
+    if (st == GS_OK && (ctx->o.tile_shape < 0 || ctx->o.tile_shape > 3))
+        st = fail(GS_ERR_INVALID, "tile_shape must be 0 (auto), 1 (32 x 64), 2 (16 x 32) or 3 (8 x 32), not %d", ctx->o.tile_shape);
     if (st == GS_OK && ctx->o.boundary != GS_BOUNDARY_CLIPPED && ctx->o.boundary != GS_BOUNDARY_ZERO_HALO)
         st = fail(GS_ERR_INVALID, "unknown boundary rule %d", ctx->o.boundary);
     if (st != GS_OK) { delete ctx; return st; }
@@ -1347,7 +1349,7 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     // Temporal blocking: `fuse` steps per pass over HBM (default 4, the measured optimum);
     // bounded by the ghost depth and by the smallest slab of the partition.
     int fuse = 1;
-    if (ctx->o.kernel == GS_KERNEL_AUTO || ctx->o.kernel == GS_KERNEL_TB) {
+    if (ctx->o.kernel == GS_KERNEL_AUTO || ctx->o.kernel == GS_KERNEL_TB || ctx->o.kernel == GS_KERNEL_TILE) {
         fuse = ctx->o.fuse_steps > 0 ? ctx->o.fuse_steps : kGhostRows;
         if (fuse > kGhostRows) fuse = kGhostRows;
         if (ctx->total_slabs() > 1 && fuse > min_slab_rows(ctx, u0)) fuse = min_slab_rows(ctx, u0);
@@ -1377,6 +1379,46 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
             slot ^= n & 1;
             left -= (uint64_t)n;
         }
+        if (result_slot) *result_slot = slot;
+        return GS_OK;
+    }
+    // GS_KERNEL_TILE (single slab): K <= 8 steps per launch on LDS-resident tiles (gs_run_tile_k).  Built
+    // for the mid-size grids, where a pass of the temporally blocked kernel is bound by the length of a
+    // wave's march and a launch per <= 4 steps; measured SLOWER than that kernel on every grid of the
+    // reference's benchmark set (profiles/r02_sweeps.md, section 4), so kernel = auto never picks it.
+    const uint64_t cells = u0->rows * u0->cols;
+    if (single && cells > 0 && steps > 0 && ctx->o.kernel == GS_KERNEL_TILE) {
+        SlabRt &sl = ctx->slabs[0];
+        GS_HIP(hipSetDevice(sl.device));
+        GS_TRY(join_bands(ctx, sl.compute));
+        ctx->bands_active = false;
+        // tile shape: the largest one that still gives every CU a workgroup; steps per launch: 8 for the
+        // big tile, 4 for the small ones, whose apron would otherwise outweigh the tile
+        static const int th[3] = {32, 16, 8}, tw[3] = {64, 32, 32};
+        int shape = 2;
+        for (int sidx = 0; sidx < 3; ++sidx)
+            if (((u0->rows + th[sidx] - 1) / th[sidx]) * ((u0->cols + tw[sidx] - 1) / tw[sidx]) >= 256) { shape = sidx; break; }
+        if (ctx->o.tile_shape >= 1 && ctx->o.tile_shape <= 3) shape = ctx->o.tile_shape - 1;
+        int kmax = shape == 0 ? kGsTileMaxSteps : 4;
+        if (ctx->o.fuse_steps > 0)
+            kmax = ctx->o.fuse_steps > kGsTileMaxSteps ? kGsTileMaxSteps : ctx->o.fuse_steps;
+        uint64_t left = steps;
+        int slot = 0;
+        const char *full_name = nullptr;
+        while (left > 0) { // the short launch first, then full ones
+            const int n = left % (uint64_t)kmax ? (int)(left % (uint64_t)kmax) : kmax;
+            GsStepArgs a = make_args(ctx, r.u[slot], r.v[slot], r.u[1 - slot], r.v[1 - slot], 0, 1);
+            const char *name = nullptr;
+            const hipError_t e = ctx->o.math == GS_MATH_FUSED ? gs_launch_tile_fused(a, n, shape, sl.compute, &name)
+                                                               : gs_launch_tile_strict(a, n, shape, sl.compute, &name);
+            if (e != hipSuccess) return fail(GS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+            if (!full_name || n == kmax) full_name = name;
+            ctx->launches++;
+            ctx->step_no++;
+            slot ^= 1;
+            left -= (uint64_t)n;
+        }
+        ctx->last_kernel = full_name;
         if (result_slot) *result_slot = slot;
         return GS_OK;
     }

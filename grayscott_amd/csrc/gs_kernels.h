@@ -12,6 +12,8 @@
 // faster than the temporally blocked kernel there (profiles/r01_sweeps.md, run 118); at 8192 cells
 // (4 more cells per thread) it would not be.
 constexpr int kGsResidentCells = 4096;
+// gs_launch_tile_*: the most time steps one launch advances its tiles by.
+constexpr int kGsTileMaxSteps = 8;
 
 struct GsStepArgs {
     const float *in_u, *in_v; // local row 0, col 0 of the input planes
@@ -50,6 +52,7 @@ struct GsStepArgs {
     hipError_t gs_launch_stream_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name); \
     hipError_t gs_launch_resident_##SUFFIX(const GsStepArgs &a, int steps, hipStream_t s, const char **name); \
     hipError_t gs_launch_tb_##SUFFIX(const GsStepArgs &a, int k, hipStream_t s, const char **name); \
+    hipError_t gs_launch_tile_##SUFFIX(const GsStepArgs &a, int k, int shape, hipStream_t s, const char **name); \
     hipError_t gs_launch_lds_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name);
 
 GS_DECLARE_LAUNCHERS(strict)

@@ -315,7 +315,8 @@ __global__ __launch_bounds__(kResidentThreads) void GS_SUFFIX(gs_run_resident_k)
 {
     extern __shared__ float lds[];
     const int cells = a.rows * a.cols, cols = a.cols;
-    float *pu[2] = {lds, lds + cells}, *pv[2] = {lds + 2 * cells, lds + 3 * cells};
+    // planes in LDS: U slot 0, U slot 1, V slot 0, V slot 1 -- addressed by offset (a select between
+    // pointers would make the compiler lose the address space and emit flat_load)
     constexpr int CPT = (kResidentCells + kResidentThreads - 1) / kResidentThreads; // cells per thread, at most
     int idx[CPT], up[CPT], down[CPT], lt[CPT], rt[CPT], grow[CPT], gcol[CPT];
     bool mrow[CPT], prow[CPT];
@@ -336,15 +337,15 @@ __global__ __launch_bounds__(kResidentThreads) void GS_SUFFIX(gs_run_resident_k)
         lt[k] = c > 0 ? -1 : 0;
         rt[k] = c + 1 < cols ? 1 : 0;
         if (live) {
-            pu[0][idx[k]] = a.in_u[(ptrdiff_t)r * a.pitch + c];
-            pv[0][idx[k]] = a.in_v[(ptrdiff_t)r * a.pitch + c];
+            lds[idx[k]] = a.in_u[(ptrdiff_t)r * a.pitch + c];
+            lds[2 * cells + idx[k]] = a.in_v[(ptrdiff_t)r * a.pitch + c];
         }
     }
     __syncthreads();
     int cur = 0;
     for (int s = 0; s < steps; ++s) {
-        const float *iu = pu[cur], *iv = pv[cur];
-        float *ou = pu[cur ^ 1], *ov = pv[cur ^ 1];
+        const int iu = cur * cells, iv = 2 * cells + cur * cells;
+        const int ou = (cur ^ 1) * cells, ov = 2 * cells + (cur ^ 1) * cells;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             if (idx[k] >= cells) continue;
@@ -354,13 +355,13 @@ __global__ __launch_bounds__(kResidentThreads) void GS_SUFFIX(gs_run_resident_k)
             Row3 *dst[3] = {&m, &z, &p};
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                dst[i]->u[0] = iu[rows3[i] + lt[k]]; dst[i]->u[1] = iu[rows3[i]]; dst[i]->u[2] = iu[rows3[i] + rt[k]];
-                dst[i]->v[0] = iv[rows3[i] + lt[k]]; dst[i]->v[1] = iv[rows3[i]]; dst[i]->v[2] = iv[rows3[i] + rt[k]];
+                dst[i]->u[0] = lds[iu + rows3[i] + lt[k]]; dst[i]->u[1] = lds[iu + rows3[i]]; dst[i]->u[2] = lds[iu + rows3[i] + rt[k]];
+                dst[i]->v[0] = lds[iv + rows3[i] + lt[k]]; dst[i]->v[1] = lds[iv + rows3[i]]; dst[i]->v[2] = lds[iv + rows3[i] + rt[k]];
             }
             float nu, nv;
             cell<true, 0, Row3>(a, m, z, p, 1, mrow[k], prow[k], la[k], ra[k], nu, nv);
-            ou[o] = nu;
-            ov[o] = nv;
+            lds[ou + o] = nu;
+            lds[ov + o] = nv;
         }
         __syncthreads();
         cur ^= 1;
@@ -370,8 +371,8 @@ __global__ __launch_bounds__(kResidentThreads) void GS_SUFFIX(gs_run_resident_k)
 #pragma unroll
     for (int k = 0; k < CPT; ++k)
         if (idx[k] < cells) {
-            gu[(ptrdiff_t)grow[k] * a.pitch + gcol[k]] = pu[cur][idx[k]];
-            gv[(ptrdiff_t)grow[k] * a.pitch + gcol[k]] = pv[cur][idx[k]];
+            gu[(ptrdiff_t)grow[k] * a.pitch + gcol[k]] = lds[cur * cells + idx[k]];
+            gv[(ptrdiff_t)grow[k] * a.pitch + gcol[k]] = lds[2 * cells + cur * cells + idx[k]];
         }
 }
 #endif // !GS_TB_OP_ONLY
@@ -757,6 +758,141 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
 
 #if !GS_TB_OP_ONLY
 // ------------------------------------------------------------------------------------
+// Mid-size grids: K <= 8 time steps per launch on LDS-resident tiles.
+//
+// Between the single-workgroup resident kernel (<= 4096 cells) and grids that fill the chip with
+// marching waves (~1 M cells and up), a pass of gs_step_tb_k is bound by the LENGTH of a wave's march
+// (unit height + 2K ticks, one wave per SIMD issuing every 4th cycle) plus a dependent launch per
+// K <= 4 steps: 2.3-3.7 us per step whatever the grid (profiles/r01_criterion_grid.md).  Here a
+// workgroup owns a tile (32 x 64, 16 x 32 or 8 x 32 cells, picked by the host so that the tiles fill the
+// chip): it loads the tile with a K-cell apron into LDS, advances
+// it K times LDS -> LDS (a workgroup barrier per step; the region of valid cells shrinks by one ring
+// per step and ends as the tile) and stores the tile: one launch per K steps, all waves of the
+// workgroup working on every step.  Every thread updates strips of 4 cells from a 3 x 6 window read
+// with ds_read_b128 + 2 ds_read_b32 per row and species, through the same cell<> code as every
+// other kernel: bit-identical.  Tiles whose window leaves the grid run the general flavour with
+// per-cell presence flags / masks (cells outside the grid hold zeros and are never a neighbour).
+// ------------------------------------------------------------------------------------
+constexpr int kTileMaxK = kGsTileMaxSteps;
+// window column wc lives at LDS column wc + 3, so that the strips (which start at window column 1) are
+// 16-byte aligned; the pitch covers the last strip's right neighbour and is a multiple of 4 floats
+__host__ __device__ constexpr int tile_pitch(int tw, int k) { return ((tw + 2 * k + 7 + 3) / 4) * 4; }
+__host__ __device__ constexpr size_t tile_lds_bytes(int th, int tw, int k) { return (size_t)4 * (th + 2 * k) * tile_pitch(tw, k) * sizeof(float); }
+
+// One strip of 4 cells at window (wr, wc), LDS element offset o = wr * P + wc + 3 (a multiple of 4).
+template <bool GENERAL, int FAST>
+__device__ __forceinline__ void tile_strip(const GsStepArgs &a, const float *lds, int src, int plane, int P, int o, int gr, int gc,
+                                           float4 &nu, float4 &nv)
+{
+    RowW m, z, p;
+    RowW *dst[3] = {&m, &z, &p};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float *pu = lds + (src + o + (i - 1) * P), *pv = lds + (2 * plane + src + o + (i - 1) * P);
+        const float4 fu = *reinterpret_cast<const float4 *>(pu);
+        const float4 fv = *reinterpret_cast<const float4 *>(pv);
+        dst[i]->u[1] = fu.x; dst[i]->u[2] = fu.y; dst[i]->u[3] = fu.z; dst[i]->u[4] = fu.w;
+        dst[i]->v[1] = fv.x; dst[i]->v[2] = fv.y; dst[i]->v[3] = fv.z; dst[i]->v[4] = fv.w;
+        dst[i]->u[0] = pu[-1]; dst[i]->u[5] = pu[4];
+        dst[i]->v[0] = pv[-1]; dst[i]->v[5] = pv[4];
+    }
+    if (GENERAL) {
+        const bool mrow = gr > 0, prow = gr + 1 < a.rows;
+        uint32_t la[4], ra[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            la[k] = (gc + k == 0) ? 0xffffffffu : 0u;
+            ra[k] = (gc + k + 1 >= a.cols) ? 0xffffffffu : 0u;
+            asm volatile("" : "+v"(la[k]), "+v"(ra[k])); // keep the blends bitwise (see tb_march)
+        }
+        cell<true>(a, m, z, p, 1, mrow, prow, la[0], ra[0], nu.x, nv.x);
+        cell<true>(a, m, z, p, 2, mrow, prow, la[1], ra[1], nu.y, nv.y);
+        cell<true>(a, m, z, p, 3, mrow, prow, la[2], ra[2], nu.z, nv.z);
+        cell<true>(a, m, z, p, 4, mrow, prow, la[3], ra[3], nu.w, nv.w);
+    } else {
+        cell<false, FAST>(a, m, z, p, 1, true, true, 0u, 0u, nu.x, nv.x);
+        cell<false, FAST>(a, m, z, p, 2, true, true, 0u, 0u, nu.y, nv.y);
+        cell<false, FAST>(a, m, z, p, 3, true, true, 0u, 0u, nu.z, nv.z);
+        cell<false, FAST>(a, m, z, p, 4, true, true, 0u, 0u, nu.w, nv.w);
+    }
+}
+
+template <int TH, int TW, int NT, int FAST>
+__global__ __launch_bounds__(NT) void GS_SUFFIX(gs_run_tile_k)(GsStepArgs a, int K)
+{
+    if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0); // half_diff: MODE.IEEE = 0
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tiles_c = (a.cols + TW - 1) / TW;
+    const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
+    const int gr0 = tr * TH - K, gc0 = tc * TW - K; // global coordinates of window cell (0, 0)
+    const int Wh = TH + 2 * K, Ww = TW + 2 * K;
+    const int P4 = tile_pitch(TW, K) >> 2, P = P4 << 2;
+    const int plane = Wh * P; // lds: U buffer 0, U buffer 1, V buffer 0, V buffer 1 -- addressed by offset: a
+                              // select between pointers makes the compiler fall back to flat_load
+    // stage the window (zeros outside the grid, and in the pad columns the strip reads reach)
+    for (int i = threadIdx.x; i < Wh * P; i += NT) {
+        const int wr = i / P, wc = i - wr * P - 3;
+        const int gr = gr0 + wr, gc = gc0 + wc;
+        const bool in = wc >= 0 && wc < Ww && gr >= 0 && gr < a.rows && gc >= 0 && gc < a.cols;
+        const ptrdiff_t g = (ptrdiff_t)gr * a.pitch + gc;
+        lds[i] = in ? a.in_u[g] : 0.f;
+        lds[plane + i] = 0.f;
+        lds[2 * plane + i] = in ? a.in_v[g] : 0.f;
+        lds[3 * plane + i] = 0.f;
+    }
+    __syncthreads();
+    // A tile whose window lies inside the grid runs code without any bounds logic.  Elsewhere only the
+    // cells ON the grid's border need the general flavour (clipped window / zero halo); cells outside
+    // the grid are skipped and stay zero (border cells mask them away), all others are interior cells.
+    const bool edge_tile = gr0 < 0 || gc0 < 0 || gr0 + Wh > a.rows || gc0 + Ww > a.cols;
+    const int nspr = (Ww - 2 + 3) >> 2; // strips of 4 cells per window row, from window column 1
+    int cur = 0;
+    for (int s = 1; s <= K; ++s) {
+        const int src = cur * plane, dst = (cur ^ 1) * plane;
+        const int nrows = Wh - 2 * s; // rows that can still be valid after this step: the ring of width s is lost
+        for (int idx = threadIdx.x; idx < nrows * nspr; idx += NT) {
+            const int rr = idx / nspr, si = idx - rr * nspr;
+            const int wr = s + rr, wc = 1 + 4 * si;
+            const int o = (wr * P4 + si + 1) << 2; // = wr * P + wc + 3, visibly 16-byte aligned
+            const int gr = gr0 + wr, gc = gc0 + wc;
+            float4 nu, nv;
+            if (!edge_tile) {
+                tile_strip<false, FAST>(a, lds, src, plane, P, o, gr, gc, nu, nv);
+            } else {
+                if (gr < 0 || gr >= a.rows || gc + 3 < 0 || gc >= a.cols) continue; // wholly outside
+                const bool border = gr == 0 || gr + 1 == a.rows || gc <= 0 || gc + 4 >= a.cols;
+                if (border) {
+                    tile_strip<true, FAST>(a, lds, src, plane, P, o, gr, gc, nu, nv);
+                    // cells of the strip outside the grid stay zero
+                    if (gc + 0 < 0 || gc + 0 >= a.cols) { nu.x = 0.f; nv.x = 0.f; }
+                    if (gc + 1 < 0 || gc + 1 >= a.cols) { nu.y = 0.f; nv.y = 0.f; }
+                    if (gc + 2 < 0 || gc + 2 >= a.cols) { nu.z = 0.f; nv.z = 0.f; }
+                    if (gc + 3 < 0 || gc + 3 >= a.cols) { nu.w = 0.f; nv.w = 0.f; }
+                } else {
+                    tile_strip<false, FAST>(a, lds, src, plane, P, o, gr, gc, nu, nv);
+                }
+            }
+            *reinterpret_cast<float4 *>(lds + (dst + o)) = nu;
+            *reinterpret_cast<float4 *>(lds + (2 * plane + dst + o)) = nv;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    const int ru = (K & 1) * plane, rv = (2 + (K & 1)) * plane;
+    for (int i = threadIdx.x; i < TH * TW; i += NT) {
+        const int r = i / TW, c = i - r * TW;
+        const int gr = tr * TH + r, gc = tc * TW + c;
+        if (gr < a.rows && gc < a.cols) {
+            const int o = (K + r) * P + K + c + 3;
+            a.out_u[(ptrdiff_t)gr * a.pitch + gc] = lds[ru + o];
+            a.out_v[(ptrdiff_t)gr * a.pitch + gc] = lds[rv + o];
+        }
+    }
+}
+#endif // !GS_TB_OP_ONLY
+
+#if !GS_TB_OP_ONLY
+// ------------------------------------------------------------------------------------
 // LDS-staged variant (one step per launch): the (tile + halo) stencil window of a block is
 // staged in LDS, then every lane reads its 3 x 6 neighbourhood back with ds_read_b128 +
 // two ds_read_b32 per row and species.  Kept as a measured alternative to the register
@@ -900,6 +1036,42 @@ hipError_t GS_SUFFIX(gs_launch_resident)(const GsStepArgs &a, int steps, hipStre
     void *kargs[] = {&args, &steps, &to_out};
     return hipLaunchKernel(reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_resident_k)), dim3(1), dim3(kResidentThreads),
                            kargs, (size_t)cells * 4 * sizeof(float), s);
+}
+
+// K <= kGsTileMaxSteps time steps of a single slab in one launch of gs_run_tile_k (in-planes -> out-planes).
+// `shape`: 0 = 32 x 64 tiles (512 threads), 1 = 16 x 32 (256), 2 = 8 x 32 (128).
+hipError_t GS_SUFFIX(gs_launch_tile)(const GsStepArgs &a, int k, int shape, hipStream_t s, const char **name)
+{
+    static const char *const names[3][2] = {{"tile32x64/" GS_MATH_NAME, "tile32x64/" GS_MATH_NAME ".op"},
+                                            {"tile16x32/" GS_MATH_NAME, "tile16x32/" GS_MATH_NAME ".op"},
+                                            {"tile8x32/" GS_MATH_NAME, "tile8x32/" GS_MATH_NAME ".op"}};
+    static const int th[3] = {32, 16, 8}, tw[3] = {64, 32, 32}, nt[3] = {512, 256, 128};
+    if (a.rows <= 0 || a.cols <= 0 || k < 1 || k > kTileMaxK || shape < 0 || shape > 2 || a.top_present || a.bottom_present)
+        return hipErrorInvalidValue;
+    int fast = a.fast & (GS_MATH_FUSED ? 0 : 3);
+    if (fast != 3) fast = 0; // only the variant for the default parameters is built besides the general one
+    if (name) *name = names[shape][fast ? 1 : 0];
+    const long tiles = (long)((a.rows + th[shape] - 1) / th[shape]) * ((a.cols + tw[shape] - 1) / tw[shape]);
+    if (tiles > 0x7fffffffL) return hipErrorInvalidConfiguration;
+    const void *fn = nullptr;
+#define GS_TILE_FN(S, TH_, TW_, NT_)                                                                          \
+    case S: fn = fast ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_tile_k)<TH_, TW_, NT_, GS_MATH_FUSED ? 0 : 3>)  \
+                      : reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_tile_k)<TH_, TW_, NT_, 0>); break;
+    switch (shape) { GS_TILE_FN(0, 32, 64, 512) GS_TILE_FN(1, 16, 32, 256) GS_TILE_FN(2, 8, 32, 128) }
+#undef GS_TILE_FN
+    const size_t lds = tile_lds_bytes(th[shape], tw[shape], k);
+    if (lds > 64 * 1024) { // more than 64 KB of dynamic LDS needs the opt-in, per device function
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[fast ? 1 : 0]) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)tile_lds_bytes(th[shape], tw[shape], kTileMaxK));
+            if (e != hipSuccess) return e;
+            attr_set[fast ? 1 : 0] = true;
+        }
+    }
+    GsStepArgs args = a;
+    void *kargs[] = {&args, &k};
+    return hipLaunchKernel(fn, dim3((unsigned)tiles), dim3(nt[shape]), kargs, lds, s);
 }
 
 hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const char **name)

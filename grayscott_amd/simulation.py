@@ -93,6 +93,7 @@ class HipArgs:
     cols_per_lane: int = field(default_factory=lambda: _env_int("GS_HIP_COLS_PER_LANE", 0))
     boundary: int = field(default_factory=lambda: _env_int("GS_HIP_BOUNDARY", capi.GS_BOUNDARY_CLIPPED))
     no_tune: int = field(default_factory=lambda: _env_int("GS_HIP_NO_TUNE", 0))
+    tile_shape: int = field(default_factory=lambda: _env_int("GS_HIP_TILE_SHAPE", 0))
     rank: int = 0
     world: int = 1
     unique_id: Optional[bytes] = None
@@ -107,6 +108,7 @@ class HipArgs:
         o.cols_per_lane = self.cols_per_lane
         o.boundary = self.boundary
         o.no_tune = self.no_tune
+        o.tile_shape = self.tile_shape
         return o
 
 

@@ -92,8 +92,12 @@ typedef enum gs_kernel {
     GS_KERNEL_SIMPLE = 1,  /* one thread per cell, global loads only (cross-check kernel)  */
     GS_KERNEL_STREAM = 2,  /* register sliding window, 16-B loads, DPP halo exchange       */
     GS_KERNEL_TB = 3,      /* temporally blocked streaming kernel: fuse_steps steps / launch */
-    GS_KERNEL_LDS = 4      /* LDS-staged (tile + halo) window, one step per launch (measured
+    GS_KERNEL_LDS = 4,     /* LDS-staged (tile + halo) window, one step per launch (measured
                               alternative to STREAM; never chosen by AUTO)                   */
+    GS_KERNEL_TILE = 5     /* gs_run only, single slab: up to 8 steps per launch on LDS-resident tiles
+                              with a K-cell apron (gs_step and slab chains fall back to STREAM / TB);
+                              a measured alternative for mid-size grids, slower than TB there too:
+                              never chosen by AUTO                                            */
 } gs_kernel;
 
 /* Rule on the edges of the global grid.  The reference has two:
@@ -129,7 +133,10 @@ typedef struct gs_options {
     int32_t no_tune;         /* 1 = gs_run never times candidate configurations: it runs the pinned *
                               * values above, a configuration set with gs_ctx_set_tuned, or the     *
                               * untuned defaults                                                   */
-    int32_t reserved[5];
+    int32_t tile_shape;      /* GS_KERNEL_TILE: 1 = 32 x 64 cells per workgroup, 2 = 16 x 32, 3 = 8 x 32; 0 = the  *
+                              * largest that gives every CU a workgroup.  With kernel = TILE, fuse_steps  *
+                              * (1..8) sets the steps per launch                                          */
+    int32_t reserved[4];
 } gs_options;
 
 typedef struct gs_ctx gs_ctx;     /* devices, streams, row partition, RCCL communicator    */

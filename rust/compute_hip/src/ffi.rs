@@ -32,7 +32,8 @@ pub struct gs_options {
     pub cols_per_lane: i32,
     pub boundary: i32,
     pub no_tune: i32,
-    pub reserved: [i32; 5],
+    pub tile_shape: i32,
+    pub reserved: [i32; 4],
 }
 
 #[repr(C)]

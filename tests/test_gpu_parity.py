@@ -250,6 +250,59 @@ def test_row_bands_on_a_large_grid(split):
 
 
 # ---- non-default parameters (CLI overrides -k -f -t, ui/src/lib.rs:51-63) and weights ------
+# ---- GS_KERNEL_TILE: up to 8 steps per launch on LDS-resident tiles (opt-in, measured alternative) ---
+@pytest.mark.parametrize("tile_shape,fuse", [(1, 0), (2, 0), (3, 0), (1, 5), (2, 8), (3, 1)])
+@pytest.mark.parametrize("boundary", [capi.GS_BOUNDARY_CLIPPED, capi.GS_BOUNDARY_ZERO_HALO])
+def test_tile_kernel_bit_exact(boundary, tile_shape, fuse):
+    """gs_run_tile_k (GS_KERNEL_TILE): every shape
+    class -- single cells and lines, one partial tile, tile multiples, ragged right and bottom tiles,
+    several tiles each way -- and step counts that are a short launch, full launches and both."""
+    for shape in [(1, 1), (1, 7), (7, 1), (2, 2), (3, 5), (17, 33), (32, 64), (33, 65), (31, 63), (64, 128), (250, 130),
+                  (65, 129), (96, 200), (40, 1000), (1000, 40), (1, 5000), (5000, 1), (129, 257)]:
+        u0, v0 = stress_fields(shape, 4)
+        for steps in (1, 3, 8, 9, 21):
+            ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True, boundary=boundary)
+            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(kernel=capi.GS_KERNEL_TILE, boundary=boundary,
+                                                                  tile_shape=tile_shape, fuse_steps=fuse))
+            kmax = fuse or (8 if tile_shape == 1 else 4)
+            assert info[0] == ("tile32x64", "tile16x32", "tile8x32")[tile_shape - 1] + "/strict.op", info
+            assert info[1] == (steps + kmax - 1) // kmax, info
+            assert_bits_equal(got_u, ref_u, f"tile U {shape} steps {steps}")
+            assert_bits_equal(got_v, ref_v, f"tile V {shape} steps {steps}")
+
+
+def test_tile_kernel_variants_and_auto_choice():
+    """General weights / dt != 1 (no specialised variant), the fused flavour, Species::new over many
+    launches with mixed entry points; kernel = auto never picks the tile kernel and a slab chain
+    falls back to temporal blocking."""
+    shape = (150, 333)
+    u0, v0 = stress_fields(shape, 6)
+    for params in (Parameters.with_stencil("patrakarttunen"), Parameters(time_step=0.5), Parameters(feed_rate=0.03, kill_rate=0.06)):
+        ref_u, ref_v = oracle.run(u0, v0, 19, params=oracle_params(params), ftz=True)
+        got_u, got_v, info = gpu_run(u0, v0, 19, params=params, args=args(kernel=capi.GS_KERNEL_TILE))
+        assert info[0].startswith("tile") and "/strict" in info[0], info
+        assert info[0].endswith(".op") == (params.weights == Parameters().weights and params.time_step == 1.0), info
+        assert_bits_equal(got_u, ref_u, f"tile U {params}")
+        assert_bits_equal(got_v, ref_v, f"tile V {params}")
+    ref_u, ref_v = oracle.run(u0, v0, 19, ftz=False)
+    got_u, got_v, info = gpu_run(u0, v0, 19, args=args(math=capi.GS_MATH_FUSED, kernel=capi.GS_KERNEL_TILE))
+    assert info[0].startswith("tile") and info[0].endswith("/fused"), info
+    assert np.max(np.abs(got_u - ref_u)) <= 1e-37 and np.max(np.abs(got_v - ref_v)) <= 1e-37
+    sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_TILE))
+    species = sim.make_species([128, 256])
+    sim.perform_steps(species, 41)
+    assert sim.context.info()[0].startswith("tile") and sim.context.info()[0].endswith("/strict.op")
+    for _ in range(3):
+        sim.perform_step(species)
+    sim.perform_steps(species, 16)
+    u, v = oracle.run(*oracle.init_species(128, 256), 60)
+    in_u, in_v, _, _ = species.in_out()
+    assert_bits_equal(in_u.make_scalar_view(sim.context), u, "tile + single steps U")
+    assert_bits_equal(in_v.make_scalar_view(sim.context), v, "tile + single steps V")
+    for kw in (dict(), dict(devices=[0, 0], kernel=capi.GS_KERNEL_TILE), dict(kernel=capi.GS_KERNEL_TB)):
+        assert gpu_run(u0, v0, 8, args=args(**kw))[2][0].startswith("tb-k"), kw
+
+
 # ---- small grids: the whole run in one launch, LDS-resident ----------------------------------------
 @pytest.mark.parametrize("boundary", [capi.GS_BOUNDARY_CLIPPED, capi.GS_BOUNDARY_ZERO_HALO])
 def test_resident_kernel_small_grids(boundary):
@@ -298,7 +351,7 @@ def test_unusual_call_sequences():
     long run on a tiny grid (the uniform state is a fixed point, so the answer is known)."""
     from grayscott_amd import pinned_empty
 
-    for shape in ((24, 40), (96, 200)):                  # resident path / temporally blocked path
+    for shape in ((24, 40), (96, 200), (1100, 1000)):    # resident path / temporally blocked path, small and large
         sim = Simulation.new(Parameters(), args())
         species = sim.make_species(list(shape))
         sim.perform_steps(species, 0)                    # no-op, result stays in the input slot
@@ -358,7 +411,7 @@ def test_short_alternating_runs_finish_tuning_without_restarting():
     """A driver loop with 32 steps per image on TWO grids in turn: each shape's tuning advances in its
     own state (it used to restart whenever the other shape ran), short calls never wait for their
     timing windows, and both shapes end up tuned; the bits stay those of the oracle throughout."""
-    sim = Simulation.new(Parameters(), args())
+    sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_TB))
     shapes = [(96, 200), (64, 700)]
     state = {s: stress_fields(s, 23) for s in shapes}
     species = {s: species_from_arrays(sim, *state[s]) for s in shapes}
@@ -390,7 +443,7 @@ def test_no_tune_option_and_handed_in_configuration():
     u0, v0 = stress_fields(shape, 3)
     ref_u, ref_v = oracle.run(u0, v0, 47, ftz=True)
     for kw in (dict(), dict(devices=[0, 0, 0])):
-        sim = Simulation.new(Parameters(), args(no_tune=1, **kw))
+        sim = Simulation.new(Parameters(), args(no_tune=1, kernel=capi.GS_KERNEL_TB, **kw))
         sp = species_from_arrays(sim, u0, v0)
         sim.perform_steps(sp, 30)
         assert "@" not in sim.context.info()[0]
@@ -413,7 +466,7 @@ def test_no_tune_option_and_handed_in_configuration():
 def test_alternating_shapes_on_one_context_keep_their_tuning():
     """The on-line choice is remembered per shape: going back to a grid does not tune again, and the
     results stay bit-exact throughout."""
-    sim = Simulation.new(Parameters(), args())
+    sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_TB))
     shapes = [(96, 200), (64, 700)]
     state = {s: stress_fields(s, 15) for s in shapes}
     species = {s: species_from_arrays(sim, *state[s]) for s in shapes}

@@ -13,7 +13,6 @@ time -- and then reports the median of 15 timed iterations.
 import argparse
 import os
 
-os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # the CPU port forks/joins per step: do not spin
 import statistics
 import sys
 import time
@@ -26,13 +25,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--graph", action="store_true", help="gs_options.use_graph = 1")
+    ap.add_argument("--kernel", type=int, default=0, help="gs_kernel to force (0 = auto, 3 = temporal blocking, 5 = LDS tiles)")
+    ap.add_argument("--kmin", type=int, default=3)
+    ap.add_argument("--kmax", type=int, default=11)
     a = ap.parse_args()
     steps_list = [1, 16, 256]
     print("| rows x cols | " + " | ".join(f"HIP {s} steps" for s in steps_list) +
           (" | CPU port 16 steps |" if a.cpu else " |"))
     print("|---|" + "---|" * (len(steps_list) + (1 if a.cpu else 0)))
-    sim = Simulation.new(Parameters(), HipArgs(devices=[0], use_graph=1 if a.graph else 0))
-    for k in range(3, 12):
+    sim = Simulation.new(Parameters(), HipArgs(devices=[0], use_graph=1 if a.graph else 0, kernel=a.kernel))
+    for k in range(a.kmin, a.kmax + 1):
         size = 2 ** k
         shape = (size, 2 * size)
         species = sim.make_species(shape)
@@ -69,6 +71,7 @@ def main():
                 times.append(time.perf_counter() - t0)
             row.append(f"{cells * 16 / statistics.median(times) / 1e6:.1f}")
             cpu.close()
+        row.append(sim.context.info()[0])
         print("| " + " | ".join(row) + " |", flush=True)
     print("\n(Mcells x steps / s; HIP timings include the host-side enqueue and one sync per iteration, "
           "as criterion's `b.iter(|| workload(...))` would)")
