@@ -36,7 +36,7 @@ EXPORTS = (
     "gs_field_finalize", "gs_field_upload", "gs_field_download", "gs_field_device_ptr",
     "gs_step", "gs_run", "gs_sync", "gs_timer_start", "gs_timer_stop", "gs_ctx_info",
     "gs_host_alloc", "gs_host_free", "gs_field_download_async", "gs_download_wait",
-    "gs_ctx_get_tuned", "gs_ctx_set_tuned", "gs_ctx_comm_info",
+    "gs_ctx_get_tuned", "gs_ctx_set_tuned", "gs_ctx_comm_info", "gs_field_colormap",
 )
 
 
@@ -129,6 +129,7 @@ def load() -> ctypes.CDLL:
         "gs_ctx_get_tuned": (i32, [vp, u64, u64, P(i32), P(i32), P(i32)]),
         "gs_ctx_set_tuned": (i32, [vp, u64, u64, i32, i32, i32]),
         "gs_ctx_comm_info": (i32, [vp, P(i32), P(i32), P(i32)]),
+        "gs_field_colormap": (i32, [vp, vp, f32, vp, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

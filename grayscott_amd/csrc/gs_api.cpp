@@ -1504,6 +1504,35 @@ int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host)
     return GS_OK;
 }
 
+int32_t gs_field_colormap(gs_ctx *ctx, gs_field *f, float scale, const uint8_t *palette_rgb, int32_t n_colors,
+                          uint8_t *host_rgb)
+{
+    if (!ctx || !f || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad argument");
+    if (!palette_rgb || n_colors < 1 || n_colors > 65536) return fail(GS_ERR_INVALID, "bad palette (%d colours)", n_colors);
+    GS_TRY(sync_all(ctx));
+    if (f->rows == 0 || f->cols == 0) return GS_OK; // nothing to paint (host may be null)
+    if (!host_rgb) return fail(GS_ERR_INVALID, "bad argument");
+    const uint64_t first = f->s.front().g_row0;
+    for (size_t i = 0; i < f->s.size(); ++i) {
+        SlabRt &sl = ctx->slabs[i];
+        const FieldSlab &fs = f->s[i];
+        GS_HIP(hipSetDevice(sl.device));
+        const size_t bytes = (size_t)fs.rows * f->cols * 3;
+        uint8_t *dev = nullptr;
+        GS_HIP(hipMalloc(reinterpret_cast<void **>(&dev), bytes + (size_t)n_colors * 3));
+        uint8_t *pal = dev + bytes;
+        hipError_t e = hipMemcpyAsync(pal, palette_rgb, (size_t)n_colors * 3, hipMemcpyHostToDevice, sl.compute);
+        if (e == hipSuccess)
+            e = gs_launch_colormap(fs.row0, f->pitch, fs.rows, (int32_t)f->cols, scale, pal, n_colors, dev, sl.compute);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(host_rgb + (fs.g_row0 - first) * f->cols * 3, dev, bytes, hipMemcpyDeviceToHost, sl.compute);
+        if (e == hipSuccess) e = hipStreamSynchronize(sl.compute);
+        (void)hipFree(dev);
+        if (e != hipSuccess) return fail(GS_ERR_HIP, "colour mapping failed: %s", hipGetErrorString(e));
+    }
+    return GS_OK;
+}
+
 int32_t gs_download_wait(gs_ctx *ctx)
 {
     if (!ctx) return fail(GS_ERR_INVALID, "null context");

@@ -63,5 +63,7 @@ GS_DECLARE_LAUNCHERS(fused)
 const void *gs_tb_op_kernel_strict(int k, int fast, int cpl);
 
 // Plane utilities (math-agnostic, defined once in gs_util_kernels.hip).
+hipError_t gs_launch_colormap(const float *row0, int32_t pitch, int32_t rows, int32_t cols, float scale,
+                              const uint8_t *palette, int32_t n, uint8_t *rgb, hipStream_t s);
 hipError_t gs_launch_fill_rect(float *row0, int32_t pitch, int32_t r0, int32_t r1, int32_t c0,
                                int32_t c1, float value, hipStream_t s);

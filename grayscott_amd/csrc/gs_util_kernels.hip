@@ -1,5 +1,6 @@
 // gs_util_kernels.hip -- plane utilities that are not arithmetic-flavour dependent.
 //
+// colormap is the per-pixel work of data-to-pics (V plane -> RGB8 through a palette).
 // fill_rect backs Concentration::zeros / ones / fill_slice
 // (/root/reference/data/src/concentration/mod.rs:205-243) directly in HBM: the seed
 // rectangle of Species::new (:36-59) is written on the device, there is no host staging
@@ -14,7 +15,43 @@ __global__ __launch_bounds__(256) void gs_fill_rect_k(float *row0, int pitch, in
     const int c = c0 + blockIdx.x * 256 + threadIdx.x;
     if (c < c1) row0[(ptrdiff_t)r * pitch + c] = value;
 }
+// Colour mapping of a result plane, data-to-pics/src/main.rs:139-144:
+//     let color = ui::GRADIENT.eval_continuous((ui::AMPLITUDE_SCALE * value).into());
+// i.e. an f32 multiply, widened to f64, handed to colorous 1.0.16 (Cargo.lock:389-392; the crate is not
+// vendored).  Its sequential gradients are a port of d3-scale-chromatic's `ramp`: a table of n colours
+// indexed with floor(t * n) clamped to [0, n - 1]; a NaN or negative t lands on entry 0 (saturating
+// float -> usize cast).  The table itself is DATA handed in by the caller (for the reference: the 256
+// entries of colorous::INFERNO), so only that indexing rule is restated here.
+__global__ __launch_bounds__(256) void gs_colormap_k(const float *row0, int pitch, int rows, int cols, float scale,
+                                                     const uint8_t *palette, int n, uint8_t *rgb)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    const double t = (double)(scale * row0[(ptrdiff_t)r * pitch + c]);
+    const double x = floor(t * (double)n);
+    const int i = !(x >= 0.0) ? 0 : (x >= (double)n ? n - 1 : (int)x);
+    uint8_t *px = rgb + ((size_t)r * cols + c) * 3;
+    px[0] = palette[3 * i];
+    px[1] = palette[3 * i + 1];
+    px[2] = palette[3 * i + 2];
+}
 } // namespace
+
+hipError_t gs_launch_colormap(const float *row0, int32_t pitch, int32_t rows, int32_t cols, float scale,
+                              const uint8_t *palette, int32_t n, uint8_t *rgb, hipStream_t s)
+{
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    for (int32_t b0 = 0; b0 < rows; b0 += 32768) { // gridDim.y is limited to 65535
+        const int32_t nb = rows - b0 > 32768 ? 32768 : rows - b0;
+        const float *src = row0 + (ptrdiff_t)b0 * pitch;
+        uint8_t *dst = rgb + (size_t)b0 * cols * 3;
+        void *kargs[] = {&src, &pitch, const_cast<int32_t *>(&nb), &cols, &scale, &palette, &n, &dst};
+        hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(&gs_colormap_k), dim3((unsigned)((cols + 255) / 256), (unsigned)nb),
+                                       dim3(256), kargs, 0, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 hipError_t gs_launch_fill_rect(float *row0, int32_t pitch, int32_t r0, int32_t r1, int32_t c0,
                                int32_t c1, float value, hipStream_t s)

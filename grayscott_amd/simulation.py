@@ -294,6 +294,20 @@ class HipConcentration:
         capi.check(context._lib.gs_field_download_async(context.handle, self.handle,
                                                         target.ctypes.data_as(ctypes.c_void_p)))
 
+    def colormap(self, context: HipContext, palette: np.ndarray, scale: float = 2.0) -> np.ndarray:
+        """The pixels ``data-to-pics`` makes of this plane (data-to-pics/src/main.rs:139-144):
+        ``palette[clamp(floor(scale * value * n), 0, n - 1)]`` as uint8 ``[rows, cols, 3]``; ``palette`` is
+        ``[n, 3]`` uint8 (the reference: the 256 colours of ``colorous::INFERNO``), ``scale`` its
+        ``AMPLITUDE_SCALE`` = 1 / 0.5 (ui/src/lib.rs:117-123)."""
+        palette = np.ascontiguousarray(palette, np.uint8)
+        assert palette.ndim == 2 and palette.shape[1] == 3 and len(palette) >= 1
+        r0, r1 = self.local_rows()
+        out = np.empty((r1 - r0, self._shape[1], 3), np.uint8)
+        capi.check(context._lib.gs_field_colormap(context.handle, self.handle, scale,
+                                                  palette.ctypes.data_as(ctypes.c_void_p), len(palette),
+                                                  out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def destroy(self) -> None:
         if self._h and self._ctx._h:
             self._ctx._lib.gs_field_destroy(self._ctx._h, self._h)

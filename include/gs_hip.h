@@ -227,6 +227,15 @@ int32_t gs_host_free(void *p);
 int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host);
 int32_t gs_download_wait(gs_ctx *ctx);
 
+/* The per-pixel work of data-to-pics (data-to-pics/src/main.rs:139-144, ui/src/lib.rs:113-123): paint this
+ * process's rows of `f` (the reference paints the V plane) into dense RGB8 [rows, cols, 3] through a
+ * palette of n_colors RGB triples: pixel = palette[clamp(floor((double)(scale * value) * n_colors), 0,
+ * n_colors - 1)], NaN -> entry 0 -- the rule of colorous' sequential gradients (the reference uses
+ * colorous::INFERNO with scale = AMPLITUDE_SCALE = 1 / 0.5).  The palette is data: a binding passes the
+ * 256 entries of the gradient it wants.  Blocking, like gs_field_download. */
+int32_t gs_field_colormap(gs_ctx *ctx, gs_field *f, float scale, const uint8_t *palette_rgb, int32_t n_colors,
+                          uint8_t *host_rgb);
+
 /* Device-side stopwatch on the context's compute stream(s) (HIP events): start/stop
  * bracket enqueued work; elapsed is the maximum over local slabs, in milliseconds. */
 int32_t gs_timer_start(gs_ctx *ctx);

@@ -95,4 +95,12 @@ extern "C" {
     pub fn gs_sync(ctx: *mut gs_ctx) -> i32;
     pub fn gs_field_download_async(ctx: *mut gs_ctx, f: *mut gs_field, host: *mut f32) -> i32;
     pub fn gs_download_wait(ctx: *mut gs_ctx) -> i32;
+    pub fn gs_field_colormap(
+        ctx: *mut gs_ctx,
+        f: *mut gs_field,
+        scale: f32,
+        palette_rgb: *const u8,
+        n_colors: i32,
+        host_rgb: *mut u8,
+    ) -> i32;
 }

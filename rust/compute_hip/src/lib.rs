@@ -275,6 +275,18 @@ impl Simulation {
 }
 
 impl HipConcentration {
+    /// The per-pixel work of data-to-pics (data-to-pics/src/main.rs:139-144) on the device: paints this
+    /// plane into dense RGB8 `[rows, cols, 3]` through `palette` (e.g. the 256 colours
+    /// `(0..256).map(|i| ui::GRADIENT.eval_rational(i, 256))` flattened to r, g, b bytes) with
+    /// `scale` = `ui::AMPLITUDE_SCALE`.
+    pub fn colormap(&mut self, context: &mut HipContext, scale: Precision, palette: &[u8], rgb: &mut [u8]) -> Result<(), HipError> {
+        assert_eq!(palette.len() % 3, 0);
+        assert_eq!(rgb.len(), self.shape[0] * self.shape[1] * 3);
+        check(unsafe {
+            ffi::gs_field_colormap(context.0, self.field, scale, palette.as_ptr(), (palette.len() / 3) as i32, rgb.as_mut_ptr())
+        })
+    }
+
     /// Counterpart of `ImageConcentration::write_scalar_view_after`
     /// (data/src/concentration/gpu/image/mod.rs:196-206), used with `prepare_steps` by a driver loop
     /// like simulate/src/main.rs:99-106: enqueue the download of this plane behind the steps already
