@@ -848,10 +848,12 @@ int32_t tune_online(Run &r, int fuse)
                     (large && (t.cpl == 1 || t.rpu < 32)))
                     continue;
             }
-            // short calls get shorter windows rather than no tuning at all; with less than 3 passes
-            // left the candidate waits for the next gs_run
+            // short calls get shorter windows rather than no tuning at all, but not shorter than two
+            // passes per window: single-pass windows are noise, and a mis-tuned configuration is worse
+            // than the untuned default (criterion grid, 16-step calls: profiles/r02_criterion_grid.md).
+            // With less than 5 passes left the candidate waits for the next gs_run.
             const uint64_t passes_left = (r.steps - r.n) / (uint64_t)t.k;
-            while (t.reps > 1 && passes_left < (uint64_t)(2 * t.reps + 1)) --t.reps;
+            while (t.reps > 2 && passes_left < (uint64_t)(2 * t.reps + 1)) --t.reps;
             if (passes_left < (uint64_t)(2 * t.reps + 1)) {
                 out_of_steps = true;
                 break;

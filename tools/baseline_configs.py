@@ -13,7 +13,6 @@ import subprocess
 import sys
 import time
 
-os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle  # noqa: E402
 from grayscott_amd import HipArgs, Parameters, Simulation  # noqa: E402
@@ -55,16 +54,18 @@ def cpu_rows():
           f"and L2/2 = {l2 // 2} B (compute/block/src/default.rs:30-48).\n")
     print("| CPU backend | grid | threads | steps timed | Mcells×steps/s |")
     print("|---|---|---|---|---|")
-    u0, v0 = oracle.init_species(1080, 1920)
-    for nthreads in (1, threads):
-        steps = 4 if nthreads == 1 else 24
-        oracle.run(u0, v0, 1, nthreads=nthreads)
-        t0 = time.perf_counter()
-        oracle.run(u0, v0, steps, nthreads=nthreads)
-        dt = time.perf_counter() - t0
-        print(f"| strict naive restatement (`oracle/gs_oracle.c`) | 1080 x 1920 | {nthreads} | {steps} | {1080 * 1920 * steps / dt / 1e6:,.0f} |",
-              flush=True)
-    for rows, cols, steps in ((1080, 1920, 200), (2048, 4096, 60), (4096, 4096, 30), (16384, 16384, 6)):
+    for rows, cols in ((1080, 1920), (2048, 4096), (4096, 4096), (16384, 16384)):
+        u0, v0 = oracle.init_species(rows, cols)
+        for nthreads in ((1, threads) if rows == 1080 else (threads,)):
+            steps = max(2, (4 if nthreads == 1 else 48) * 1080 * 1920 // (rows * cols))
+            oracle.run(u0, v0, 1, nthreads=nthreads)
+            t0 = time.perf_counter()
+            oracle.run(u0, v0, steps, nthreads=nthreads)
+            dt = time.perf_counter() - t0
+            print(f"| strict naive restatement (`oracle/gs_oracle.c`) | {rows} x {cols} | {nthreads} | {steps} | "
+                  f"{rows * cols * steps / dt / 1e6:,.0f} |", flush=True)
+        del u0, v0
+    for rows, cols, steps in ((1080, 1920, 2000), (2048, 4096, 400), (4096, 4096, 200), (16384, 16384, 40)):
         sim = cpu_parallel.ParallelSimulation(rows, cols, num_threads=threads, ftz=True)
         sim.perform_steps(2)
         t0 = time.perf_counter()
