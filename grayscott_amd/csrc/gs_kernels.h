@@ -32,6 +32,9 @@ struct GsStepArgs {
     // `big_chunks` chunks have rows_per_unit rows, the rest `small_rpu` rows, so that the units
     // dispatched last are short and the launch drains quickly.
     int32_t big_chunks, small_rpu;
+    // second taper level: after `mid_chunks` chunks of small_rpu rows the rest have tiny_rpu rows
+    // (mid_chunks < 0: one level only)
+    int32_t mid_chunks, tiny_rpu;
     // Parameter-specialised variants of the temporal-blocking kernel (bit-identical results, fewer
     // instructions): bit 0 = the four side weights w[0][1], w[1][0], w[1][2], w[2][1] are exactly
     // 0.5f, bit 1 = dt is exactly 1.0f.  Both hold for Parameters::default().

@@ -37,6 +37,9 @@
 // GS_TB_ABLATE (1: no memory traffic, 2: no arithmetic) are timing experiments only
 // (profiles/r01_sweeps.md, "ablation"); the shipped build never defines it.
 #include "gs_kernels.h"
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
 
 #ifndef GS_MATH_FUSED
 #error "compile with -DGS_MATH_FUSED=0 or 1"
@@ -709,7 +712,9 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     const int unit = blockIdx.x * 4 + wave;
     const int rpu = a.rows_per_unit;
     const int small = a.small_rpu;
-    const int chunks_a = a.big_chunks + (a.ra1 - a.ra0 - a.big_chunks * rpu + small - 1) / small;
+    const int rest_a = a.ra1 - a.ra0 - a.big_chunks * rpu; // rows of range a behind the full-height chunks
+    const int chunks_a = a.mid_chunks < 0 ? a.big_chunks + (rest_a + small - 1) / small
+                                          : a.big_chunks + a.mid_chunks + (rest_a - a.mid_chunks * small + a.tiny_rpu - 1) / a.tiny_rpu;
     const int chunks_b = (a.rb1 - a.rb0 + rpu - 1) / rpu;
     const int chunks = chunks_a + chunks_b;
     if (unit >= chunks * strips) return; // wave-uniform
@@ -740,9 +745,12 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         if (cc < a.big_chunks) {
             ur0 = a.ra0 + cc * rpu;
             ur1 = ur0 + rpu;
-        } else { // tapered tail: short units are dispatched last
+        } else if (a.mid_chunks < 0 || cc < a.big_chunks + a.mid_chunks) { // tapered tail: short units are dispatched last
             ur0 = a.ra0 + a.big_chunks * rpu + (cc - a.big_chunks) * small;
             ur1 = min(ur0 + small, a.ra1);
+        } else { // ... and the shortest ones at the very end
+            ur0 = a.ra0 + a.big_chunks * rpu + a.mid_chunks * small + (cc - a.big_chunks - a.mid_chunks) * a.tiny_rpu;
+            ur1 = min(ur0 + a.tiny_rpu, a.ra1);
         }
     } else {
         ur0 = a.rb0 + (chunk - chunks_a) * rpu;
@@ -1114,28 +1122,7 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     const long rows_a = (long)a.ra1 - a.ra0;
     const long W = tb_cols_per_wave(k, cpl);
     const long strips = (a.cols + W - 1) / W;
-    // Tapered tail: when the launch has many more units than the chip has wave slots (2048 at
-    // 2 waves per SIMD), the last ~2 x 2048 units are cut to a quarter of the unit height, so that
-    // the drain phase at the end of the launch is short (dependent launches cannot overlap).
-    long big_chunks = rows_a > 0 ? rows_a / rpu : 0, small = rpu;
-    const long quarter = rpu / 4 >= 2L * k ? rpu / 4 : 2L * k;
-    if (quarter < rpu && (rows_a / rpu) * strips >= 4 * 2048) {
-        const long small_chunks = (2 * 2048 + strips - 1) / strips;
-        long small_rows = small_chunks * quarter;
-        if (small_rows > rows_a / 4) small_rows = rows_a / 4;
-        big_chunks = (rows_a - small_rows) / rpu;
-        small = quarter;
-    }
-    const long chunks_a = rows_a > 0 ? big_chunks + (rows_a - big_chunks * rpu + small - 1) / small : 0;
-    const long chunks = chunks_a + ((long)(a.rb1 - a.rb0) + rpu - 1) / rpu;
-    if (chunks <= 0) return hipSuccess;
-    if (k > a.ghost && (a.top_present || a.bottom_present)) return hipErrorInvalidValue;
-    const long blocks = (chunks * strips + 3) / 4;
-    if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
-    GsStepArgs args = a;
-    args.big_chunks = (int32_t)big_chunks;
-    args.small_rpu = (int32_t)small;
-    void *kargs[] = {&args};
+    // Kernel entry first: the taper below needs its occupancy.
     const void *fn = nullptr;
 #define GS_TB_CASE(KK, CC)                                                                      \
     case (KK) * 8 + (CC): fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<KK, 0, CC>); break;
@@ -1152,6 +1139,68 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     }
 #undef GS_TB_CASE
     if (!fn) return hipErrorInvalidValue;
+    // Tapered tail (consecutive passes are dependent launches that cannot overlap, so the drain phase
+    // of a launch is idle time): when the launch is at least two rounds of the chip's wave slots, the
+    // last round of units is an eighth as tall as the others and the round before it half as tall.
+    // Measured at 16384^2 (profiles/r02_sweeps.md, section 7): +1...2 % over round 1's single level
+    // (the last two rounds at a quarter), and unit heights of 128-192 rows become usable.
+    int waves = 0;
+    {
+        static const void *occ_fn[32];
+        static int occ_waves[32], occ_n = 0; // waves per SIMD of each kernel entry (256-thread blocks: one wave per SIMD)
+        static std::mutex occ_lock;          // contexts on different threads launch through here
+        std::lock_guard<std::mutex> occ_guard(occ_lock);
+        for (int i = 0; i < occ_n; ++i)
+            if (occ_fn[i] == fn) waves = occ_waves[i];
+        if (!waves) {
+            // waves per SIMD the register file allows: 512 registers per lane, allocated in steps of 8
+            // (MI355X_MICROARCH.md, register files); the kernels use no LDS memory
+            hipFuncAttributes attr;
+            waves = 2;
+            if (hipFuncGetAttributes(&attr, fn) == hipSuccess && attr.numRegs > 0) {
+                const int alloc = ((attr.numRegs + 7) / 8) * 8;
+                waves = 512 / alloc > 8 ? 8 : (512 / alloc < 1 ? 1 : 512 / alloc);
+            } else {
+                (void)hipGetLastError();
+            }
+            if (std::getenv("GS_HIP_TRACE_TUNER"))
+                std::fprintf(stderr, "gs_hip: kernel entry %p: %d registers -> %d waves per SIMD\n", fn, attr.numRegs, waves);
+            if (occ_n < 32) { occ_fn[occ_n] = fn; occ_waves[occ_n++] = waves; }
+        }
+    }
+    const long slots = 1024L * waves; // 256 CUs x 4 SIMDs x waves per SIMD
+    long big_chunks = rows_a > 0 ? rows_a / rpu : 0, small = rpu, mid_chunks = -1, tiny = rpu;
+    if ((rows_a / rpu) * strips >= 2 * slots) {
+        const long h1 = rpu / 2 >= 2L * k ? rpu / 2 : 2L * k;
+        const long h2 = rpu / 8 >= 2L * k ? rpu / 8 : 2L * k;
+        const long c1 = (slots + strips - 1) / strips, c2 = (slots + strips - 1) / strips;
+        const long rows12 = c1 * h1 + c2 * h2;
+        if (h1 < rpu && rows12 <= rows_a / 3) {
+            big_chunks = (rows_a - rows12) / rpu;
+            small = h1;
+            if (h2 < h1) {
+                tiny = h2;
+                mid_chunks = (rows_a - big_chunks * rpu - c2 * h2 + h1 - 1) / h1;
+                while (mid_chunks > 0 && rows_a - big_chunks * rpu - mid_chunks * h1 < 0) --mid_chunks;
+                if (mid_chunks < 0) mid_chunks = 0;
+            }
+        }
+    }
+    const long rest = rows_a - big_chunks * rpu;
+    const long chunks_a = rows_a <= 0 ? 0
+                        : mid_chunks < 0 ? big_chunks + (rest + small - 1) / small
+                                         : big_chunks + mid_chunks + (rest - mid_chunks * small + tiny - 1) / tiny;
+    const long chunks = chunks_a + ((long)(a.rb1 - a.rb0) + rpu - 1) / rpu;
+    if (chunks <= 0) return hipSuccess;
+    if (k > a.ghost && (a.top_present || a.bottom_present)) return hipErrorInvalidValue;
+    const long blocks = (chunks * strips + 3) / 4;
+    if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
+    GsStepArgs args = a;
+    args.big_chunks = (int32_t)big_chunks;
+    args.small_rpu = (int32_t)small;
+    args.mid_chunks = (int32_t)mid_chunks;
+    args.tiny_rpu = (int32_t)tiny;
+    void *kargs[] = {&args};
     return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), kargs, 0, s);
 }
 
