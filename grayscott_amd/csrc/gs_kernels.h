@@ -35,6 +35,9 @@ struct GsStepArgs {
     // second taper level: after `mid_chunks` chunks of small_rpu rows the rest have tiny_rpu rows
     // (mid_chunks < 0: one level only)
     int32_t mid_chunks, tiny_rpu;
+    // how many of range a's LAST chunks are dispatched first (the chunks a bottom grid edge can touch;
+    // at least 1), filled in by the launcher
+    int32_t bot_first;
     // Parameter-specialised variants of the temporal-blocking kernel (bit-identical results, fewer
     // instructions): bit 0 = the four side weights w[0][1], w[1][0], w[1][2], w[2][1] are exactly
     // 0.5f, bit 1 = dt is exactly 1.0f.  Both hold for Parameters::default().

@@ -229,7 +229,11 @@ __device__ __forceinline__ RowW widen(const RowIn &r)
 // (wave-uniform), `la` / `ra` whether the left / right neighbour column is absent (per lane).
 // FAST (strict build, chosen by the host from the parameters; see gs_kernels.h): bit 0 = the four
 // side weights are exactly 0.5f (interior cells fold `sub, mul` into half_diff), bit 1 = dt == 1.
-template <bool EDGE, int FAST = 0, typename Row = RowW>
+// ZH (EDGE flavour): the boundary rule, -1 = read a.zero_halo at run time, 0 = clipped window, 1 = zero
+// halo.  The temporally blocked kernel branches on the rule ONCE per unit and instantiates both: with
+// a run-time test inside the cell the compiler hoists the other rule's selects above the branch
+// (speculative execution) and every edge cell pays for both rules.
+template <bool EDGE, int FAST = 0, typename Row = RowW, int ZH = -1>
 __device__ __forceinline__ void cell(const GsStepArgs &a, const Row &m, const Row &z,
                                      const Row &p, int k, bool mrow, bool prow, uint32_t la, uint32_t ra,
                                      float &out_u, float &out_v)
@@ -254,19 +258,19 @@ __device__ __forceinline__ void cell(const GsStepArgs &a, const Row &m, const Ro
         GS_TAP(acc_u, a.w[2][0], p.u[k - 1], u); GS_TAP(acc_v, a.w[2][0], p.v[k - 1], v);
         GS_TAP(acc_u, a.w[2][1], p.u[k], u);     GS_TAP(acc_v, a.w[2][1], p.v[k], v);
         GS_TAP(acc_u, a.w[2][2], p.u[k + 1], u); GS_TAP(acc_v, a.w[2][2], p.v[k + 1], v);
-    } else if (a.zero_halo) {
+    } else if (ZH < 0 ? a.zero_halo != 0 : ZH != 0) {
         // GS_BOUNDARY_ZERO_HALO: all nine taps, centred weights; a neighbour outside the grid reads
-        // as 0 (per-lane column masks, wave-uniform row flags).
+        // as 0: per-lane column masks, and for an absent row a wave-uniform all-zeros word ANDed in (a
+        // `present ? x : 0` select would be a v_cndmask_b32, ~10x a plain VALU op on gfx950).
 #define GS_ROW_TAPS_Z(R, WI, PRESENT, WITH_CENTRE)                                             \
     {                                                                                          \
-        const float ul = (PRESENT) ? blend(la, 0.0f, R.u[k - 1]) : 0.0f;                       \
-        const float vl = (PRESENT) ? blend(la, 0.0f, R.v[k - 1]) : 0.0f;                       \
-        const float ur = (PRESENT) ? blend(ra, 0.0f, R.u[k + 1]) : 0.0f;                       \
-        const float vr = (PRESENT) ? blend(ra, 0.0f, R.v[k + 1]) : 0.0f;                       \
+        const uint32_t keep = (PRESENT) ? 0xffffffffu : 0u;                                    \
+        const float ul = blend(keep & ~la, R.u[k - 1], 0.0f), vl = blend(keep & ~la, R.v[k - 1], 0.0f); \
+        const float ur = blend(keep & ~ra, R.u[k + 1], 0.0f), vr = blend(keep & ~ra, R.v[k + 1], 0.0f); \
         GS_TAP(acc_u, a.w[WI][0], ul, u); GS_TAP(acc_v, a.w[WI][0], vl, v);                    \
         if (WITH_CENTRE) {                                                                     \
-            GS_TAP(acc_u, a.w[WI][1], (PRESENT) ? R.u[k] : 0.0f, u);                           \
-            GS_TAP(acc_v, a.w[WI][1], (PRESENT) ? R.v[k] : 0.0f, v);                           \
+            GS_TAP(acc_u, a.w[WI][1], blend(keep, R.u[k], 0.0f), u);                           \
+            GS_TAP(acc_v, a.w[WI][1], blend(keep, R.v[k], 0.0f), v);                           \
         }                                                                                      \
         GS_TAP(acc_u, a.w[WI][2], ur, u); GS_TAP(acc_v, a.w[WI][2], vr, v);                    \
     }
@@ -278,12 +282,18 @@ __device__ __forceinline__ void cell(const GsStepArgs &a, const Row &m, const Ro
         // Weight row of the centre row: 1 normally, 0 when the row above is clipped away.
         // Weight column of the centre column: 1 normally, 0 when the left column is clipped.
         // An absent left/right neighbour is replaced by the centre value (adds +0).
+        // Weight row of the centre row: 1 normally, 0 when the row above is clipped away.
+        // Weight column of the centre column: 1 normally, 0 when the left column is clipped.
+        // An absent left/right neighbour is replaced by the centre value (adds +0).
         const int zi = mrow ? 1 : 0;
+        const float wsel[3][3] = {{a.w[0][0], a.w[0][1], a.w[0][2]},
+                                  {a.w[zi][0], a.w[zi][1], a.w[zi][2]},
+                                  {a.w[zi + 1][0], a.w[zi + 1][1], a.w[zi + 1][2]}};
 #define GS_ROW_TAPS(R, WI, WITH_CENTRE)                                                        \
     {                                                                                          \
-        const float wl = a.w[WI][0];                                                           \
-        const float wc = blend(la, a.w[WI][0], a.w[WI][1]);                                    \
-        const float wr = blend(la, a.w[WI][1], a.w[WI][2]);                                    \
+        const float wl = wsel[WI][0];                                                          \
+        const float wc = blend(la, wsel[WI][0], wsel[WI][1]);                                  \
+        const float wr = blend(la, wsel[WI][1], wsel[WI][2]);                                  \
         const float ul = blend(la, u, R.u[k - 1]), vl = blend(la, v, R.v[k - 1]);              \
         const float ur = blend(ra, u, R.u[k + 1]), vr = blend(ra, v, R.v[k + 1]);              \
         GS_TAP(acc_u, wl, ul, u); GS_TAP(acc_v, wl, vl, v);                                    \
@@ -291,8 +301,8 @@ __device__ __forceinline__ void cell(const GsStepArgs &a, const Row &m, const Ro
         GS_TAP(acc_u, wr, ur, u); GS_TAP(acc_v, wr, vr, v);                                    \
     }
         if (mrow) GS_ROW_TAPS(m, 0, true)
-        GS_ROW_TAPS(z, zi, false)
-        if (prow) GS_ROW_TAPS(p, zi + 1, true)
+        GS_ROW_TAPS(z, 1, false)
+        if (prow) GS_ROW_TAPS(p, 2, true)
 #undef GS_ROW_TAPS
     }
     react<(FAST & 2) != 0>(a, u, v, acc_u, acc_v, out_u, out_v);
@@ -546,7 +556,9 @@ __device__ __forceinline__ float shift_from_prev_lane(float own)
 // lane i receives lane i+1's `own` (lane 63: lane 0's)
 __device__ __forceinline__ float shift_from_next_lane(float own)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane_id() + 1) & 63) << 2, __builtin_bit_cast(int, own)));
+    // the previous lane's address + 8: the add folds into the instruction's offset field (one address
+    // register for both directions), and the crossbar takes the lane index modulo 64
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((((lane_id() - 1) & 63) << 2) + 8, __builtin_bit_cast(int, own)));
 }
 #else
 // DPP wave shifts with bound_ctrl (0 for the lane without a source), no `old` operand.
@@ -592,7 +604,59 @@ __device__ __forceinline__ void store_cols(float *p, const float (&in)[CPL])
     *reinterpret_cast<typename VecOf<CPL>::type *>(p) = x;
 }
 
-template <int K, bool EDGE, int FAST, int CPL>
+// Buffer-instruction forms of the same accesses: address = 128-bit resource in SGPRs (base pointer of
+// the unit's first row) + per-lane byte offset (one VGPR for the whole march) + scalar byte offset of
+// the row.  Interior units use them (GS_TB_BUFFER_OPS): no 64-bit per-lane addresses to keep or to
+// recompute per row.  The resource is raw (stride 0) with the widest record count: these units never
+// step outside their planes, so nothing relies on the range check.
+#ifndef GS_TB_BUFFER_OPS
+#define GS_TB_BUFFER_OPS 1
+#endif
+// GS_TB_LATE_FETCH: 1 = the K = 4 / 2-columns-per-lane march requests its next level-0 row at the END of a
+// tick (2 rows in flight while the levels are computed, not 3).  With that, the buffer addressing above
+// and the edge path's column masks kept as lane masks in SGPRs, the whole kernel entry -- general path
+// included -- fits 126 registers: 4 waves per SIMD instead of 3, +9 % at 16384^2 (profiles/r02_sweeps.md,
+// section 8).  Other layouts keep the early request: it is worth 2-6 % where the occupancy does not change.
+#ifndef GS_TB_LATE_FETCH
+#define GS_TB_LATE_FETCH 1
+#endif
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+}
+template <int CPL>
+__device__ __forceinline__ void load_cols_buf(__amdgpu_buffer_rsrc_t r, int voff, int soff, float (&out)[CPL])
+{
+    if constexpr (CPL == 4) {
+        const auto x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        __builtin_memcpy(out, &x, sizeof x);
+    } else if constexpr (CPL == 2) {
+        const auto x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        __builtin_memcpy(out, &x, sizeof x);
+    } else {
+        const auto x = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+        __builtin_memcpy(out, &x, sizeof x);
+    }
+}
+template <int CPL>
+__device__ __forceinline__ void store_cols_buf(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&in)[CPL])
+{
+    if constexpr (CPL == 4) {
+        decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) x;
+        __builtin_memcpy(&x, in, sizeof x);
+        __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, 0);
+    } else if constexpr (CPL == 2) {
+        decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0)) x;
+        __builtin_memcpy(&x, in, sizeof x);
+        __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
+    } else {
+        decltype(__builtin_amdgcn_raw_buffer_load_b32(r, 0, 0, 0)) x;
+        __builtin_memcpy(&x, in, sizeof x);
+        __builtin_amdgcn_raw_buffer_store_b32(x, r, voff, soff, 0);
+    }
+}
+
+template <int K, bool EDGE, int FAST, int CPL, int ZH = -1>
 __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, int strip, int lane)
 {
     constexpr int S = tb_sacrificial_lanes(K, CPL), W = tb_cols_per_wave(K, CPL);
@@ -600,21 +664,41 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
     const bool load_ok = !EDGE || (c >= 0 && c < a.pitch);
     const bool store_ok = (lane >= S) && (lane < 64 - S) && (!EDGE || c < a.pitch);
     const ptrdiff_t pitch = a.pitch;
+#if !GS_TB_BUFFER_OPS
     const float *bu = a.in_u + c, *bv = a.in_v + c;
+#endif
 
     // Level-0 rows needed: [ur0 - K, ur1 + K) clipped to the rows that exist: the slab's own
     // rows plus, on a slab seam, `ghost` rows of the neighbouring slab.
     const int row_lo = max(ur0 - K, a.top_present ? -a.ghost : 0);
     const int row_hi = min(ur1 + K - 1, a.bottom_present ? a.rows + a.ghost - 1 : a.rows - 1);
+    constexpr bool BUF = GS_TB_BUFFER_OPS != 0;
+    constexpr bool LATE = GS_TB_LATE_FETCH && K == 4 && CPL == 2;
+    // resources based at the unit's first input row (row_lo) / first output row (ur0): scalar row offsets
+    // stay small and positive whatever the size of the plane
+    const __amdgpu_buffer_rsrc_t ru = plane_rsrc(a.in_u + (ptrdiff_t)row_lo * pitch), rv = plane_rsrc(a.in_v + (ptrdiff_t)row_lo * pitch);
+    const __amdgpu_buffer_rsrc_t wu = plane_rsrc(a.out_u + (ptrdiff_t)ur0 * pitch), wv = plane_rsrc(a.out_v + (ptrdiff_t)ur0 * pitch);
+    const int voff = c * (int)sizeof(float), pitch_bytes = a.pitch * (int)sizeof(float);
     auto fetch = [&](int row) {
         RowQ<CPL> r;
         const int rr = min(max(row, row_lo), row_hi);
+        if constexpr (BUF) {
+            if (load_ok) {
+                load_cols_buf<CPL>(ru, voff, (rr - row_lo) * pitch_bytes, r.u);
+                load_cols_buf<CPL>(rv, voff, (rr - row_lo) * pitch_bytes, r.v);
+            } else {
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) { r.u[i] = 0.f; r.v[i] = 0.f; }
+            }
+            return r;
+        }
 #if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 1 /* experiment: no loads (VALU-only timing) */
         const float fr = (float)rr * a.du + (float)lane;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) { r.u[i] = fr + a.dv * (float)i; r.v[i] = fr * a.dv - a.feed * (float)i; }
         return r;
 #endif
+#if !GS_TB_BUFFER_OPS
         if (load_ok) {
             load_cols<CPL>(bu + (ptrdiff_t)rr * pitch, r.u);
             load_cols<CPL>(bv + (ptrdiff_t)rr * pitch, r.v);
@@ -622,6 +706,7 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
 #pragma unroll
             for (int i = 0; i < CPL; ++i) { r.u[i] = 0.f; r.v[i] = 0.f; }
         }
+#endif
         return r;
     };
 
@@ -630,12 +715,12 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
     uint32_t la[CPL], ra[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
+        // Plain comparisons: the compiler keeps them as lane masks in SGPR pairs and selects with
+        // v_cndmask_b32.  Round 1 kept opaque all-ones / all-zeros words in VGPRs and blended bitwise
+        // (v_cndmask is ~10x a plain VALU op on gfx950), which made the edge units 0.5 % of a pass
+        // faster -- and cost the 3 registers that kept the whole kernel at 3 waves per SIMD.
         la[k] = (EDGE && k == 0 && c == 0) ? 0xffffffffu : 0u;
         ra[k] = (EDGE && (c + k + 1 >= a.cols)) ? 0xffffffffu : 0u;
-        if (EDGE) { // keep the masks opaque, or the compiler turns every blend back into v_cndmask
-            if (k == 0) asm volatile("" : "+v"(la[k]));
-            asm volatile("" : "+v"(ra[k]));
-        }
     }
 
     RowT<CPL> w[K][3]; // w[j][slot]: level-j rows, newest in slot (tick % 3)
@@ -658,7 +743,7 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
             if (tick < nticks) {
                 const int l0 = first + tick; // level-0 row entering the pipeline
                 w[0][s3] = widen_tb<CPL>(q[s3].u, q[s3].v);
-                q[s3] = fetch(l0 + 3);
+                if constexpr (!LATE) q[s3] = fetch(l0 + 3);
 #pragma unroll
                 for (int j = 1; j <= K; ++j) {
                     const int row = l0 - j; // level-j row produced in this tick
@@ -678,7 +763,7 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
 #else
 #pragma unroll
                         for (int k = 0; k < CPL; ++k)
-                            cell<EDGE, FAST>(a, m, z, p, k + 1, mrow, prow, la[k], ra[k], nu[k], nv[k]);
+                            cell<EDGE, FAST, RowT<CPL>, ZH>(a, m, z, p, k + 1, mrow, prow, la[k], ra[k], nu[k], nv[k]);
 #endif
 #if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 1
                         if (j < K) {
@@ -689,11 +774,17 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                             w[j < K ? j : 0][s3] = widen_tb<CPL>(nu, nv);
                         } else if (store_ok) {
 #endif
-                            store_cols<CPL>(a.out_u + (ptrdiff_t)row * pitch + c, nu);
-                            store_cols<CPL>(a.out_v + (ptrdiff_t)row * pitch + c, nv);
+                            if constexpr (BUF) {
+                                store_cols_buf<CPL>(wu, voff, (row - ur0) * pitch_bytes, nu);
+                                store_cols_buf<CPL>(wv, voff, (row - ur0) * pitch_bytes, nv);
+                            } else {
+                                store_cols<CPL>(a.out_u + (ptrdiff_t)row * pitch + c, nu);
+                                store_cols<CPL>(a.out_v + (ptrdiff_t)row * pitch + c, nv);
+                            }
                         }
                     }
                 }
+                if constexpr (LATE) q[s3] = fetch(l0 + 3); // two rows in flight while the levels are computed
             }
         }
     }
@@ -718,11 +809,12 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     const int chunks_b = (a.rb1 - a.rb0 + rpu - 1) / rpu;
     const int chunks = chunks_a + chunks_b;
     if (unit >= chunks * strips) return; // wave-uniform
-    // Dispatch order.  Units on a global edge take the general path, which is about twice as
-    // slow (per-lane selects); a slow unit that starts in the last round of a launch stretches
+    // Dispatch order.  Units on a global edge take the general path, which is 1.6x as slow
+    // (per-lane selects); a slow unit that starts in the last round of a launch stretches
     // its tail, so all edge units go first: the left-most and right-most strips of every chunk,
-    // then (below) the first and last chunk, then everything else.  A strip is a right-edge strip
-    // when its window, sacrificial lanes included, reaches the last column.
+    // then (below) the last `bot_first` and the first chunks of range a -- the ones a grid edge can
+    // touch -- then everything else.  A strip is a right-edge strip when its window, sacrificial
+    // lanes included, reaches the last column.
     const int er = ((strips - 1) * W + S * CPL >= a.cols && strips >= 2) ? 2 : 1; // edge strips on the right
     const int ne = 1 + er;                                                        // ... per chunk
     int chunk, strip;
@@ -740,8 +832,9 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     }
     int ur0, ur1;
     if (chunk < chunks_a) {
-        // the last chunk of the range first, then chunks 0, 1, 2, ... (top / bottom edge chunks)
-        const int cc = chunk == 0 ? chunks_a - 1 : chunk - 1;
+        // the last chunks of the range first, then chunks 0, 1, 2, ... (bottom / top edge chunks)
+        const int bf = min(a.bot_first, chunks_a);
+        const int cc = chunk < bf ? chunks_a - 1 - chunk : chunk - bf;
         if (cc < a.big_chunks) {
             ur0 = a.ra0 + cc * rpu;
             ur1 = ur0 + rpu;
@@ -758,10 +851,12 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     }
     const bool edge = (strip == 0) || ((strip + 1) * W + S * CPL >= a.cols) ||
                       (ur0 - K < 0 && !a.top_present) || (ur1 + K > a.rows && !a.bottom_present);
-    if (edge)
-        tb_march<K, true, FAST, CPL>(a, ur0, ur1, strip, lane);
-    else
+    if (!edge)
         tb_march<K, false, FAST, CPL>(a, ur0, ur1, strip, lane);
+    else if (a.zero_halo) // one branch per unit, one instantiation per boundary rule (see cell<>)
+        tb_march<K, true, FAST, CPL, 1>(a, ur0, ur1, strip, lane);
+    else
+        tb_march<K, true, FAST, CPL, 0>(a, ur0, ur1, strip, lane);
 }
 
 #if !GS_TB_OP_ONLY
@@ -1139,35 +1234,34 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     }
 #undef GS_TB_CASE
     if (!fn) return hipErrorInvalidValue;
+    // waves per SIMD the register file allows a kernel entry: 512 registers per lane, allocated in steps
+    // of 8 (MI355X_MICROARCH.md, register files); the kernels use no LDS memory
+    auto waves_of = [](const void *f) -> int {
+        static const void *occ_fn[64];
+        static int occ_waves[64], occ_n = 0;
+        static std::mutex occ_lock; // contexts on different threads launch through here
+        std::lock_guard<std::mutex> occ_guard(occ_lock);
+        for (int i = 0; i < occ_n; ++i)
+            if (occ_fn[i] == f) return occ_waves[i];
+        hipFuncAttributes attr;
+        int w = 2;
+        if (hipFuncGetAttributes(&attr, f) == hipSuccess && attr.numRegs > 0) {
+            const int alloc = ((attr.numRegs + 7) / 8) * 8;
+            w = 512 / alloc > 8 ? 8 : (512 / alloc < 1 ? 1 : 512 / alloc);
+        } else {
+            (void)hipGetLastError();
+        }
+        if (std::getenv("GS_HIP_TRACE_TUNER"))
+            std::fprintf(stderr, "gs_hip: kernel entry %p: %d registers -> %d waves per SIMD\n", f, attr.numRegs, w);
+        if (occ_n < 64) { occ_fn[occ_n] = f; occ_waves[occ_n++] = w; }
+        return w;
+    };
+    const int waves = waves_of(fn);
     // Tapered tail (consecutive passes are dependent launches that cannot overlap, so the drain phase
     // of a launch is idle time): when the launch is at least two rounds of the chip's wave slots, the
     // last round of units is an eighth as tall as the others and the round before it half as tall.
     // Measured at 16384^2 (profiles/r02_sweeps.md, section 7): +1...2 % over round 1's single level
     // (the last two rounds at a quarter), and unit heights of 128-192 rows become usable.
-    int waves = 0;
-    {
-        static const void *occ_fn[32];
-        static int occ_waves[32], occ_n = 0; // waves per SIMD of each kernel entry (256-thread blocks: one wave per SIMD)
-        static std::mutex occ_lock;          // contexts on different threads launch through here
-        std::lock_guard<std::mutex> occ_guard(occ_lock);
-        for (int i = 0; i < occ_n; ++i)
-            if (occ_fn[i] == fn) waves = occ_waves[i];
-        if (!waves) {
-            // waves per SIMD the register file allows: 512 registers per lane, allocated in steps of 8
-            // (MI355X_MICROARCH.md, register files); the kernels use no LDS memory
-            hipFuncAttributes attr;
-            waves = 2;
-            if (hipFuncGetAttributes(&attr, fn) == hipSuccess && attr.numRegs > 0) {
-                const int alloc = ((attr.numRegs + 7) / 8) * 8;
-                waves = 512 / alloc > 8 ? 8 : (512 / alloc < 1 ? 1 : 512 / alloc);
-            } else {
-                (void)hipGetLastError();
-            }
-            if (std::getenv("GS_HIP_TRACE_TUNER"))
-                std::fprintf(stderr, "gs_hip: kernel entry %p: %d registers -> %d waves per SIMD\n", fn, attr.numRegs, waves);
-            if (occ_n < 32) { occ_fn[occ_n] = fn; occ_waves[occ_n++] = waves; }
-        }
-    }
     const long slots = 1024L * waves; // 256 CUs x 4 SIMDs x waves per SIMD
     long big_chunks = rows_a > 0 ? rows_a / rpu : 0, small = rpu, mid_chunks = -1, tiny = rpu;
     if ((rows_a / rpu) * strips >= 2 * slots) {
@@ -1200,6 +1294,18 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     args.small_rpu = (int32_t)small;
     args.mid_chunks = (int32_t)mid_chunks;
     args.tiny_rpu = (int32_t)tiny;
+    // Row range of chunk cc of range a (the kernel's formulas); the last `bot` chunks -- the ones the
+    // grid's bottom edge can touch, at least one -- are dispatched first, then the chunks from the top.
+    auto chunk_rows = [&](long cc, long &r0, long &r1) {
+        if (cc < big_chunks) { r0 = a.ra0 + cc * rpu; r1 = r0 + rpu; }
+        else if (mid_chunks < 0 || cc < big_chunks + mid_chunks) { r0 = a.ra0 + big_chunks * rpu + (cc - big_chunks) * small; r1 = r0 + small < a.ra1 ? r0 + small : a.ra1; }
+        else { r0 = a.ra0 + big_chunks * rpu + mid_chunks * small + (cc - big_chunks - mid_chunks) * tiny; r1 = r0 + tiny < a.ra1 ? r0 + tiny : a.ra1; }
+    };
+    long bot = 0, r0 = 0, r1 = 0;
+    if (!a.bottom_present)
+        for (; bot < chunks_a; ++bot) { chunk_rows(chunks_a - 1 - bot, r0, r1); if (!(r1 + k > a.rows)) break; }
+    if (bot < 1 && chunks_a > 0) bot = 1; // the launch order of earlier rounds: the last chunk first
+    args.bot_first = (int32_t)bot;
     void *kargs[] = {&args};
     return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), kargs, 0, s);
 }

@@ -1,0 +1,14 @@
+#!/bin/bash
+set -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/r02_run14
+mkdir -p "$OUT"
+cd "$ROOT"
+for v in nb main i4 i3 i2; do
+  echo "== variant $v" | tee -a "$OUT/sweep.log"
+  lib=$ROOT/grayscott_amd/variants/libgs_hip_$v.so
+  [ $v = main ] && lib=$ROOT/grayscott_amd/libgs_hip.so
+  GS_HIP_LIBRARY=$lib timeout -k 10 300 python tools/sweep.py --steps 96 --rounds 5 \
+     rows_per_block=192,cols_per_lane=2 rows_per_block=128,cols_per_lane=2 rows_per_block=96,cols_per_lane=2 rows_per_block=64,cols_per_lane=2 rows_per_block=128,cols_per_lane=1 2>&1 | grep -v "^grid" | tee -a "$OUT/sweep.log"
+done
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_timed_sizes.py -m gpu -x -q 2>&1 | tail -2 | tee -a "$OUT/sweep.log"
