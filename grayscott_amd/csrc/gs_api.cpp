@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -361,6 +362,47 @@ long tb_strips(int32_t cols, int fuse, int cpl)
     return (cols + w - 1) / w;
 }
 
+// GsStepArgs::fast for this context's parameters: bit 0 = the four side weights are 0.5, bit 1 = dt == 1.
+int fast_of(const gs_ctx *ctx)
+{
+    int fast = 0;
+    if (!ctx->o.general_kernels) {
+        const float(*w)[3] = ctx->p.w;
+        if (w[0][1] == 0.5f && w[1][0] == 0.5f && w[1][2] == 0.5f && w[2][1] == 0.5f) fast |= 1;
+        if (ctx->p.dt == 1.0f) fast |= 2;
+    }
+    return fast;
+}
+
+// Unit heights that make a launch of the temporally blocked kernel exactly `r` rounds of the chip's wave
+// slots (256 CUs x 4 SIMDs x the kernel entry's waves per SIMD): strips x chunks <= r x slots with the
+// chunks as short as that allows.  A launch that misses such a height by one chunk runs a nearly empty
+// extra round: at 4096^2 with 2 columns per lane 36 rows give 749 k Mcells x steps/s, 32 rows 677 k, 40
+// rows 687 k (profiles/r02_sweeps.md, section 9).  From two rounds up the launcher tapers the last two
+// rounds (an eighth and a half as tall: 0.625 rounds' worth of rows), which the formula accounts for.
+// Writes up to `max` heights, by ascending number of rounds (descending height); returns their number.
+int fit_heights(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse, int cpl, int fast, int *out, int max)
+{
+    const int slots = ctx->o.math == GS_MATH_FUSED ? gs_tb_wave_slots_fused(fuse, fast, cpl) : gs_tb_wave_slots_strict(fuse, fast, cpl);
+    const long strips = tb_strips(cols, fuse, cpl);
+    if (slots <= 0 || strips <= 0) return 0;
+    const long per_round = slots / strips; // chunks per round
+    if (per_round < 1) return 0;
+    const long per_round_up = (slots + strips - 1) / strips; // what the launcher tapers (gs_launch_tb)
+    int n = 0;
+    // r = 1, 2: un-tapered launches of r full rounds; r >= 3: (r - 1) full rounds + the two tapered ones
+    // (the launcher tapers from two rounds' worth of full-height units up)
+    for (int r = 1; r <= 8 && n < max; ++r) {
+        const double chunks = r < 3 ? (double)(per_round * r) : (double)(per_round * (r - 1)) + 0.625 * (double)per_round_up;
+        long h = (long)std::ceil((double)rows / chunks - 1e-9);
+        if (h < 2L * fuse) break;
+        if (h > rows) h = rows;
+        if (n > 0 && out[n - 1] == (int)h) continue;
+        out[n++] = (int)h;
+    }
+    return n;
+}
+
 // `rows` = rows of one slab.  Slabs of an uneven partition differ by one row: same configuration.
 bool tuned_for(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse)
 {
@@ -386,8 +428,21 @@ int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fu
 {
     if (ctx->o.rows_per_block > 0) return ctx->o.rows_per_block;
     if (tuned_for(ctx, rows, cols, fuse)) return ctx->tuned_rpu;
-    const long strips = fuse > 1 ? tb_strips(cols, fuse, pick_cols_per_lane(ctx, rows, cols, fuse)) : (cols + 255) / 256;
+    const int cpl = pick_cols_per_lane(ctx, rows, cols, fuse);
+    const long strips = fuse > 1 ? tb_strips(cols, fuse, cpl) : (cols + 255) / 256;
     const long want = fuse > 1 ? 32L * fuse : 16;
+    if (fuse > 1) {
+        // A launch of a whole number of rounds of the chip's wave slots (fit_heights): of the heights of
+        // at least 4K rows (at most a third of a unit's rows recomputed) the one nearest to 32K, else the
+        // single-round height.
+        int fit[8];
+        const int nf = fit_heights(ctx, rows, cols, fuse, cpl, fast_of(ctx), fit, 8);
+        long best = 0;
+        for (int i = 0; i < nf; ++i)
+            if (fit[i] >= 4 * fuse && (best == 0 || std::labs(fit[i] - want) < std::labs(best - want))) best = fit[i];
+        if (best == 0 && nf > 0 && fit[0] >= 2 * fuse) best = fit[0];
+        if (best > 0) return (int32_t)best;
+    }
     long rpu = ((long)rows * strips + 16383) / 16384; // keep >= 16384 waves per launch when possible
     if (rpu > want) rpu = want;
     // small grids are bound by the length of a wave's march: units of K rows there (runs 120-122)
@@ -455,11 +510,7 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
     // both operands are normal numbers, so forming it here in f32 gives the same bits.
     a.feed_plus_kill = ctx->p.feed + ctx->p.kill;
     a.dt = ctx->p.dt;
-    if (!ctx->o.general_kernels) {
-        const float(*w)[3] = ctx->p.w;
-        if (w[0][1] == 0.5f && w[1][0] == 0.5f && w[1][2] == 0.5f && w[2][1] == 0.5f) a.fast |= 1;
-        if (ctx->p.dt == 1.0f) a.fast |= 2;
-    }
+    a.fast = fast_of(ctx);
     return a;
 }
 
@@ -720,23 +771,53 @@ void remember_tuned(gs_ctx *ctx, const gs_ctx::Tuned &t)
 //   redundant rows per unit can cost more than the extra passes; phase D (columns per lane not
 //   pinned): 1 and 4 columns per lane -- more, narrower waves for small grids; fewer, wider ones
 //   with 16-byte accesses -- with a few unit heights each (large grids skip the candidates that
-//   would only multiply tiny units).  A-C run with 2 columns per lane.
+//   would only multiply tiny units).  A-C run with the untuned layout (pick_cols_per_lane).  Every list
+//   of heights is a fixed ladder plus the heights that make a launch a whole number of rounds of the
+//   chip's wave slots (fit_heights).
 int32_t tune_online(Run &r, int fuse)
 {
     gs_ctx *ctx = r.ctx;
     const gs_field *f = r.u[0];
-    static const int cand[] = {2, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192};
+    static const int cand0[] = {2, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192};
     static const int altk[] = {3, 2};
-    static const int candn[] = {2, 4, 8, 16, 32, 64, 128};
-    static const int cpls[] = {1, 4};
-    const int ncand = (int)(sizeof cand / sizeof cand[0]);
-    const int nalt = 0; // phase B is empty
-    const int nk = ctx->o.fuse_steps == 0 ? (int)(sizeof altk / sizeof altk[0]) : 0;
+    static const int candn0[] = {2, 4, 8, 16, 32, 64, 128};
     const uint64_t cells = f->rows * f->cols;
-    const int ncandn = (int)(sizeof candn / sizeof candn[0]);
-    const int nn = ctx->o.cols_per_lane == 0 ? ncandn * (int)(sizeof cpls / sizeof cpls[0]) : 0;
     const bool large = cells > (1ull << 26);
     const int user_cpl = ctx->o.cols_per_lane;
+    // phases A-C run with the layout an untuned context would use (1 column per lane on small grids, 2
+    // from about 1024 x 2048 up), so that what a run is given before its tuning has finished is already
+    // close; phase D tries the other two layouts
+    const int base_cpl = user_cpl ? user_cpl : ((long)f->rows * tb_strips((int32_t)f->cols, fuse, 2) / (8L * fuse) >= 2048 ? 2 : 1);
+    const int cpls[2] = {base_cpl == 1 ? 2 : 1, base_cpl == 4 ? 2 : 4};
+    const int fast = fast_of(ctx);
+    // a fixed ladder of heights plus the heights that make a launch a whole number of rounds of the
+    // chip's wave slots (fit_heights), in ascending order without near-duplicates
+    auto heights = [&](const int *fixed, int nfixed, int k, int cpl) {
+        std::vector<int> v(fixed, fixed + nfixed);
+        int fit[8];
+        // (not on large grids: from about six rounds per launch up the rate is flat in the unit height --
+        // 16384^2: 0.2469-0.2511 ms per step from 96 to 214 rows -- and every candidate costs passes)
+        const int nf = large ? 0 : fit_heights(ctx, (int32_t)f->rows, (int32_t)f->cols, k, cpl, fast, fit, 8);
+        for (int i = 0; i < nf; ++i) {
+            bool dup = false;
+            for (int x : v) dup = dup || x == fit[i];
+            if (!dup) v.push_back(fit[i]);
+        }
+        std::sort(v.begin(), v.end());
+        return v;
+    };
+    const std::vector<int> cand = heights(cand0, (int)(sizeof cand0 / sizeof cand0[0]), fuse, base_cpl);
+    const int ncand = (int)cand.size();
+    const int nalt = 0; // phase B is empty
+    const int nk = ctx->o.fuse_steps == 0 ? (int)(sizeof altk / sizeof altk[0]) : 0;
+    // phase D: (columns per lane, height) pairs.  (Fitted for `fuse` steps per pass whatever phase C kept:
+    // the list must not change while the phases advance, and the strips of 3 and 4 fused steps are the
+    // same width for 2 and 4 columns per lane, 58 against 56 columns for 1.)
+    std::vector<int> d_cpl, d_rpu;
+    if (user_cpl == 0)
+        for (int c : cpls)
+            for (int h : heights(candn0, (int)(sizeof candn0 / sizeof candn0[0]), fuse, c)) { d_cpl.push_back(c); d_rpu.push_back(h); }
+    const int nn = (int)d_cpl.size();
     // timed passes per candidate: short passes need more of them for a stable comparison
     const int reps = cells >= (1ull << 27) ? 2 : (cells >= (1ull << 24) ? 6 : 8);
     constexpr int kMaxBatch = (int)(sizeof(gs_ctx::Tuning::batch) / sizeof(gs_ctx::Trial));
@@ -827,7 +908,7 @@ int32_t tune_online(Run &r, int fuse)
         int nb = 0;
         int32_t st = GS_OK;
         for (; tu->next < phase_end[phase] && nb < kMaxBatch && st == GS_OK; ++tu->next) {
-            gs_ctx::Trial t{0, V0, fuse, user_cpl ? user_cpl : 2, reps};
+            gs_ctx::Trial t{0, V0, fuse, base_cpl, reps};
             const int i = tu->next - (phase ? phase_end[phase - 1] : 0);
             if (phase == 0) {
                 t.rpu = cand[i];
@@ -840,8 +921,8 @@ int32_t tune_online(Run &r, int fuse)
                 t.k = altk[i];
                 if (t.rpu == 0 || t.k >= fuse) continue;
             } else { // phase 3 (phase 1 has no candidates)
-                t.cpl = cpls[i / ncandn];
-                t.rpu = candn[i % ncandn];
+                t.cpl = d_cpl[i];
+                t.rpu = d_rpu[i];
                 t.V = tu->best_split;
                 t.k = tu->best_k;
                 if (tu->best_rpu == 0 || (t.rpu < 2 * t.k && cells > (1ull << 21)) || (uint64_t)t.rpu > f->rows ||

@@ -59,7 +59,8 @@ struct GsStepArgs {
     hipError_t gs_launch_resident_##SUFFIX(const GsStepArgs &a, int steps, hipStream_t s, const char **name); \
     hipError_t gs_launch_tb_##SUFFIX(const GsStepArgs &a, int k, hipStream_t s, const char **name); \
     hipError_t gs_launch_tile_##SUFFIX(const GsStepArgs &a, int k, int shape, hipStream_t s, const char **name); \
-    hipError_t gs_launch_lds_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name);
+    hipError_t gs_launch_lds_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name);  \
+    int gs_tb_wave_slots_##SUFFIX(int k, int fast, int cpl);
 
 GS_DECLARE_LAUNCHERS(strict)
 GS_DECLARE_LAUNCHERS(fused)

@@ -682,22 +682,27 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
     auto fetch = [&](int row) {
         RowQ<CPL> r;
         const int rr = min(max(row, row_lo), row_hi);
-        if constexpr (BUF) {
-            if (load_ok) {
-                load_cols_buf<CPL>(ru, voff, (rr - row_lo) * pitch_bytes, r.u);
-                load_cols_buf<CPL>(rv, voff, (rr - row_lo) * pitch_bytes, r.v);
-            } else {
-#pragma unroll
-                for (int i = 0; i < CPL; ++i) { r.u[i] = 0.f; r.v[i] = 0.f; }
-            }
-            return r;
-        }
 #if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 1 /* experiment: no loads (VALU-only timing) */
         const float fr = (float)rr * a.du + (float)lane;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) { r.u[i] = fr + a.dv * (float)i; r.v[i] = fr * a.dv - a.feed * (float)i; }
         return r;
 #endif
+        if constexpr (BUF) {
+            if (load_ok) {
+#if defined(GS_TB_ABLATE) && GS_TB_ABLATE >= 3 /* experiment: every load hits the cache (8 rows per unit) */
+                load_cols_buf<CPL>(ru, voff, ((rr - row_lo) & 7) * pitch_bytes, r.u);
+                load_cols_buf<CPL>(rv, voff, ((rr - row_lo) & 7) * pitch_bytes, r.v);
+#else
+                load_cols_buf<CPL>(ru, voff, (rr - row_lo) * pitch_bytes, r.u);
+                load_cols_buf<CPL>(rv, voff, (rr - row_lo) * pitch_bytes, r.v);
+#endif
+            } else {
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) { r.u[i] = 0.f; r.v[i] = 0.f; }
+            }
+            return r;
+        }
 #if !GS_TB_BUFFER_OPS
         if (load_ok) {
             load_cols<CPL>(bu + (ptrdiff_t)rr * pitch, r.u);
@@ -775,8 +780,13 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                         } else if (store_ok) {
 #endif
                             if constexpr (BUF) {
+#if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 4 /* experiment: ... and every store goes to the same 8 rows */
+                                store_cols_buf<CPL>(wu, voff, ((row - ur0) & 7) * pitch_bytes, nu);
+                                store_cols_buf<CPL>(wv, voff, ((row - ur0) & 7) * pitch_bytes, nv);
+#else
                                 store_cols_buf<CPL>(wu, voff, (row - ur0) * pitch_bytes, nu);
                                 store_cols_buf<CPL>(wv, voff, (row - ur0) * pitch_bytes, nv);
+#endif
                             } else {
                                 store_cols<CPL>(a.out_u + (ptrdiff_t)row * pitch + c, nu);
                                 store_cols<CPL>(a.out_v + (ptrdiff_t)row * pitch + c, nv);
@@ -1194,30 +1204,9 @@ hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const
 }
 
 // K fused steps over the row ranges of GsStepArgs; on slab seams the ghost rows must be K deep.
-hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, const char **name)
+// Kernel entry for k fused steps, specialisation `fast` (already reduced to {0, 1, 3}) and cpl columns per lane.
+static const void *tb_entry(int k, int fast, int cpl)
 {
-    // "cN": N columns per lane (4 = the wide layout); ".op": the variant specialised for the
-    // default (Oono-Puri) side weights, with or without dt == 1
-#define GS_TB_NAMES(C)                                                                          \
-    {{"tb-k1" C "/" GS_MATH_NAME, "tb-k2" C "/" GS_MATH_NAME, "tb-k3" C "/" GS_MATH_NAME, "tb-k4" C "/" GS_MATH_NAME}, \
-     {"tb-k1" C "/" GS_MATH_NAME ".op", "tb-k2" C "/" GS_MATH_NAME ".op", "tb-k3" C "/" GS_MATH_NAME ".op",            \
-      "tb-k4" C "/" GS_MATH_NAME ".op"}}
-    static const char *const names[3][2][4] = {GS_TB_NAMES("c1"), GS_TB_NAMES("c2"), GS_TB_NAMES("")};
-#undef GS_TB_NAMES
-    if (k < 1 || k > 4 || a.cols <= 0 || a.rows_per_unit <= 0) return hipErrorInvalidValue;
-    const int cpl = a.cpl == 0 ? 4 : a.cpl;
-    if (cpl != 1 && cpl != 2 && cpl != 4) return hipErrorInvalidValue;
-    // The fused build has no use for bit 0 (its taps are sub + fma already) and measured slower
-    // with bit 1 (profiles/r01_sweeps.md, runs 48/49): it always runs the general variant.  dt == 1
-    // alone (fast == 2) is not worth a variant either.
-    int fast = a.fast & (GS_MATH_FUSED ? 0 : 3);
-    if (fast == 2) fast = 0;
-    if (name) *name = names[cpl == 1 ? 0 : (cpl == 2 ? 1 : 2)][fast ? 1 : 0][k - 1];
-    const long rpu = a.rows_per_unit;
-    const long rows_a = (long)a.ra1 - a.ra0;
-    const long W = tb_cols_per_wave(k, cpl);
-    const long strips = (a.cols + W - 1) / W;
-    // Kernel entry first: the taper below needs its occupancy.
     const void *fn = nullptr;
 #define GS_TB_CASE(KK, CC)                                                                      \
     case (KK) * 8 + (CC): fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<KK, 0, CC>); break;
@@ -1233,30 +1222,75 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
         }
     }
 #undef GS_TB_CASE
+    return fn;
+}
+
+// Waves per SIMD the register file allows a kernel entry: 512 registers per lane, allocated in steps
+// of 8 (MI355X_MICROARCH.md, register files); the kernels use no LDS memory.
+static int tb_waves_of(const void *f)
+{
+    static const void *occ_fn[64];
+    static int occ_waves[64], occ_n = 0;
+    static std::mutex occ_lock; // contexts on different threads launch through here
+    std::lock_guard<std::mutex> occ_guard(occ_lock);
+    for (int i = 0; i < occ_n; ++i)
+        if (occ_fn[i] == f) return occ_waves[i];
+    hipFuncAttributes attr;
+    attr.numRegs = 0;
+    int w = 2;
+    if (hipFuncGetAttributes(&attr, f) == hipSuccess && attr.numRegs > 0) {
+        const int alloc = ((attr.numRegs + 7) / 8) * 8;
+        w = 512 / alloc > 8 ? 8 : (512 / alloc < 1 ? 1 : 512 / alloc);
+    } else {
+        (void)hipGetLastError();
+    }
+    if (std::getenv("GS_HIP_TRACE_TUNER"))
+        std::fprintf(stderr, "gs_hip: kernel entry %p: %d registers -> %d waves per SIMD\n", f, attr.numRegs, w);
+    if (occ_n < 64) { occ_fn[occ_n] = f; occ_waves[occ_n++] = w; }
+    return w;
+}
+
+static int tb_reduce_fast(int fast)
+{
+    // The fused build has no use for bit 0 (its taps are sub + fma already) and measured slower
+    // with bit 1 (profiles/r01_sweeps.md, runs 48/49): it always runs the general variant.  dt == 1
+    // alone (fast == 2) is not worth a variant either.
+    fast &= GS_MATH_FUSED ? 0 : 3;
+    return fast == 2 ? 0 : fast;
+}
+
+// Wave slots of the chip for the kernel entry a launch with these parameters would use (the tuner's
+// "a launch of exactly r rounds" candidates, gs_api.cpp); 0 = no such entry.
+int GS_SUFFIX(gs_tb_wave_slots)(int k, int fast, int cpl)
+{
+    if (k < 1 || k > 4 || (cpl != 1 && cpl != 2 && cpl != 4)) return 0;
+    const void *fn = tb_entry(k, tb_reduce_fast(fast), cpl);
+    return fn ? 1024 * tb_waves_of(fn) : 0;
+}
+
+hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, const char **name)
+{
+    // "cN": N columns per lane (4 = the wide layout); ".op": the variant specialised for the
+    // default (Oono-Puri) side weights, with or without dt == 1
+#define GS_TB_NAMES(C)                                                                          \
+    {{"tb-k1" C "/" GS_MATH_NAME, "tb-k2" C "/" GS_MATH_NAME, "tb-k3" C "/" GS_MATH_NAME, "tb-k4" C "/" GS_MATH_NAME}, \
+     {"tb-k1" C "/" GS_MATH_NAME ".op", "tb-k2" C "/" GS_MATH_NAME ".op", "tb-k3" C "/" GS_MATH_NAME ".op",            \
+      "tb-k4" C "/" GS_MATH_NAME ".op"}}
+    static const char *const names[3][2][4] = {GS_TB_NAMES("c1"), GS_TB_NAMES("c2"), GS_TB_NAMES("")};
+#undef GS_TB_NAMES
+    if (k < 1 || k > 4 || a.cols <= 0 || a.rows_per_unit <= 0) return hipErrorInvalidValue;
+    const int cpl = a.cpl == 0 ? 4 : a.cpl;
+    if (cpl != 1 && cpl != 2 && cpl != 4) return hipErrorInvalidValue;
+    const int fast = tb_reduce_fast(a.fast);
+    if (name) *name = names[cpl == 1 ? 0 : (cpl == 2 ? 1 : 2)][fast ? 1 : 0][k - 1];
+    const long rpu = a.rows_per_unit;
+    const long rows_a = (long)a.ra1 - a.ra0;
+    const long W = tb_cols_per_wave(k, cpl);
+    const long strips = (a.cols + W - 1) / W;
+    // Kernel entry first: the taper below needs its occupancy.
+    const void *fn = tb_entry(k, fast, cpl);
     if (!fn) return hipErrorInvalidValue;
-    // waves per SIMD the register file allows a kernel entry: 512 registers per lane, allocated in steps
-    // of 8 (MI355X_MICROARCH.md, register files); the kernels use no LDS memory
-    auto waves_of = [](const void *f) -> int {
-        static const void *occ_fn[64];
-        static int occ_waves[64], occ_n = 0;
-        static std::mutex occ_lock; // contexts on different threads launch through here
-        std::lock_guard<std::mutex> occ_guard(occ_lock);
-        for (int i = 0; i < occ_n; ++i)
-            if (occ_fn[i] == f) return occ_waves[i];
-        hipFuncAttributes attr;
-        int w = 2;
-        if (hipFuncGetAttributes(&attr, f) == hipSuccess && attr.numRegs > 0) {
-            const int alloc = ((attr.numRegs + 7) / 8) * 8;
-            w = 512 / alloc > 8 ? 8 : (512 / alloc < 1 ? 1 : 512 / alloc);
-        } else {
-            (void)hipGetLastError();
-        }
-        if (std::getenv("GS_HIP_TRACE_TUNER"))
-            std::fprintf(stderr, "gs_hip: kernel entry %p: %d registers -> %d waves per SIMD\n", f, attr.numRegs, w);
-        if (occ_n < 64) { occ_fn[occ_n] = f; occ_waves[occ_n++] = w; }
-        return w;
-    };
-    const int waves = waves_of(fn);
+    const int waves = tb_waves_of(fn);
     // Tapered tail (consecutive passes are dependent launches that cannot overlap, so the drain phase
     // of a launch is idle time): when the launch is at least two rounds of the chip's wave slots, the
     // last round of units is an eighth as tall as the others and the round before it half as tall.

@@ -12,3 +12,4 @@ timeout -k 10 300 python __graft_entry__.py --smoke > "$OUT/smoke.log" 2>&1; ech
 timeout -k 10 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.log"; echo "bench rc=$?"; tail -1 "$OUT/bench.json" | cut -c1-1200
 GS_HIP_ROWS_PER_BLOCK=${GS_HIP_ROWS_PER_BLOCK:-128} timeout -k 10 900 bash tools/profile_gpu.sh $TAG 400 > "$OUT/profile.log" 2>&1; echo "profile rc=$?"; tail -2 "$OUT/profile.log"
 timeout -k 10 600 python tools/criterion_grid.py --cpu > "$OUT/criterion_grid.md" 2> "$OUT/criterion_grid.log"; echo "grid rc=$?"; cat "$OUT/criterion_grid.md"
+timeout -k 10 900 python tools/baseline_configs.py > "$OUT/baseline_configs.md" 2> "$OUT/baseline_configs.log"; echo "configs rc=$?"; head -8 "$OUT/baseline_configs.md"
