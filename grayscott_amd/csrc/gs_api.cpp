@@ -514,6 +514,30 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
     return a;
 }
 
+// Window shape and steps per launch of the LDS-window kernel (gs_run_tile_k) for a grid, from a cost model
+// fitted to the measured launches (profiles/r02_sweeps.md, section 10): a launch costs T0 = 2.4 us (launch
+// gap, window load and store) plus K steps of 1.0 / 0.6 / 1.75 us for the 32 / 16 / 64-row window while
+// every workgroup has a CU to itself; beyond 256 workgroups they run in rounds (two share a CU at 0.87 of
+// the time of two turns).  The model is within ~15 % of the measured rates from 64 x 128 to 1024 x 1024 and
+// picks the measured-best or second-best configuration on every grid of that table.
+constexpr uint64_t kTileAutoCells = 1536 * 1024; // above, the marching kernel is ahead (1080 x 1920: 380 k vs 350 k)
+void pick_tile_config(long rows, long cols, int *shape, int *k)
+{
+    static const int window_rows[3] = {32, 16, 64};
+    static const double step_us[3] = {1.0, 0.6, 1.75};
+    static const int ks[3] = {4, 6, 8};
+    double best = 0.0;
+    for (int sh = 0; sh < 3; ++sh)
+        for (int kk : ks) {
+            if (2 * kk >= window_rows[sh]) continue;
+            const long ho = window_rows[sh] - 2 * kk, wo = 64 - 2 * kk;
+            const long wgs = ((rows + ho - 1) / ho) * ((cols + wo - 1) / wo);
+            const double rounds = wgs <= 256 ? 1.0 : 0.87 * (double)((wgs + 255) / 256);
+            const double us_per_step = (2.4 + kk * step_us[sh] * rounds) / kk;
+            if (best == 0.0 || us_per_step < best) { best = us_per_step; *shape = sh; *k = kk; }
+        }
+}
+
 // ---- in-place row bands of a single slab -------------------------------------------------
 // One slab can be scheduled as V row bands that alias the same planes: a band's "ghost rows" are
 // simply the neighbouring band's rows, so nothing is copied, but the dependency structure is
@@ -1465,26 +1489,33 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
         if (result_slot) *result_slot = slot;
         return GS_OK;
     }
-    // GS_KERNEL_TILE (single slab): K <= 8 steps per launch on LDS-resident tiles (gs_run_tile_k).  Built
-    // for the mid-size grids, where a pass of the temporally blocked kernel is bound by the length of a
-    // wave's march and a launch per <= 4 steps; measured SLOWER than that kernel on every grid of the
-    // reference's benchmark set (profiles/r02_sweeps.md, section 4), so kernel = auto never picks it.
+    // Mid-size grids (single slab): K <= 8 steps per launch on LDS-resident windows (gs_run_tile_k), where a
+    // pass of the temporally blocked kernel is bound by the length of a wave's march and a launch per <= 4
+    // steps.  kernel = auto picks it between the resident kernel's 4096 cells and 1.5 M cells when nothing
+    // is pinned, with the window and steps per launch of pick_tile_config (profiles/r02_sweeps.md, section
+    // 10: 2.2x at 64 x 128 and 128 x 256, 1.8x at 256 x 512, 1.4x at 512 x 1024; at 1080 x 1920 the marching
+    // kernel is ahead again); GS_KERNEL_TILE forces it (tile_shape and fuse_steps then choose the window
+    // and the steps per launch).
     const uint64_t cells = u0->rows * u0->cols;
-    if (single && cells > 0 && steps > 0 && ctx->o.kernel == GS_KERNEL_TILE) {
+    int auto_shape = -1, auto_k = 0;
+    if (single && ctx->o.kernel == GS_KERNEL_AUTO && ctx->o.fuse_steps == 0 && ctx->o.rows_per_block == 0 &&
+        ctx->o.cols_per_lane == 0 && ctx->o.split <= 1 && !ctx->o.use_graph && cells > (uint64_t)kGsResidentCells &&
+        cells < kTileAutoCells)
+        pick_tile_config((long)u0->rows, (long)u0->cols, &auto_shape, &auto_k);
+    if (single && cells > 0 && steps > 0 && (ctx->o.kernel == GS_KERNEL_TILE || auto_shape >= 0)) {
         SlabRt &sl = ctx->slabs[0];
         GS_HIP(hipSetDevice(sl.device));
         GS_TRY(join_bands(ctx, sl.compute));
         ctx->bands_active = false;
-        // tile shape: the largest one that still gives every CU a workgroup; steps per launch: 8 for the
-        // big tile, 4 for the small ones, whose apron would otherwise outweigh the tile
-        static const int th[3] = {32, 16, 8}, tw[3] = {64, 32, 32};
-        int shape = 2;
-        for (int sidx = 0; sidx < 3; ++sidx)
-            if (((u0->rows + th[sidx] - 1) / th[sidx]) * ((u0->cols + tw[sidx] - 1) / tw[sidx]) >= 256) { shape = sidx; break; }
-        if (ctx->o.tile_shape >= 1 && ctx->o.tile_shape <= 3) shape = ctx->o.tile_shape - 1;
-        int kmax = shape == 0 ? kGsTileMaxSteps : 4;
-        if (ctx->o.fuse_steps > 0)
+        // window shape (gs_launch_tile): 0 = 32 rows x 64 columns, 1 = 16 x 64, 2 = 64 x 64; steps per launch:
+        // 8, or 4 for the 16-row window, whose apron would otherwise outweigh what it produces
+        int shape = auto_shape >= 0 ? auto_shape : 0;
+        if (auto_shape < 0 && ctx->o.tile_shape >= 1 && ctx->o.tile_shape <= 3) shape = ctx->o.tile_shape - 1;
+        const int window_rows = shape == 0 ? 32 : (shape == 1 ? 16 : 64);
+        int kmax = auto_shape >= 0 ? auto_k : (shape == 1 ? 4 : kGsTileMaxSteps);
+        if (auto_shape < 0 && ctx->o.fuse_steps > 0)
             kmax = ctx->o.fuse_steps > kGsTileMaxSteps ? kGsTileMaxSteps : ctx->o.fuse_steps;
+        if (2 * kmax >= window_rows) kmax = window_rows / 2 - 1;
         uint64_t left = steps;
         int slot = 0;
         const char *full_name = nullptr;

@@ -871,134 +871,118 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
 
 #if !GS_TB_OP_ONLY
 // ------------------------------------------------------------------------------------
-// Mid-size grids: K <= 8 time steps per launch on LDS-resident tiles.
+// Mid-size grids: K <= 8 time steps per launch on LDS-resident windows, one cell per lane and row.
 //
 // Between the single-workgroup resident kernel (<= 4096 cells) and grids that fill the chip with
 // marching waves (~1 M cells and up), a pass of gs_step_tb_k is bound by the LENGTH of a wave's march
-// (unit height + 2K ticks, one wave per SIMD issuing every 4th cycle) plus a dependent launch per
-// K <= 4 steps: 2.3-3.7 us per step whatever the grid (profiles/r01_criterion_grid.md).  Here a
-// workgroup owns a tile (32 x 64, 16 x 32 or 8 x 32 cells, picked by the host so that the tiles fill the
-// chip): it loads the tile with a K-cell apron into LDS, advances
-// it K times LDS -> LDS (a workgroup barrier per step; the region of valid cells shrinks by one ring
-// per step and ends as the tile) and stores the tile: one launch per K steps, all waves of the
-// workgroup working on every step.  Every thread updates strips of 4 cells from a 3 x 6 window read
-// with ds_read_b128 + 2 ds_read_b32 per row and species, through the same cell<> code as every
-// other kernel: bit-identical.  Tiles whose window leaves the grid run the general flavour with
-// per-cell presence flags / masks (cells outside the grid hold zeros and are never a neighbour).
+// (unit height + 2K ticks of K levels, one wave per SIMD issuing every 4th cycle) plus a dependent
+// launch per K <= 4 steps: 2.3-3.4 us per step whatever the grid (profiles/r02_criterion_grid.md).
+// Here a workgroup of 16 waves owns a window of 16 * RPW rows x 64 columns: wave w holds rows
+// w * RPW ... in registers, one column per lane.  Per step every wave publishes its rows in LDS
+// (double-buffered: one workgroup barrier per step), reads the rows above and below its own and the
+// left / right neighbours of its own cells back (ds_read_b32 at constant offsets from one address), and
+// updates its cells through the same cell<> code as every other kernel: bit-identical.  Nothing is
+// exchanged with other workgroups: the ring of cells whose neighbours lie outside the window loses its
+// validity, one ring per step, so after K steps the window shrunk by K cells on every side is exact
+// and is what the workgroup stores (windows overlap by 2K).  Where a window leaves the grid, the cells
+// outside hold garbage that no cell inside ever uses: the general flavour of cell<> selects an absent
+// neighbour away (clipped window) or reads it as zero (zero halo), exactly as in the other kernels.
+// The first form of this kernel (4-cell strips, 2-8 waves per tile; profiles/r02_sweeps.md, section 4)
+// spent 3.3-5.5 us per step on a 16 x 40 window: a wave alone on its SIMD issues one instruction per 4
+// cycles and a strip was a chain of ~250 of them.  With 16 waves per window every SIMD has 4 waves to
+// issue from and a step is ~55 * RPW instructions per wave.
 // ------------------------------------------------------------------------------------
 constexpr int kTileMaxK = kGsTileMaxSteps;
-// window column wc lives at LDS column wc + 3, so that the strips (which start at window column 1) are
-// 16-byte aligned; the pitch covers the last strip's right neighbour and is a multiple of 4 floats
-__host__ __device__ constexpr int tile_pitch(int tw, int k) { return ((tw + 2 * k + 7 + 3) / 4) * 4; }
-__host__ __device__ constexpr size_t tile_lds_bytes(int th, int tw, int k) { return (size_t)4 * (th + 2 * k) * tile_pitch(tw, k) * sizeof(float); }
+constexpr int kTileCols = 64;                 // window columns = lanes
+constexpr int kTilePitch = kTileCols + 2;     // + window columns -1 and 64 (never valid, only addressable)
+constexpr int kTileWaves = 16;                // 1024 threads
+__host__ __device__ constexpr int tile_rows(int rpw) { return kTileWaves * rpw; }
+// 2 buffers x 2 species x (rows + the rows above and below the window) x pitch
+__host__ __device__ constexpr size_t tile_lds_bytes(int rpw) { return (size_t)4 * (tile_rows(rpw) + 2) * kTilePitch * sizeof(float); }
 
-// One strip of 4 cells at window (wr, wc), LDS element offset o = wr * P + wc + 3 (a multiple of 4).
-template <bool GENERAL, int FAST>
-__device__ __forceinline__ void tile_strip(const GsStepArgs &a, const float *lds, int src, int plane, int P, int o, int gr, int gc,
-                                           float4 &nu, float4 &nv)
+template <int RPW, bool EDGE, int FAST, int ZH>
+__device__ __forceinline__ void tile_steps(const GsStepArgs &a, float *lds, int K, int gr, int gc, int wave, int lane,
+                                           float (&u)[RPW], float (&v)[RPW])
 {
-    RowW m, z, p;
-    RowW *dst[3] = {&m, &z, &p};
+    constexpr int H = tile_rows(RPW), P = kTilePitch, plane = (H + 2) * P; // plane: one species of one buffer
+    // element (buffer b, species s, window row r, window column c) = (2 b + s) * plane + (r + 1) * P + c + 1;
+    // `o` = this lane's first cell in species 0 of buffer 0
+    const int o = (wave * RPW + 1) * P + lane + 1;
+    const uint32_t la = (EDGE && gc == 0) ? 0xffffffffu : 0u, ra = (EDGE && gc + 1 >= a.cols) ? 0xffffffffu : 0u;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float *pu = lds + (src + o + (i - 1) * P), *pv = lds + (2 * plane + src + o + (i - 1) * P);
-        const float4 fu = *reinterpret_cast<const float4 *>(pu);
-        const float4 fv = *reinterpret_cast<const float4 *>(pv);
-        dst[i]->u[1] = fu.x; dst[i]->u[2] = fu.y; dst[i]->u[3] = fu.z; dst[i]->u[4] = fu.w;
-        dst[i]->v[1] = fv.x; dst[i]->v[2] = fv.y; dst[i]->v[3] = fv.z; dst[i]->v[4] = fv.w;
-        dst[i]->u[0] = pu[-1]; dst[i]->u[5] = pu[4];
-        dst[i]->v[0] = pv[-1]; dst[i]->v[5] = pv[4];
-    }
-    if (GENERAL) {
-        const bool mrow = gr > 0, prow = gr + 1 < a.rows;
-        uint32_t la[4], ra[4];
+    for (int i = 0; i < RPW; ++i) { lds[o + i * P] = u[i]; lds[plane + o + i * P] = v[i]; }
+    __syncthreads();
+    int cur = 0;
+    for (int s = 1; s <= K; ++s) {
+        const float *su = lds + cur * 2 * plane + o, *sv = su + plane;
+        Row3 R[RPW + 2]; // R[0] = the row above this wave's rows, R[1 + i] = its row i, R[RPW + 1] = the row below
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            la[k] = (gc + k == 0) ? 0xffffffffu : 0u;
-            ra[k] = (gc + k + 1 >= a.cols) ? 0xffffffffu : 0u;
-            asm volatile("" : "+v"(la[k]), "+v"(ra[k])); // keep the blends bitwise (see tb_march)
+        for (int i = 0; i < RPW + 2; ++i) {
+            const int d = (i - 1) * P;
+            R[i].u[0] = su[d - 1]; R[i].u[2] = su[d + 1];
+            R[i].v[0] = sv[d - 1]; R[i].v[2] = sv[d + 1];
+            if (i == 0 || i == RPW + 1) { R[i].u[1] = su[d]; R[i].v[1] = sv[d]; }
+            else { R[i].u[1] = u[i - 1]; R[i].v[1] = v[i - 1]; }
         }
-        cell<true>(a, m, z, p, 1, mrow, prow, la[0], ra[0], nu.x, nv.x);
-        cell<true>(a, m, z, p, 2, mrow, prow, la[1], ra[1], nu.y, nv.y);
-        cell<true>(a, m, z, p, 3, mrow, prow, la[2], ra[2], nu.z, nv.z);
-        cell<true>(a, m, z, p, 4, mrow, prow, la[3], ra[3], nu.w, nv.w);
-    } else {
-        cell<false, FAST>(a, m, z, p, 1, true, true, 0u, 0u, nu.x, nv.x);
-        cell<false, FAST>(a, m, z, p, 2, true, true, 0u, 0u, nu.y, nv.y);
-        cell<false, FAST>(a, m, z, p, 3, true, true, 0u, 0u, nu.z, nv.z);
-        cell<false, FAST>(a, m, z, p, 4, true, true, 0u, 0u, nu.w, nv.w);
+        float nu[RPW], nv[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const bool mrow = !EDGE || gr + i > 0, prow = !EDGE || gr + i + 1 < a.rows; // wave-uniform
+            cell<EDGE, FAST, Row3, ZH>(a, R[i], R[i + 1], R[i + 2], 1, mrow, prow, la, ra, nu[i], nv[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) { u[i] = nu[i]; v[i] = nv[i]; }
+        if (s < K) { // publish for the next step (the other buffer: no wave can still be reading it)
+            float *du = lds + (cur ^ 1) * 2 * plane + o;
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) { du[i * P] = u[i]; du[plane + i * P] = v[i]; }
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 }
 
-template <int TH, int TW, int NT, int FAST>
-__global__ __launch_bounds__(NT) void GS_SUFFIX(gs_run_tile_k)(GsStepArgs a, int K)
+template <int RPW, int FAST>
+__global__ __launch_bounds__(kTileWaves * 64) void GS_SUFFIX(gs_run_tile_k)(GsStepArgs a, int K)
 {
     if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0); // half_diff: MODE.IEEE = 0
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tiles_c = (a.cols + TW - 1) / TW;
+    extern __shared__ float lds[];
+    constexpr int H = tile_rows(RPW);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int HO = H - 2 * K, WO = kTileCols - 2 * K; // output rows / columns per window
+    const int tiles_c = (a.cols + WO - 1) / WO;
     const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
-    const int gr0 = tr * TH - K, gc0 = tc * TW - K; // global coordinates of window cell (0, 0)
-    const int Wh = TH + 2 * K, Ww = TW + 2 * K;
-    const int P4 = tile_pitch(TW, K) >> 2, P = P4 << 2;
-    const int plane = Wh * P; // lds: U buffer 0, U buffer 1, V buffer 0, V buffer 1 -- addressed by offset: a
-                              // select between pointers makes the compiler fall back to flat_load
-    // stage the window (zeros outside the grid, and in the pad columns the strip reads reach)
-    for (int i = threadIdx.x; i < Wh * P; i += NT) {
-        const int wr = i / P, wc = i - wr * P - 3;
-        const int gr = gr0 + wr, gc = gc0 + wc;
-        const bool in = wc >= 0 && wc < Ww && gr >= 0 && gr < a.rows && gc >= 0 && gc < a.cols;
-        const ptrdiff_t g = (ptrdiff_t)gr * a.pitch + gc;
-        lds[i] = in ? a.in_u[g] : 0.f;
-        lds[plane + i] = 0.f;
-        lds[2 * plane + i] = in ? a.in_v[g] : 0.f;
-        lds[3 * plane + i] = 0.f;
+    const int gr0 = tr * HO - K, gc0 = tc * WO - K; // global coordinates of window cell (0, 0)
+    const int gr = gr0 + wave * RPW, gc = gc0 + lane; // this lane's first cell
+    // load (clamped to the grid: cells outside it are never used, they only have to be addressable)
+    float u[RPW], v[RPW];
+    const int cc = min(max(gc, 0), a.cols - 1);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const ptrdiff_t g = (ptrdiff_t)min(max(gr + i, 0), a.rows - 1) * a.pitch + cc;
+        u[i] = a.in_u[g];
+        v[i] = a.in_v[g];
     }
-    __syncthreads();
-    // A tile whose window lies inside the grid runs code without any bounds logic.  Elsewhere only the
-    // cells ON the grid's border need the general flavour (clipped window / zero halo); cells outside
-    // the grid are skipped and stay zero (border cells mask them away), all others are interior cells.
-    const bool edge_tile = gr0 < 0 || gc0 < 0 || gr0 + Wh > a.rows || gc0 + Ww > a.cols;
-    const int nspr = (Ww - 2 + 3) >> 2; // strips of 4 cells per window row, from window column 1
-    int cur = 0;
-    for (int s = 1; s <= K; ++s) {
-        const int src = cur * plane, dst = (cur ^ 1) * plane;
-        const int nrows = Wh - 2 * s; // rows that can still be valid after this step: the ring of width s is lost
-        for (int idx = threadIdx.x; idx < nrows * nspr; idx += NT) {
-            const int rr = idx / nspr, si = idx - rr * nspr;
-            const int wr = s + rr, wc = 1 + 4 * si;
-            const int o = (wr * P4 + si + 1) << 2; // = wr * P + wc + 3, visibly 16-byte aligned
-            const int gr = gr0 + wr, gc = gc0 + wc;
-            float4 nu, nv;
-            if (!edge_tile) {
-                tile_strip<false, FAST>(a, lds, src, plane, P, o, gr, gc, nu, nv);
-            } else {
-                if (gr < 0 || gr >= a.rows || gc + 3 < 0 || gc >= a.cols) continue; // wholly outside
-                const bool border = gr == 0 || gr + 1 == a.rows || gc <= 0 || gc + 4 >= a.cols;
-                if (border) {
-                    tile_strip<true, FAST>(a, lds, src, plane, P, o, gr, gc, nu, nv);
-                    // cells of the strip outside the grid stay zero
-                    if (gc + 0 < 0 || gc + 0 >= a.cols) { nu.x = 0.f; nv.x = 0.f; }
-                    if (gc + 1 < 0 || gc + 1 >= a.cols) { nu.y = 0.f; nv.y = 0.f; }
-                    if (gc + 2 < 0 || gc + 2 >= a.cols) { nu.z = 0.f; nv.z = 0.f; }
-                    if (gc + 3 < 0 || gc + 3 >= a.cols) { nu.w = 0.f; nv.w = 0.f; }
-                } else {
-                    tile_strip<false, FAST>(a, lds, src, plane, P, o, gr, gc, nu, nv);
-                }
+    // A window inside the grid runs code without any bounds logic; the others the general flavour, one
+    // instantiation per boundary rule (as gs_step_tb_k).
+    const bool edge = gr0 <= 0 || gc0 <= 0 || gr0 + H >= a.rows || gc0 + kTileCols >= a.cols;
+    if (!edge)
+        tile_steps<RPW, false, FAST, -1>(a, lds, K, gr, gc, wave, lane, u, v);
+    else if (a.zero_halo)
+        tile_steps<RPW, true, FAST, 1>(a, lds, K, gr, gc, wave, lane, u, v);
+    else
+        tile_steps<RPW, true, FAST, 0>(a, lds, K, gr, gc, wave, lane, u, v);
+    // store the window shrunk by K, where it lies in the grid
+    if (lane >= K && lane < kTileCols - K && gc < a.cols) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int wr = wave * RPW + i;
+            if (wr >= K && wr < H - K && gr + i < a.rows) {
+                const ptrdiff_t g = (ptrdiff_t)(gr + i) * a.pitch + gc;
+                a.out_u[g] = u[i];
+                a.out_v[g] = v[i];
             }
-            *reinterpret_cast<float4 *>(lds + (dst + o)) = nu;
-            *reinterpret_cast<float4 *>(lds + (2 * plane + dst + o)) = nv;
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-    const int ru = (K & 1) * plane, rv = (2 + (K & 1)) * plane;
-    for (int i = threadIdx.x; i < TH * TW; i += NT) {
-        const int r = i / TW, c = i - r * TW;
-        const int gr = tr * TH + r, gc = tc * TW + c;
-        if (gr < a.rows && gc < a.cols) {
-            const int o = (K + r) * P + K + c + 3;
-            a.out_u[(ptrdiff_t)gr * a.pitch + gc] = lds[ru + o];
-            a.out_v[(ptrdiff_t)gr * a.pitch + gc] = lds[rv + o];
         }
     }
 }
@@ -1152,39 +1136,41 @@ hipError_t GS_SUFFIX(gs_launch_resident)(const GsStepArgs &a, int steps, hipStre
 }
 
 // K <= kGsTileMaxSteps time steps of a single slab in one launch of gs_run_tile_k (in-planes -> out-planes).
-// `shape`: 0 = 32 x 64 tiles (512 threads), 1 = 16 x 32 (256), 2 = 8 x 32 (128).
+// `shape`: 0 = windows of 32 rows x 64 columns (2 rows per wave), 1 = 16 x 64 (1 row), 2 = 64 x 64 (4 rows);
+// 2K < window rows.
 hipError_t GS_SUFFIX(gs_launch_tile)(const GsStepArgs &a, int k, int shape, hipStream_t s, const char **name)
 {
     static const char *const names[3][2] = {{"tile32x64/" GS_MATH_NAME, "tile32x64/" GS_MATH_NAME ".op"},
-                                            {"tile16x32/" GS_MATH_NAME, "tile16x32/" GS_MATH_NAME ".op"},
-                                            {"tile8x32/" GS_MATH_NAME, "tile8x32/" GS_MATH_NAME ".op"}};
-    static const int th[3] = {32, 16, 8}, tw[3] = {64, 32, 32}, nt[3] = {512, 256, 128};
-    if (a.rows <= 0 || a.cols <= 0 || k < 1 || k > kTileMaxK || shape < 0 || shape > 2 || a.top_present || a.bottom_present)
+                                            {"tile16x64/" GS_MATH_NAME, "tile16x64/" GS_MATH_NAME ".op"},
+                                            {"tile64x64/" GS_MATH_NAME, "tile64x64/" GS_MATH_NAME ".op"}};
+    static const int rpw[3] = {2, 1, 4};
+    if (a.rows <= 0 || a.cols <= 0 || k < 1 || k > kTileMaxK || shape < 0 || shape > 2 || a.top_present || a.bottom_present ||
+        2 * k >= tile_rows(rpw[shape]))
         return hipErrorInvalidValue;
     int fast = a.fast & (GS_MATH_FUSED ? 0 : 3);
     if (fast != 3) fast = 0; // only the variant for the default parameters is built besides the general one
     if (name) *name = names[shape][fast ? 1 : 0];
-    const long tiles = (long)((a.rows + th[shape] - 1) / th[shape]) * ((a.cols + tw[shape] - 1) / tw[shape]);
+    const long ho = tile_rows(rpw[shape]) - 2 * k, wo = kTileCols - 2 * k;
+    const long tiles = ((a.rows + ho - 1) / ho) * ((a.cols + wo - 1) / wo);
     if (tiles > 0x7fffffffL) return hipErrorInvalidConfiguration;
     const void *fn = nullptr;
-#define GS_TILE_FN(S, TH_, TW_, NT_)                                                                          \
-    case S: fn = fast ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_tile_k)<TH_, TW_, NT_, GS_MATH_FUSED ? 0 : 3>)  \
-                      : reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_tile_k)<TH_, TW_, NT_, 0>); break;
-    switch (shape) { GS_TILE_FN(0, 32, 64, 512) GS_TILE_FN(1, 16, 32, 256) GS_TILE_FN(2, 8, 32, 128) }
+#define GS_TILE_FN(S, RPW_)                                                                                   \
+    case S: fn = fast ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_tile_k)<RPW_, GS_MATH_FUSED ? 0 : 3>)  \
+                      : reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_tile_k)<RPW_, 0>); break;
+    switch (shape) { GS_TILE_FN(0, 2) GS_TILE_FN(1, 1) GS_TILE_FN(2, 4) }
 #undef GS_TILE_FN
-    const size_t lds = tile_lds_bytes(th[shape], tw[shape], k);
+    const size_t lds = tile_lds_bytes(rpw[shape]);
     if (lds > 64 * 1024) { // more than 64 KB of dynamic LDS needs the opt-in, per device function
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[fast ? 1 : 0]) {
-            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)tile_lds_bytes(th[shape], tw[shape], kTileMaxK));
+        static bool attr_set[3][2] = {{false, false}, {false, false}, {false, false}};
+        if (!attr_set[shape][fast ? 1 : 0]) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            attr_set[fast ? 1 : 0] = true;
+            attr_set[shape][fast ? 1 : 0] = true;
         }
     }
     GsStepArgs args = a;
     void *kargs[] = {&args, &k};
-    return hipLaunchKernel(fn, dim3((unsigned)tiles), dim3(nt[shape]), kargs, lds, s);
+    return hipLaunchKernel(fn, dim3((unsigned)tiles), dim3(kTileWaves * 64), kargs, lds, s);
 }
 
 hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const char **name)

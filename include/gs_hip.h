@@ -133,9 +133,9 @@ typedef struct gs_options {
     int32_t no_tune;         /* 1 = gs_run never times candidate configurations: it runs the pinned *
                               * values above, a configuration set with gs_ctx_set_tuned, or the     *
                               * untuned defaults                                                   */
-    int32_t tile_shape;      /* GS_KERNEL_TILE: 1 = 32 x 64 cells per workgroup, 2 = 16 x 32, 3 = 8 x 32; 0 = the  *
-                              * largest that gives every CU a workgroup.  With kernel = TILE, fuse_steps  *
-                              * (1..8) sets the steps per launch                                          */
+    int32_t tile_shape;      /* GS_KERNEL_TILE: window of a workgroup, 1 = 32 rows x 64 columns, 2 = 16 x 64,       *
+                              * 3 = 64 x 64; 0 = 32 x 64.  With kernel = TILE, fuse_steps (1..8, and less than  *
+                              * half the window's rows) sets the steps per launch                          */
     int32_t reserved[4];
 } gs_options;
 

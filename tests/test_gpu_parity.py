@@ -250,13 +250,13 @@ def test_row_bands_on_a_large_grid(split):
 
 
 # ---- non-default parameters (CLI overrides -k -f -t, ui/src/lib.rs:51-63) and weights ------
-# ---- GS_KERNEL_TILE: up to 8 steps per launch on LDS-resident tiles (opt-in, measured alternative) ---
-@pytest.mark.parametrize("tile_shape,fuse", [(1, 0), (2, 0), (3, 0), (1, 5), (2, 8), (3, 1)])
+# ---- GS_KERNEL_TILE: up to 8 steps per launch on LDS-resident windows (kernel = auto on mid-size grids) ---
+@pytest.mark.parametrize("tile_shape,fuse", [(1, 0), (2, 0), (3, 0), (1, 5), (2, 7), (3, 1)])
 @pytest.mark.parametrize("boundary", [capi.GS_BOUNDARY_CLIPPED, capi.GS_BOUNDARY_ZERO_HALO])
 def test_tile_kernel_bit_exact(boundary, tile_shape, fuse):
-    """gs_run_tile_k (GS_KERNEL_TILE): every shape
-    class -- single cells and lines, one partial tile, tile multiples, ragged right and bottom tiles,
-    several tiles each way -- and step counts that are a short launch, full launches and both."""
+    """gs_run_tile_k (GS_KERNEL_TILE), every window shape: every shape class of grid -- single cells and
+    lines, one partial window, multiples of a window's output, ragged right and bottom windows, several
+    windows each way -- and step counts that are a short launch, full launches and both."""
     for shape in [(1, 1), (1, 7), (7, 1), (2, 2), (3, 5), (17, 33), (32, 64), (33, 65), (31, 63), (64, 128), (250, 130),
                   (65, 129), (96, 200), (40, 1000), (1000, 40), (1, 5000), (5000, 1), (129, 257)]:
         u0, v0 = stress_fields(shape, 4)
@@ -264,8 +264,8 @@ def test_tile_kernel_bit_exact(boundary, tile_shape, fuse):
             ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True, boundary=boundary)
             got_u, got_v, info = gpu_run(u0, v0, steps, args=args(kernel=capi.GS_KERNEL_TILE, boundary=boundary,
                                                                   tile_shape=tile_shape, fuse_steps=fuse))
-            kmax = fuse or (8 if tile_shape == 1 else 4)
-            assert info[0] == ("tile32x64", "tile16x32", "tile8x32")[tile_shape - 1] + "/strict.op", info
+            kmax = fuse or (4 if tile_shape == 2 else 8)
+            assert info[0] == ("tile32x64", "tile16x64", "tile64x64")[tile_shape - 1] + "/strict.op", info
             assert info[1] == (steps + kmax - 1) // kmax, info
             assert_bits_equal(got_u, ref_u, f"tile U {shape} steps {steps}")
             assert_bits_equal(got_v, ref_v, f"tile V {shape} steps {steps}")
@@ -273,8 +273,8 @@ def test_tile_kernel_bit_exact(boundary, tile_shape, fuse):
 
 def test_tile_kernel_variants_and_auto_choice():
     """General weights / dt != 1 (no specialised variant), the fused flavour, Species::new over many
-    launches with mixed entry points; kernel = auto never picks the tile kernel and a slab chain
-    falls back to temporal blocking."""
+    launches with mixed entry points; what kernel = auto picks, and that a slab chain falls back to
+    temporal blocking."""
     shape = (150, 333)
     u0, v0 = stress_fields(shape, 6)
     for params in (Parameters.with_stencil("patrakarttunen"), Parameters(time_step=0.5), Parameters(feed_rate=0.03, kill_rate=0.06)):
@@ -299,8 +299,25 @@ def test_tile_kernel_variants_and_auto_choice():
     in_u, in_v, _, _ = species.in_out()
     assert_bits_equal(in_u.make_scalar_view(sim.context), u, "tile + single steps U")
     assert_bits_equal(in_v.make_scalar_view(sim.context), v, "tile + single steps V")
-    for kw in (dict(), dict(devices=[0, 0], kernel=capi.GS_KERNEL_TILE), dict(kernel=capi.GS_KERNEL_TB)):
-        assert gpu_run(u0, v0, 8, args=args(**kw))[2][0].startswith("tb-k"), kw
+    # kernel = auto: the window kernel between the resident kernel's 4096 cells and 1.5 M cells when nothing is
+    # pinned (window and steps per launch from a cost model, gs_api.cpp: pick_tile_config); temporal
+    # blocking for slab chains, pinned schedules and everything larger
+    ref_u, ref_v = oracle.run(u0, v0, 29, ftz=True)
+    for kw, want in ((dict(), "tile16x64/"), (dict(devices=[0, 0], kernel=capi.GS_KERNEL_TILE), "tb-k"),
+                     (dict(kernel=capi.GS_KERNEL_TB), "tb-k"), (dict(fuse_steps=4), "tb-k"), (dict(rows_per_block=8), "tb-k"),
+                     (dict(devices=[0, 0]), "tb-k")):
+        got_u, got_v, info = gpu_run(u0, v0, 29, args=args(**kw))
+        assert info[0].startswith(want), (kw, info)
+        assert_bits_equal(got_u, ref_u, f"auto choice U {kw}")
+        assert_bits_equal(got_v, ref_v, f"auto choice V {kw}")
+    for shape2, want in (((300, 400), "tile32x64/"), ((600, 900), "tile64x64/"), ((1024, 1024), "tile64x64/"), ((3000, 40), "tile"),
+                         ((12, 3000), "tile"), ((1300, 1300), "tb-k")):
+        a0, b0 = stress_fields(shape2, 9)
+        ref_u, ref_v = oracle.run(a0, b0, 21, ftz=True)
+        got_u, got_v, info = gpu_run(a0, b0, 21, args=args())
+        assert info[0].startswith(want), (shape2, info)
+        assert_bits_equal(got_u, ref_u, f"auto choice U {shape2}")
+        assert_bits_equal(got_v, ref_v, f"auto choice V {shape2}")
 
 
 # ---- small grids: the whole run in one launch, LDS-resident ----------------------------------------

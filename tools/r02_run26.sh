@@ -1,0 +1,12 @@
+#!/bin/bash
+set -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/r02_run26
+mkdir -p "$OUT"
+cd "$ROOT"
+S="timeout -k 10 400 python tools/sweep.py --rounds 5"
+$S --steps 96 rows_per_block=122,cols_per_lane=2 rows_per_block=122,cols_per_lane=2,split=2 rows_per_block=122,cols_per_lane=2,split=3 rows_per_block=122,cols_per_lane=2,split=4 rows_per_block=96,cols_per_lane=2,split=2 rows_per_block=64,cols_per_lane=2,split=2 2>&1 | grep -v "^grid" | tee -a "$OUT/sweep.log"
+$S --rows 8192 --cols 8192 --steps 200 rows_per_block=64,cols_per_lane=2 rows_per_block=64,cols_per_lane=2,split=2 rows_per_block=48,cols_per_lane=2,split=2 rows_per_block=64,cols_per_lane=2,split=3 rows_per_block=32,cols_per_lane=2,split=2 2>&1 | grep -v "^grid" | tee -a "$OUT/sweep.log"
+$S --rows 4096 --cols 4096 --steps 400 rows_per_block=30,cols_per_lane=1 rows_per_block=30,cols_per_lane=1,split=2 rows_per_block=16,cols_per_lane=1,split=2 rows_per_block=18,cols_per_lane=2,split=2 2>&1 | grep -v "^grid" | tee -a "$OUT/sweep.log"
+$S --rows 32768 --cols 16384 --steps 48 rows_per_block=122,cols_per_lane=2 rows_per_block=96,cols_per_lane=2 rows_per_block=192,cols_per_lane=2 2>&1 | grep -v "^grid" | tee -a "$OUT/sweep.log"
+$S --rows 65536 --cols 16384 --steps 24 rows_per_block=122,cols_per_lane=2 rows_per_block=192,cols_per_lane=2 2>&1 | grep -v "^grid" | tee -a "$OUT/sweep.log"
