@@ -919,10 +919,17 @@ __device__ __forceinline__ void tile_steps(const GsStepArgs &a, float *lds, int 
 #pragma unroll
         for (int i = 0; i < RPW + 2; ++i) {
             const int d = (i - 1) * P;
+#if defined(GS_TILE_ABLATE) && (GS_TILE_ABLATE & 2) /* timing experiment: no LDS reads */
+            const float fu = u[(i + RPW - 1) % RPW], fv = v[(i + RPW - 1) % RPW];
+            R[i].u[0] = fu * a.dv; R[i].u[2] = fu + a.du; R[i].v[0] = fv * a.du; R[i].v[2] = fv + a.dv;
+            R[i].u[1] = fu; R[i].v[1] = fv;
+            (void)su; (void)sv; (void)d;
+#else
             R[i].u[0] = su[d - 1]; R[i].u[2] = su[d + 1];
             R[i].v[0] = sv[d - 1]; R[i].v[2] = sv[d + 1];
             if (i == 0 || i == RPW + 1) { R[i].u[1] = su[d]; R[i].v[1] = sv[d]; }
             else { R[i].u[1] = u[i - 1]; R[i].v[1] = v[i - 1]; }
+#endif
         }
         float nu[RPW], nv[RPW];
 #pragma unroll
@@ -936,7 +943,9 @@ __device__ __forceinline__ void tile_steps(const GsStepArgs &a, float *lds, int 
             float *du = lds + (cur ^ 1) * 2 * plane + o;
 #pragma unroll
             for (int i = 0; i < RPW; ++i) { du[i * P] = u[i]; du[plane + i * P] = v[i]; }
+#if !(defined(GS_TILE_ABLATE) && (GS_TILE_ABLATE & 1)) /* timing experiment: no barrier */
             __syncthreads();
+#endif
             cur ^= 1;
         }
     }
@@ -1159,7 +1168,9 @@ hipError_t GS_SUFFIX(gs_launch_tile)(const GsStepArgs &a, int k, int shape, hipS
                       : reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_tile_k)<RPW_, 0>); break;
     switch (shape) { GS_TILE_FN(0, 2) GS_TILE_FN(1, 1) GS_TILE_FN(2, 4) }
 #undef GS_TILE_FN
-    const size_t lds = tile_lds_bytes(rpw[shape]);
+    size_t lds = tile_lds_bytes(rpw[shape]);
+    static const int lds_floor = std::getenv("GS_HIP_TILE_LDS_FLOOR") ? std::atoi(std::getenv("GS_HIP_TILE_LDS_FLOOR")) : 0;
+    if (lds < (size_t)lds_floor) lds = (size_t)lds_floor; // experiment: limit the workgroups per CU
     if (lds > 64 * 1024) { // more than 64 KB of dynamic LDS needs the opt-in, per device function
         static bool attr_set[3][2] = {{false, false}, {false, false}, {false, false}};
         if (!attr_set[shape][fast ? 1 : 0]) {

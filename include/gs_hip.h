@@ -85,8 +85,10 @@ typedef struct gs_params {
  *                   (GS_ERR_UNSUPPORTED) for weights that are not 0 or a power of two.    */
 typedef enum gs_math { GS_MATH_STRICT = 0, GS_MATH_FUSED = 1 } gs_math;
 
-/* Which step kernel runs.  AUTO = STREAM for a single gs_step, TB with fuse_steps (default 4)
- * inside gs_run. */
+/* Which step kernel runs.  AUTO = STREAM for a single gs_step; inside gs_run, by grid size when nothing
+ * is pinned: the LDS-resident whole-run kernel up to 4096 cells, TILE up to 1.5 M cells, TB with
+ * fuse_steps (default 4) above, for slab chains and whenever fuse_steps, rows_per_block, cols_per_lane,
+ * split or use_graph pin a schedule. */
 typedef enum gs_kernel {
     GS_KERNEL_AUTO = 0,    /* best measured variant for the shape                          */
     GS_KERNEL_SIMPLE = 1,  /* one thread per cell, global loads only (cross-check kernel)  */
@@ -94,10 +96,9 @@ typedef enum gs_kernel {
     GS_KERNEL_TB = 3,      /* temporally blocked streaming kernel: fuse_steps steps / launch */
     GS_KERNEL_LDS = 4,     /* LDS-staged (tile + halo) window, one step per launch (measured
                               alternative to STREAM; never chosen by AUTO)                   */
-    GS_KERNEL_TILE = 5     /* gs_run only, single slab: up to 8 steps per launch on LDS-resident tiles
-                              with a K-cell apron (gs_step and slab chains fall back to STREAM / TB);
-                              a measured alternative for mid-size grids, slower than TB there too:
-                              never chosen by AUTO                                            */
+    GS_KERNEL_TILE = 5     /* gs_run only, single slab: up to 8 steps per launch on LDS-resident windows
+                              with a K-cell apron, one cell per lane and 16 waves per window (gs_step and
+                              slab chains fall back to STREAM / TB); what AUTO runs on mid-size grids  */
 } gs_kernel;
 
 /* Rule on the edges of the global grid.  The reference has two:
