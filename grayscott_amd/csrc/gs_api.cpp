@@ -905,7 +905,11 @@ int32_t tune_online(Run &r, int fuse)
                              (unsigned long long)f->rows, (unsigned long long)f->cols, t.rpu, t.V, t.k, t.cpl, ms, w0, w1);
             // prefer the incumbent unless the newcomer is clearly faster: by 1 %, or by 3 % when it
             // fuses fewer steps (more HBM traffic, slower remainder passes: a tie is not worth it)
-            const float margin = t.k < tu->best_k ? 0.97f : 0.99f;
+            // ... and a taller unit of the same layout wins a near-tie: it recomputes fewer rows, and on large
+            // grids the rate is flat over a wide range of heights, where a 1 % margin would keep the first
+            // (shortest) height of the plateau's edge
+            const bool taller = t.k == tu->best_k && t.cpl == tu->best_cpl && t.V == tu->best_split && t.rpu > tu->best_rpu;
+            const float margin = t.k < tu->best_k ? 0.97f : (taller ? 0.998f : 0.99f);
             if (tu->best_rpu == 0 || ms < margin * tu->best_ms) {
                 tu->best_ms = ms;
                 tu->best_rpu = t.rpu;
