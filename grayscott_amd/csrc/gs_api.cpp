@@ -380,8 +380,8 @@ int fast_of(const gs_ctx *ctx)
 // extra round: at 4096^2 with 2 columns per lane 36 rows give 749 k Mcells x steps/s, 32 rows 677 k, 40
 // rows 687 k (profiles/r02_sweeps.md, section 9).  From two rounds up the launcher tapers the last two
 // rounds (an eighth and a half as tall: 0.625 rounds' worth of rows), which the formula accounts for.
-// Writes up to `max` heights, by ascending number of rounds (descending height); returns their number.
-int fit_heights(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse, int cpl, int fast, int *out, int max)
+// Writes up to `max` heights (the single-round one first); returns their number.
+int fit_heights(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse, int cpl, int fast, int *out, int max, bool partial = false)
 {
     const int slots = ctx->o.math == GS_MATH_FUSED ? gs_tb_wave_slots_fused(fuse, fast, cpl) : gs_tb_wave_slots_strict(fuse, fast, cpl);
     const long strips = tb_strips(cols, fuse, cpl);
@@ -390,15 +390,34 @@ int fit_heights(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse, int cpl
     if (per_round < 1) return 0;
     const long per_round_up = (slots + strips - 1) / strips; // what the launcher tapers (gs_launch_tb)
     int n = 0;
-    // r = 1, 2: un-tapered launches of r full rounds; r >= 3: (r - 1) full rounds + the two tapered ones
-    // (the launcher tapers from two rounds' worth of full-height units up)
-    for (int r = 1; r <= 8 && n < max; ++r) {
-        const double chunks = r < 3 ? (double)(per_round * r) : (double)(per_round * (r - 1)) + 0.625 * (double)per_round_up;
-        long h = (long)std::ceil((double)rows / chunks - 1e-9);
-        if (h < 2L * fuse) break;
+    auto push = [&](long h) {
         if (h > rows) h = rows;
-        if (n > 0 && out[n - 1] == (int)h) continue;
-        out[n++] = (int)h;
+        for (int i = 0; i < n; ++i)
+            if (out[i] == (int)h) return;
+        if (n < max) out[n++] = (int)h;
+    };
+    // A launch of at most one round dispatches its edge units -- up to 3 strips of every chunk, all strips of
+    // the top and bottom chunk rows -- as two halves each (gs_launch_tb): count them.  `partial`: also the
+    // heights that leave every SIMD w = waves - 1, ..., 1 waves instead of a full round (1080 x 1920, 1 column
+    // per lane, 5 waves per SIMD: 8 rows fill the round, 10 rows give every SIMD 4 waves and are 6 % faster).
+    const int waves = slots / 1024;
+    const long wcols = (64 - 2 * ((fuse + cpl - 1) / cpl)) * (long)cpl, scols = ((fuse + cpl - 1) / cpl) * (long)cpl;
+    const long ne = strips <= 1 ? strips : (((strips - 1) * wcols + scols >= cols && strips >= 2) ? 3 : 2); // edge strips (gs_step_tb_k)
+    for (int w = waves; w >= (partial ? 1 : waves); --w) {
+        // units = chunks x (strips + ne) + 2 x (strips - ne): the halves of the edge strips of every chunk and
+        // of the other strips of the top and bottom chunk rows
+        const long chunks = strips <= ne ? 1024L * w / (2 * strips) : (1024L * w - 2 * (strips - ne)) / (strips + ne);
+        if (chunks < 1) continue;
+        const long h = (rows + chunks - 1) / chunks;
+        if (h >= 2) push(h);
+    }
+    // r = 2: an un-tapered launch of two full rounds; r >= 3: (r - 1) full rounds + the two tapered ones (the
+    // launcher tapers from two rounds' worth of full-height units up)
+    for (int r = 2; r <= 8 && n < max; ++r) {
+        const double chunks = r < 3 ? (double)(per_round * r) : (double)(per_round * (r - 1)) + 0.625 * (double)per_round_up;
+        const long h = (long)std::ceil((double)rows / chunks - 1e-9);
+        if (h < 2L * fuse) break;
+        push(h);
     }
     return n;
 }
@@ -424,11 +443,17 @@ int32_t pick_cols_per_lane(const gs_ctx *ctx, int32_t rows, int32_t cols, int fu
 
 // Rows each wave marches over when nothing was tuned on line (slab chains, short runs).  Measured
 // at 16384^2 (profiles/r01_sweeps.md, sweep17/18): 16 rows for single steps, 128 for 4 fused steps.
+int32_t model_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse, int cpl);
 int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse)
 {
     if (ctx->o.rows_per_block > 0) return ctx->o.rows_per_block;
     if (tuned_for(ctx, rows, cols, fuse)) return ctx->tuned_rpu;
-    const int cpl = pick_cols_per_lane(ctx, rows, cols, fuse);
+    return model_rows_per_unit(ctx, rows, cols, fuse, pick_cols_per_lane(ctx, rows, cols, fuse));
+}
+
+// ... for a given lane layout, from the launch geometry alone (also the tuner's first candidate).
+int32_t model_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse, int cpl)
+{
     const long strips = fuse > 1 ? tb_strips(cols, fuse, cpl) : (cols + 255) / 256;
     const long want = fuse > 1 ? 32L * fuse : 16;
     if (fuse > 1) {
@@ -818,10 +843,10 @@ int32_t tune_online(Run &r, int fuse)
     // chip's wave slots (fit_heights), in ascending order without near-duplicates
     auto heights = [&](const int *fixed, int nfixed, int k, int cpl) {
         std::vector<int> v(fixed, fixed + nfixed);
-        int fit[8];
+        int fit[16];
         // (not on large grids: from about six rounds per launch up the rate is flat in the unit height --
         // 16384^2: 0.2469-0.2511 ms per step from 96 to 214 rows -- and every candidate costs passes)
-        const int nf = large ? 0 : fit_heights(ctx, (int32_t)f->rows, (int32_t)f->cols, k, cpl, fast, fit, 8);
+        const int nf = large ? 0 : fit_heights(ctx, (int32_t)f->rows, (int32_t)f->cols, k, cpl, fast, fit, 16, true);
         for (int i = 0; i < nf; ++i) {
             bool dup = false;
             for (int x : v) dup = dup || x == fit[i];
@@ -830,7 +855,13 @@ int32_t tune_online(Run &r, int fuse)
         std::sort(v.begin(), v.end());
         return v;
     };
-    const std::vector<int> cand = heights(cand0, (int)(sizeof cand0 / sizeof cand0[0]), fuse, base_cpl);
+    std::vector<int> cand = heights(cand0, (int)(sizeof cand0 / sizeof cand0[0]), fuse, base_cpl);
+    // The height an untuned context would use (the model's: a whole number of rounds, ~32K rows) is timed
+    // last in phase A, when the chip has warmed up, and is preferred on large grids unless it is 2 % slower
+    // than the best of the ladder (see the margins in evaluate()).
+    const int dflt = model_rows_per_unit(ctx, (int32_t)f->rows, (int32_t)f->cols, fuse, base_cpl);
+    cand.erase(std::remove(cand.begin(), cand.end(), dflt), cand.end());
+    cand.push_back(dflt);
     const int ncand = (int)cand.size();
     const int nalt = 0; // phase B is empty
     const int nk = ctx->o.fuse_steps == 0 ? (int)(sizeof altk / sizeof altk[0]) : 0;
@@ -909,7 +940,12 @@ int32_t tune_online(Run &r, int fuse)
             // grids the rate is flat over a wide range of heights, where a 1 % margin would keep the first
             // (shortest) height of the plateau's edge
             const bool taller = t.k == tu->best_k && t.cpl == tu->best_cpl && t.V == tu->best_split && t.rpu > tu->best_rpu;
-            const float margin = t.k < tu->best_k ? 0.97f : (taller ? 0.998f : 0.99f);
+            // On large grids (a plateau from 96 to 214 rows at 16384^2, windows of two passes that scatter by
+            // 1-2 %, more while the chip warms up) picking inside the plateau by such measurements is a lottery
+            // (64 or 256 rows, 2-3 % below the plateau, in two of six runs): the model's height, timed last
+            // in phase A, wins unless it is 2 % slower than the best of the ladder.
+            float margin = t.k < tu->best_k ? 0.97f : (taller ? 0.998f : 0.99f);
+            if (large && t.rpu == dflt && t.cpl == base_cpl && t.k == fuse) margin = 1.02f;
             if (tu->best_rpu == 0 || ms < margin * tu->best_ms) {
                 tu->best_ms = ms;
                 tu->best_rpu = t.rpu;
@@ -930,6 +966,24 @@ int32_t tune_online(Run &r, int fuse)
     const int phase_end[4] = {ncand, ncand + nalt, ncand + nalt + nk, ncand + nalt + nk + nn};
     int warm_cpl = 0, warm_k = 0; // kernel of the newest pass enqueued by this call
     bool out_of_steps = false;
+    // The first milliseconds of work on an idle chip run slow (the first windows of a 16384^2 context measured
+    // 0.32 ms per step against 0.255 a few passes later: clocks, first touches), which used to cost whichever
+    // candidate was timed first its chance.  A tuning therefore starts with ~20 ms of untimed passes (real
+    // passes of the run, like all the others) in the model's configuration.
+    if (tu->next == 0 && tu->best_rpu == 0 && tu->nb == 0) {
+        uint64_t want = 2500000000ull / (cells ? cells : 1); // ~20 ms at 500 k Mcells x steps / s
+        if (want < 8) want = 8;
+        if (want > 2000) want = 2000;
+        const uint64_t have = (r.steps - r.n) / (uint64_t)fuse;
+        const uint64_t n = have > 4 * want ? want : have / 4;
+        ctx->o.cols_per_lane = base_cpl;
+        int32_t st = GS_OK;
+        for (uint64_t i = 0; i < n && st == GS_OK; ++i) st = r.advance(V0, fuse);
+        ctx->o.cols_per_lane = user_cpl;
+        if (st != GS_OK) return st;
+        warm_cpl = base_cpl;
+        warm_k = fuse;
+    }
     while (tu->next < phase_end[3] && !out_of_steps) {
         int phase = 0;
         while (tu->next >= phase_end[phase]) ++phase;
@@ -942,7 +996,7 @@ int32_t tune_online(Run &r, int fuse)
                 t.rpu = cand[i];
                 // units shorter than 2K rows recompute more rows than they produce: only worth it
                 // where a pass is latency-bound, i.e. on small grids
-                if ((t.rpu < 2 * fuse && cells > (1ull << 21)) || (uint64_t)t.rpu > f->rows) continue;
+                if ((t.rpu < 2 * fuse && cells > (1ull << 21)) || (uint64_t)t.rpu > f->rows || (large && t.rpu < 32)) continue;
             } else if (phase == 2) {
                 t.rpu = tu->best_rpu;
                 t.V = tu->best_split;

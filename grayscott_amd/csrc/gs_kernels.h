@@ -38,6 +38,11 @@ struct GsStepArgs {
     // how many of range a's LAST chunks are dispatched first (the chunks a bottom grid edge can touch;
     // at least 1), filled in by the launcher
     int32_t bot_first;
+    // 2 = units on a global edge are dispatched as two half-height units (1 = whole): the outer strips of
+    // every chunk and all strips of the first `edge_chunks` chunks in dispatch order (the bottom and top
+    // chunk rows).  Edge units run the general path, ~1.6x as slow: in a launch of one or two rounds of wave
+    // slots, where every unit starts at once, whole ones would finish last.  Filled in by the launcher.
+    int32_t edge_split, edge_chunks;
     // Parameter-specialised variants of the temporal-blocking kernel (bit-identical results, fewer
     // instructions): bit 0 = the four side weights w[0][1], w[1][0], w[1][2], w[2][1] are exactly
     // 0.5f, bit 1 = dt is exactly 1.0f.  Both hold for Parameters::default().

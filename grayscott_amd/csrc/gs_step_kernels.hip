@@ -818,7 +818,6 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
                                           : a.big_chunks + a.mid_chunks + (rest_a - a.mid_chunks * small + a.tiny_rpu - 1) / a.tiny_rpu;
     const int chunks_b = (a.rb1 - a.rb0 + rpu - 1) / rpu;
     const int chunks = chunks_a + chunks_b;
-    if (unit >= chunks * strips) return; // wave-uniform
     // Dispatch order.  Units on a global edge take the general path, which is 1.6x as slow
     // (per-lane selects); a slow unit that starts in the last round of a launch stretches
     // its tail, so all edge units go first: the left-most and right-most strips of every chunk,
@@ -827,18 +826,35 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     // lanes included, reaches the last column.
     const int er = ((strips - 1) * W + S * CPL >= a.cols && strips >= 2) ? 2 : 1; // edge strips on the right
     const int ne = 1 + er;                                                        // ... per chunk
-    int chunk, strip;
+    // With edge_split = 2 the edge units come as two half-height units each (half = 0 / 1): they are the
+    // outer strips of every chunk and every strip of the first edge_chunks chunks in dispatch order.
+    const int es = a.edge_split == 2 ? 2 : 1;
+    int chunk, strip, half = -1;
     if (strips <= ne) {
-        chunk = unit / strips;
-        strip = unit - chunk * strips;
-    } else if (unit < chunks * ne) {
-        chunk = unit / ne;
-        const int se = unit - chunk * ne;
+        if (unit >= chunks * strips * es) return; // wave-uniform
+        chunk = unit / (strips * es);
+        const int rem = unit - chunk * strips * es;
+        strip = rem / es;
+        if (es == 2) half = rem - strip * es;
+    } else if (unit < chunks * ne * es) {
+        chunk = unit / (ne * es);
+        const int rem = unit - chunk * ne * es, se = rem / es;
+        if (es == 2) half = rem - se * es;
         strip = se == 0 ? 0 : strips - er + (se - 1);
     } else {
-        const int v = unit - chunks * ne, ni = strips - ne;
-        chunk = v / ni;
-        strip = 1 + (v - chunk * ni);
+        const int ni = strips - ne, nec = es == 2 ? min(a.edge_chunks, chunks) : 0;
+        int v = unit - chunks * ne * es;
+        if (v < nec * ni * es) {
+            chunk = v / (ni * es);
+            const int rem = v - chunk * ni * es, si = rem / es;
+            half = rem - si * es;
+            strip = 1 + si;
+        } else {
+            v -= nec * ni * es;
+            chunk = nec + v / ni;
+            if (chunk >= chunks) return; // wave-uniform
+            strip = 1 + (v - (v / ni) * ni);
+        }
     }
     int ur0, ur1;
     if (chunk < chunks_a) {
@@ -858,6 +874,12 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     } else {
         ur0 = a.rb0 + (chunk - chunks_a) * rpu;
         ur1 = min(ur0 + rpu, a.rb1);
+    }
+    if (half >= 0) { // this unit is one half of its chunk's rows
+        const int hh = (ur1 - ur0 + 1) >> 1;
+        if (half == 0) ur1 = min(ur0 + hh, ur1);
+        else ur0 = ur0 + hh;
+        if (ur0 >= ur1) return; // a one-row chunk has no second half (wave-uniform)
     }
     const bool edge = (strip == 0) || ((strip + 1) * W + S * CPL >= a.cols) ||
                       (ur0 - K < 0 && !a.top_present) || (ur1 + K > a.rows && !a.bottom_present);
@@ -1318,8 +1340,6 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     const long chunks = chunks_a + ((long)(a.rb1 - a.rb0) + rpu - 1) / rpu;
     if (chunks <= 0) return hipSuccess;
     if (k > a.ghost && (a.top_present || a.bottom_present)) return hipErrorInvalidValue;
-    const long blocks = (chunks * strips + 3) / 4;
-    if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
     GsStepArgs args = a;
     args.big_chunks = (int32_t)big_chunks;
     args.small_rpu = (int32_t)small;
@@ -1337,6 +1357,30 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
         for (; bot < chunks_a; ++bot) { chunk_rows(chunks_a - 1 - bot, r0, r1); if (!(r1 + k > a.rows)) break; }
     if (bot < 1 && chunks_a > 0) bot = 1; // the launch order of earlier rounds: the last chunk first
     args.bot_first = (int32_t)bot;
+    // Edge units as two halves each when the launch is about one round of wave slots (every unit starts at
+    // once, so the slow edge units would finish last: 1080 x 1920 +5.7 %, 2048 x 4096 +1.6 %; from two rounds
+    // up the edge-first order does the job and halves only add recomputed rows: 8192^2 -1 %;
+    // profiles/r02_sweeps.md, section 11).  The kernel's dispatch order: the outer strips of every chunk, then all strips of the
+    // bottom `bot` and the top chunk row of range a, then the rest.
+    static const int split_env = std::getenv("GS_HIP_EDGE_SPLIT") ? std::atoi(std::getenv("GS_HIP_EDGE_SPLIT")) : -1;
+    const long er = ((strips - 1) * W + tb_sacrificial_lanes(k, cpl) * cpl >= a.cols && strips >= 2) ? 2 : 1, ne = 1 + er;
+    bool split = 4 * chunks * strips <= 5 * slots && rpu >= 2;
+    if (split_env >= 0) split = split_env != 0;
+    long units = chunks * strips;
+    args.edge_split = 1;
+    args.edge_chunks = 0;
+    if (split) {
+        args.edge_split = 2;
+        if (strips <= ne) {
+            units = chunks * strips * 2;
+        } else {
+            const long nec = chunks_a > 0 ? (bot + 1 < chunks ? bot + 1 : chunks) : 0;
+            args.edge_chunks = (int32_t)nec;
+            units = chunks * ne * 2 + nec * (strips - ne) * 2 + (chunks - nec) * (strips - ne);
+        }
+    }
+    const long blocks = (units + 3) / 4;
+    if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
     void *kargs[] = {&args};
     return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), kargs, 0, s);
 }
