@@ -158,6 +158,51 @@ def developed_species(sim, rows, cols, develop_steps=4000):
     return species
 
 
+NOMINAL_SCLK_MHZ = 2400.0  # the clock VALU_PEAK_TLANEOPS is priced at
+
+
+def sample_clock_and_power(work, device: int):
+    """Medians of rocm-smi's shader clock (MHz) and socket power (W) sampled while `work()` runs; None when
+    rocm-smi is missing or says nothing useful (informational fields, never part of `value`)."""
+    import re
+    import shutil
+    import statistics
+    import subprocess
+    import threading
+
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    sclk, power, stop = [], [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                out = subprocess.run([smi, "-d", str(device), "--showclocks", "--showpower"], capture_output=True,
+                                     text=True, timeout=10).stdout
+            except Exception:
+                return
+            m = re.search(r"sclk clock level:[^(]*\((\d+)Mhz\)", out)
+            if m:
+                sclk.append(float(m.group(1)))
+            m = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+            if m:
+                power.append(float(m.group(1)))
+            stop.wait(0.2)
+
+    thread = threading.Thread(target=sampler, daemon=True)
+    thread.start()
+    try:
+        work()
+    finally:
+        stop.set()
+        thread.join(timeout=15)
+    busy = [c for c in sclk if c > 1000.0]          # samples taken while the kernel ran
+    if not busy:
+        return None
+    return {"sclk_MHz": statistics.median(busy), "power_W": statistics.median(power) if power else None, "samples": len(busy)}
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,8 +332,12 @@ def main() -> int:
     # chain, the small boundary-band launch); a pass advances `steps / passes` time steps (temporal
     # blocking).
     passes = launches if args.gpus == 1 else launches // 2
-    extra, developed = None, None
+    extra, developed, clocks = None, None, None
     if args.gpus == 1 and not args.no_extra:
+        # informational: shader clock and socket power while the same kernel runs (rocm-smi samples next to
+        # an untimed repeat of the timed run; the VALU roof is priced at the nominal 2.4 GHz, the chip
+        # sustains less on its power limit)
+        clocks = sample_clock_and_power(lambda: timed_run(species, max(args.steps, 8000)), local_rank)
         # informational: the same kernel, same context, on a developed spot pattern (the chip sustains
         # a lower clock on non-trivial operands; BASELINE.md asks for "random/real data not zeros")
         sp_dev = developed_species(sim, rows, cols)
@@ -374,6 +423,11 @@ def main() -> int:
     if comm:
         result["rccl_ranks"] = comm[0][0]
         result["ranks"] = [{"rccl_rank": c[1], "rccl_device": c[2], "local_rank": c[3]} for c in comm]
+    if clocks:
+        roofline["sclk_MHz_under_load"] = clocks["sclk_MHz"]
+        roofline["socket_power_W_under_load"] = clocks["power_W"]
+        if valu_rate and valu_bound:
+            roofline["valu_at_sustained_clock"] = valu_rate / (VALU_PEAK_TLANEOPS * clocks["sclk_MHz"] / NOMINAL_SCLK_MHZ)
     if developed is not None:
         result["value_developed_pattern"] = developed
     if extra is not None:
