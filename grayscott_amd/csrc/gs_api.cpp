@@ -540,16 +540,16 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
 }
 
 // Window shape and steps per launch of the LDS-window kernel (gs_run_tile_k) for a grid, from a cost model
-// fitted to the measured launches (profiles/r02_sweeps.md, section 10): a launch costs T0 = 2.4 us (launch
-// gap, window load and store) plus K steps of 1.0 / 0.6 / 1.75 us for the 32 / 16 / 64-row window while
-// every workgroup has a CU to itself; beyond 256 workgroups they run in rounds (two share a CU at 0.87 of
-// the time of two turns).  The model is within ~15 % of the measured rates from 64 x 128 to 1024 x 1024 and
-// picks the measured-best or second-best configuration on every grid of that table.
-constexpr uint64_t kTileAutoCells = 1536 * 1024; // above, the marching kernel is ahead (1080 x 1920: 380 k vs 350 k)
+// fitted to the measured launches (profiles/r02_sweeps.md, section 10): a launch costs T0 = 3.4 / 2.6 / 3.7 us
+// (launch gap, weights, window load and store) plus K steps of 0.74 / 0.585 / 1.38 us for the 32 / 16 / 64-row
+// window while every workgroup has a CU to itself; beyond 256 workgroups they run in rounds (two share a CU
+// at 0.87 of the time of two turns).  The model is within ~15 % of the measured rates from 64 x 128 to 1024 x
+// 1024 and picks the measured-best or second-best configuration on every grid of that table.
+constexpr uint64_t kTileAutoCells = 1536 * 1024; // above, the marching kernel is ahead (1080 x 1920: 380-420 k vs 350 k)
 void pick_tile_config(long rows, long cols, int *shape, int *k)
 {
     static const int window_rows[3] = {32, 16, 64};
-    static const double step_us[3] = {1.0, 0.6, 1.75};
+    static const double launch_us[3] = {3.4, 2.6, 3.7}, step_us[3] = {0.74, 0.585, 1.38};
     static const int ks[3] = {4, 6, 8};
     double best = 0.0;
     for (int sh = 0; sh < 3; ++sh)
@@ -558,7 +558,7 @@ void pick_tile_config(long rows, long cols, int *shape, int *k)
             const long ho = window_rows[sh] - 2 * kk, wo = 64 - 2 * kk;
             const long wgs = ((rows + ho - 1) / ho) * ((cols + wo - 1) / wo);
             const double rounds = wgs <= 256 ? 1.0 : 0.87 * (double)((wgs + 255) / 256);
-            const double us_per_step = (2.4 + kk * step_us[sh] * rounds) / kk;
+            const double us_per_step = (launch_us[sh] + kk * step_us[sh] * rounds) / kk;
             if (best == 0.0 || us_per_step < best) { best = us_per_step; *shape = sh; *k = kk; }
         }
 }

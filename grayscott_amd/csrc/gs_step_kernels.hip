@@ -907,8 +907,9 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
 // exchanged with other workgroups: the ring of cells whose neighbours lie outside the window loses its
 // validity, one ring per step, so after K steps the window shrunk by K cells on every side is exact
 // and is what the workgroup stores (windows overlap by 2K).  Where a window leaves the grid, the cells
-// outside hold garbage that no cell inside ever uses: the general flavour of cell<> selects an absent
-// neighbour away (clipped window) or reads it as zero (zero halo), exactly as in the other kernels.
+// outside are zeros and stay zeros: that is the zero-halo rule as it stands, and for the clipped-window rule
+// every cell of such a window carries its own eight weights (cell_border: the table shifted as the
+// reference's corner-anchored indexing shifts it, 0 for a neighbour that does not exist).
 // The first form of this kernel (4-cell strips, 2-8 waves per tile; profiles/r02_sweeps.md, section 4)
 // spent 3.3-5.5 us per step on a 16 x 40 window: a wave alone on its SIMD issues one instruction per 4
 // cycles and a strip was a chain of ~250 of them.  With 16 waves per window every SIMD has 4 waves to
@@ -922,6 +923,34 @@ __host__ __device__ constexpr int tile_rows(int rpw) { return kTileWaves * rpw; 
 // 2 buffers x 2 species x (rows + the rows above and below the window) x pitch
 __host__ __device__ constexpr size_t tile_lds_bytes(int rpw) { return (size_t)4 * (tile_rows(rpw) + 2) * kTilePitch * sizeof(float); }
 
+// One cell of a window that touches the grid's border, clipped-window rule, with the eight neighbour weights
+// of THIS cell in E (row-major, centre left out): the reference indexes its weight table from the top-left
+// corner of the clipped window, so a cell without a row above / a column to its left uses the table shifted
+// by one row / column, and a neighbour outside the grid has no tap at all -- weight 0 here, which adds
+// +-0 to an accumulator that starts at +0: the same bits as no tap, as long as the neighbour's VALUE is
+// finite (cells outside the grid are kept at 0).  Every lane runs the same straight-line code: no selects.
+template <int FAST>
+__device__ __forceinline__ void cell_border(const GsStepArgs &a, const float (&E)[8], const Row3 &m, const Row3 &z, const Row3 &p,
+                                            float &out_u, float &out_v)
+{
+    const float u = z.u[1], v = z.v[1];
+    float acc_u = 0.0f, acc_v = 0.0f;
+    GS_TAP(acc_u, E[0], m.u[0], u); GS_TAP(acc_v, E[0], m.v[0], v);
+    GS_TAP(acc_u, E[1], m.u[1], u); GS_TAP(acc_v, E[1], m.v[1], v);
+    GS_TAP(acc_u, E[2], m.u[2], u); GS_TAP(acc_v, E[2], m.v[2], v);
+    GS_TAP(acc_u, E[3], z.u[0], u); GS_TAP(acc_v, E[3], z.v[0], v);
+    GS_TAP(acc_u, E[4], z.u[2], u); GS_TAP(acc_v, E[4], z.v[2], v);
+    GS_TAP(acc_u, E[5], p.u[0], u); GS_TAP(acc_v, E[5], p.v[0], v);
+    GS_TAP(acc_u, E[6], p.u[1], u); GS_TAP(acc_v, E[6], p.v[1], v);
+    GS_TAP(acc_u, E[7], p.u[2], u); GS_TAP(acc_v, E[7], p.v[2], v);
+    react<(FAST & 2) != 0>(a, u, v, acc_u, acc_v, out_u, out_v);
+}
+
+// K steps of a window.  EDGE: the window touches the grid's border.  Its cells outside the grid are zeros
+// and stay zeros; with the zero-halo rule (ZH = 1) that IS the rule and every cell runs the interior code;
+// with the clipped rule (ZH = 0) every cell runs cell_border with its own weights.  (The general flavour of
+// cell<>, per-tap selects, costs 1.57x an interior cell -- and while every workgroup has a CU to itself the
+// launch lasts as long as its slowest workgroup, a border window: this form costs 1.04x / 1.19x.)
 template <int RPW, bool EDGE, int FAST, int ZH>
 __device__ __forceinline__ void tile_steps(const GsStepArgs &a, float *lds, int K, int gr, int gc, int wave, int lane,
                                            float (&u)[RPW], float (&v)[RPW])
@@ -930,7 +959,31 @@ __device__ __forceinline__ void tile_steps(const GsStepArgs &a, float *lds, int 
     // element (buffer b, species s, window row r, window column c) = (2 b + s) * plane + (r + 1) * P + c + 1;
     // `o` = this lane's first cell in species 0 of buffer 0
     const int o = (wave * RPW + 1) * P + lane + 1;
-    const uint32_t la = (EDGE && gc == 0) ? 0xffffffffu : 0u, ra = (EDGE && gc + 1 >= a.cols) ? 0xffffffffu : 0u;
+    bool inside[RPW];
+    float E[RPW][8];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        inside[i] = !EDGE || (gr + i >= 0 && gr + i < a.rows && gc >= 0 && gc < a.cols);
+        if (EDGE && ZH == 0) {
+            // the table's shift for this cell: rows are wave-uniform (scalar selects), columns per lane
+            const int rs = gr + i == 0 ? 1 : 0;
+            const bool cs = gc == 0;
+            const bool left = gc - 1 >= 0 && gc - 1 < a.cols, right = gc + 1 >= 0 && gc + 1 < a.cols;
+            int t = 0;
+#pragma unroll
+            for (int dr = -1; dr <= 1; ++dr) {
+                const bool row_present = gr + i + dr >= 0 && gr + i + dr < a.rows;
+                const int ri = dr + 1 - rs < 0 ? 0 : dr + 1 - rs; // (-1 only for a row that does not exist)
+                float wrow[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    wrow[j] = !row_present ? 0.0f : (ri == 0 ? a.w[0][j] : (ri == 1 ? a.w[1][j] : a.w[2][j]));
+                E[i][t++] = left ? wrow[0] : 0.0f;                           // (no left neighbour at column 0)
+                if (dr != 0) E[i][t++] = cs ? wrow[0] : wrow[1];
+                E[i][t++] = right ? (cs ? wrow[1] : wrow[2]) : 0.0f;
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < RPW; ++i) { lds[o + i * P] = u[i]; lds[plane + o + i * P] = v[i]; }
     __syncthreads();
@@ -956,11 +1009,13 @@ __device__ __forceinline__ void tile_steps(const GsStepArgs &a, float *lds, int 
         float nu[RPW], nv[RPW];
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
-            const bool mrow = !EDGE || gr + i > 0, prow = !EDGE || gr + i + 1 < a.rows; // wave-uniform
-            cell<EDGE, FAST, Row3, ZH>(a, R[i], R[i + 1], R[i + 2], 1, mrow, prow, la, ra, nu[i], nv[i]);
+            if (EDGE && ZH == 0)
+                cell_border<FAST>(a, E[i], R[i], R[i + 1], R[i + 2], nu[i], nv[i]);
+            else
+                cell<false, FAST, Row3>(a, R[i], R[i + 1], R[i + 2], 1, true, true, 0u, 0u, nu[i], nv[i]);
         }
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) { u[i] = nu[i]; v[i] = nv[i]; }
+        for (int i = 0; i < RPW; ++i) { u[i] = inside[i] ? nu[i] : 0.0f; v[i] = inside[i] ? nv[i] : 0.0f; }
         if (s < K) { // publish for the next step (the other buffer: no wave can still be reading it)
             float *du = lds + (cur ^ 1) * 2 * plane + o;
 #pragma unroll
@@ -986,14 +1041,15 @@ __global__ __launch_bounds__(kTileWaves * 64) void GS_SUFFIX(gs_run_tile_k)(GsSt
     const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
     const int gr0 = tr * HO - K, gc0 = tc * WO - K; // global coordinates of window cell (0, 0)
     const int gr = gr0 + wave * RPW, gc = gc0 + lane; // this lane's first cell
-    // load (clamped to the grid: cells outside it are never used, they only have to be addressable)
+    // load; cells outside the grid are zeros (and stay zeros: tile_steps)
     float u[RPW], v[RPW];
     const int cc = min(max(gc, 0), a.cols - 1);
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const ptrdiff_t g = (ptrdiff_t)min(max(gr + i, 0), a.rows - 1) * a.pitch + cc;
-        u[i] = a.in_u[g];
-        v[i] = a.in_v[g];
+        const bool in = gr + i >= 0 && gr + i < a.rows && gc >= 0 && gc < a.cols;
+        u[i] = in ? a.in_u[g] : 0.0f;
+        v[i] = in ? a.in_v[g] : 0.0f;
     }
     // A window inside the grid runs code without any bounds logic; the others the general flavour, one
     // instantiation per boundary rule (as gs_step_tb_k).

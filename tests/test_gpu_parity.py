@@ -303,7 +303,7 @@ def test_tile_kernel_variants_and_auto_choice():
     # pinned (window and steps per launch from a cost model, gs_api.cpp: pick_tile_config); temporal
     # blocking for slab chains, pinned schedules and everything larger
     ref_u, ref_v = oracle.run(u0, v0, 29, ftz=True)
-    for kw, want in ((dict(), "tile16x64/"), (dict(devices=[0, 0], kernel=capi.GS_KERNEL_TILE), "tb-k"),
+    for kw, want in ((dict(), "tile"), (dict(devices=[0, 0], kernel=capi.GS_KERNEL_TILE), "tb-k"),
                      (dict(kernel=capi.GS_KERNEL_TB), "tb-k"), (dict(fuse_steps=4), "tb-k"), (dict(rows_per_block=8), "tb-k"),
                      (dict(devices=[0, 0]), "tb-k")):
         got_u, got_v, info = gpu_run(u0, v0, 29, args=args(**kw))
