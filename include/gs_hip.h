@@ -86,7 +86,7 @@ typedef struct gs_params {
 typedef enum gs_math { GS_MATH_STRICT = 0, GS_MATH_FUSED = 1 } gs_math;
 
 /* Which step kernel runs.  AUTO = STREAM for a single gs_step; inside gs_run, by grid size when nothing
- * is pinned: the LDS-resident whole-run kernel up to 4096 cells, TILE up to 1.5 M cells, TB with
+ * is pinned: the LDS-resident whole-run kernel up to 1536 cells, TILE up to 1.5 M cells, TB with
  * fuse_steps (default 4) above, for slab chains and whenever fuse_steps, rows_per_block, cols_per_lane,
  * split or use_graph pin a schedule. */
 typedef enum gs_kernel {

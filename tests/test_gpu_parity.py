@@ -323,15 +323,22 @@ def test_tile_kernel_variants_and_auto_choice():
 # ---- small grids: the whole run in one launch, LDS-resident ----------------------------------------
 @pytest.mark.parametrize("boundary", [capi.GS_BOUNDARY_CLIPPED, capi.GS_BOUNDARY_ZERO_HALO])
 def test_resident_kernel_small_grids(boundary):
-    """Grids of at most 4096 cells run gs_run as ONE launch (gs_run_resident_k); every shape class,
-    odd and even step counts (the result lands in the other slot), long runs, both boundary rules."""
-    for shape in [(1, 1), (1, 7), (7, 1), (2, 2), (3, 5), (8, 16), (16, 32), (17, 33), (32, 64), (64, 64), (1, 4096),
+    """Small grids run gs_run as ONE launch (gs_run_resident_k): up to 1536 cells by default (above, the
+    LDS-window kernel is faster), up to 4096 cells when a marching-kernel schedule is pinned; every shape
+    class, odd and even step counts (the result lands in the other slot), long runs, both boundary rules."""
+    for shape in [(1, 1), (1, 7), (7, 1), (2, 2), (3, 5), (8, 16), (16, 32), (17, 33), (32, 48), (32, 64), (64, 64), (1, 4096),
                   (4096, 1), (5, 819)]:
         u0, v0 = stress_fields(shape, 16)
+        pin = dict(cols_per_lane=1) if shape[0] * shape[1] > 1536 else {}
         for steps in (1, 2, 9, 256):
             ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True, boundary=boundary)
-            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(boundary=boundary))
+            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(boundary=boundary, **pin))
             assert info[0].startswith("resident-lds/") and info[1] == 1, info      # one launch
+            if pin:  # ... and nothing pinned: the window kernel
+                tile_u, tile_v, tinfo = gpu_run(u0, v0, steps, args=args(boundary=boundary))
+                assert tinfo[0].startswith("tile"), tinfo
+                assert_bits_equal(tile_u, ref_u, f"window kernel U {shape} steps {steps}")
+                assert_bits_equal(tile_v, ref_v, f"window kernel V {shape} steps {steps}")
             assert_bits_equal(got_u, ref_u, f"resident U {shape} steps {steps}")
             assert_bits_equal(got_v, ref_v, f"resident V {shape} steps {steps}")
     # just above the limit the ordinary kernels take over
@@ -340,11 +347,11 @@ def test_resident_kernel_small_grids(boundary):
 
 
 def test_resident_kernel_species_new_and_mixed_entry_points():
-    """Species::new on a 32 x 64 grid through 1000 steps in uneven calls, single steps in between
+    """Species::new on a 32 x 48 grid through 1000 steps in uneven calls, single steps in between
     (gs_step uses the stream kernel), parameters changed on the way, fused flavour within tolerance."""
     sim = Simulation.new(Parameters(), args())
-    species = sim.make_species([32, 64])
-    u, v = oracle.init_species(32, 64)
+    species = sim.make_species([32, 48])
+    u, v = oracle.init_species(32, 48)
     p = Parameters()
     for steps in (1, 7, 256, 333, 403):
         sim.perform_steps(species, steps)
@@ -355,7 +362,7 @@ def test_resident_kernel_species_new_and_mixed_entry_points():
         assert_bits_equal(iv.make_scalar_view(sim.context), v, f"V after +{steps}+1")
         p = Parameters(feed_rate=0.03, kill_rate=0.06, time_step=0.5) if steps == 7 else p
         sim.context.set_params(p)
-    u0, v0 = stress_fields((40, 100), 17)
+    u0, v0 = stress_fields((30, 50), 17)
     ref_u, ref_v = oracle.run(u0, v0, 50, ftz=True)
     got_u, got_v, info = gpu_run(u0, v0, 50, args=args(math=capi.GS_MATH_FUSED))
     assert info[0] == "resident-lds/fused"
