@@ -545,9 +545,6 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
 // window while every workgroup has a CU to itself; beyond 256 workgroups they run in rounds (two share a CU
 // at 0.87 of the time of two turns).  The model is within ~15 % of the measured rates from 64 x 128 to 1024 x
 // 1024 and picks the measured-best or second-best configuration on every grid of that table.
-// up to here kernel = auto runs the single-workgroup resident kernel; above, the window kernel is faster (1536
-// cells: 1630 against 1558 Mcells x steps / s; 2048: 1596 against 2062; 4096: 1695 against 4153; run 48)
-constexpr uint64_t kResidentAutoCells = 1536;
 constexpr uint64_t kTileAutoCells = 1536 * 1024; // above, the marching kernel is ahead (1080 x 1920: 380-420 k vs 350 k)
 void pick_tile_config(long rows, long cols, int *shape, int *k)
 {
@@ -1525,13 +1522,10 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     }
     const bool single = ctx->total_slabs() == 1;
     // Small grids (single slab, kernel = auto): the whole run is one launch with the grid resident
-    // in LDS (gs_run_resident_k) -- up to kResidentAutoCells cells, or up to what the kernel can hold when
-    // a marching-kernel schedule is pinned.
-    static const uint64_t resident_cells = std::getenv("GS_HIP_RESIDENT_CELLS") ? (uint64_t)std::atol(std::getenv("GS_HIP_RESIDENT_CELLS"))
-                                                                                : kResidentAutoCells;
-    const bool pinned = ctx->o.fuse_steps || ctx->o.rows_per_block || ctx->o.cols_per_lane || ctx->o.split > 1 || ctx->o.use_graph;
+    // in LDS (gs_run_resident_k) -- up to kGsResidentCells = 1536 cells; above, the window kernel is faster (1536
+    // cells: 1630 against 1558 Mcells x steps / s; 2048: 1596 against 2062; 4096: 1695 against 4153; run 48).
     if (single && ctx->o.kernel == GS_KERNEL_AUTO && u0->rows * u0->cols > 0 && steps > 0 &&
-        u0->rows * u0->cols <= (uint64_t)kGsResidentCells && (u0->rows * u0->cols <= resident_cells || pinned)) {
+        u0->rows * u0->cols <= (uint64_t)kGsResidentCells) {
         SlabRt &sl = ctx->slabs[0];
         GS_HIP(hipSetDevice(sl.device));
         GS_TRY(join_bands(ctx, sl.compute));
@@ -1564,7 +1558,7 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     const uint64_t cells = u0->rows * u0->cols;
     int auto_shape = -1, auto_k = 0;
     if (single && ctx->o.kernel == GS_KERNEL_AUTO && ctx->o.fuse_steps == 0 && ctx->o.rows_per_block == 0 &&
-        ctx->o.cols_per_lane == 0 && ctx->o.split <= 1 && !ctx->o.use_graph && cells > resident_cells &&
+        ctx->o.cols_per_lane == 0 && ctx->o.split <= 1 && !ctx->o.use_graph && cells > (uint64_t)kGsResidentCells &&
         cells < kTileAutoCells)
         pick_tile_config((long)u0->rows, (long)u0->cols, &auto_shape, &auto_k);
     if (single && cells > 0 && steps > 0 && (ctx->o.kernel == GS_KERNEL_TILE || auto_shape >= 0)) {

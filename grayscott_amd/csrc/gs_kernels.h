@@ -8,10 +8,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Largest grid (cells) gs_launch_resident_* takes: 4 planes x 4 B x cells = 64 KB of LDS.  Still 19 %
-// faster than the temporally blocked kernel there (profiles/r01_sweeps.md, run 118); at 8192 cells
-// (4 more cells per thread) it would not be.
-constexpr int kGsResidentCells = 4096;
+// Largest grid (cells) gs_launch_resident_* takes (4 planes of (rows + 2) x (cols + 2) floats in LDS: at most
+// 74 KB).  Above, the LDS-window kernel with its many workgroups is faster (profiles/r02_sweeps.md, section 10).
+constexpr int kGsResidentCells = 1536;
 // gs_launch_tile_*: the most time steps one launch advances its tiles by.
 constexpr int kGsTileMaxSteps = 8;
 

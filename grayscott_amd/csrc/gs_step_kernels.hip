@@ -324,57 +324,103 @@ constexpr int kResidentThreads = 1024;
 
 struct Row3 { float u[3], v[3]; }; // [0] = column c-1, [1] = c, [2] = c+1
 
+// One cell on or near the grid's border, clipped-window rule, with the eight neighbour weights
+// of THIS cell in E (row-major, centre left out): the reference indexes its weight table from the top-left
+// corner of the clipped window, so a cell without a row above / a column to its left uses the table shifted
+// by one row / column, and a neighbour outside the grid has no tap at all -- weight 0 here, which adds
+// +-0 to an accumulator that starts at +0: the same bits as no tap, as long as the neighbour's VALUE is
+// finite (cells outside the grid are kept at 0).  Every lane runs the same straight-line code: no selects.
+template <int FAST>
+__device__ __forceinline__ void cell_border(const GsStepArgs &a, const float (&E)[8], const Row3 &m, const Row3 &z, const Row3 &p,
+                                            float &out_u, float &out_v)
+{
+    const float u = z.u[1], v = z.v[1];
+    float acc_u = 0.0f, acc_v = 0.0f;
+    GS_TAP(acc_u, E[0], m.u[0], u); GS_TAP(acc_v, E[0], m.v[0], v);
+    GS_TAP(acc_u, E[1], m.u[1], u); GS_TAP(acc_v, E[1], m.v[1], v);
+    GS_TAP(acc_u, E[2], m.u[2], u); GS_TAP(acc_v, E[2], m.v[2], v);
+    GS_TAP(acc_u, E[3], z.u[0], u); GS_TAP(acc_v, E[3], z.v[0], v);
+    GS_TAP(acc_u, E[4], z.u[2], u); GS_TAP(acc_v, E[4], z.v[2], v);
+    GS_TAP(acc_u, E[5], p.u[0], u); GS_TAP(acc_v, E[5], p.v[0], v);
+    GS_TAP(acc_u, E[6], p.u[1], u); GS_TAP(acc_v, E[6], p.v[1], v);
+    GS_TAP(acc_u, E[7], p.u[2], u); GS_TAP(acc_v, E[7], p.v[2], v);
+    react<(FAST & 2) != 0>(a, u, v, acc_u, acc_v, out_u, out_v);
+}
+
+// The eight weights of the cell at (r, c) for the clipped-window rule (see cell_border): the table shifted by
+// one row for a cell of row 0 and by one column for a cell of column 0, 0 for a neighbour outside the grid.
+__device__ __forceinline__ void border_weights(const GsStepArgs &a, int r, int c, float (&E)[8])
+{
+    const int rs = r == 0 ? 1 : 0;
+    const bool cs = c == 0, left = c - 1 >= 0 && c - 1 < a.cols, right = c + 1 >= 0 && c + 1 < a.cols;
+    int t = 0;
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr) {
+        const bool row_present = r + dr >= 0 && r + dr < a.rows;
+        const int ri = dr + 1 - rs < 0 ? 0 : dr + 1 - rs; // (-1 only for a row that does not exist)
+        float wrow[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            wrow[j] = !row_present ? 0.0f : (ri == 0 ? a.w[0][j] : (ri == 1 ? a.w[1][j] : a.w[2][j]));
+        E[t++] = left ? wrow[0] : 0.0f; // (no left neighbour at column 0)
+        if (dr != 0) E[t++] = cs ? wrow[0] : wrow[1];
+        E[t++] = right ? (cs ? wrow[1] : wrow[2]) : 0.0f;
+    }
+}
+
+// The grid lives in LDS with a ring of zeros around it (pitch cols + 2, rows + 2 rows; two buffers per
+// species): every neighbour is addressable at a fixed offset and a neighbour outside the grid reads 0.
+// That IS the zero-halo rule (interior code for every cell, ZH = 1); for the clipped-window rule every cell
+// carries its own eight weights (cell_border).  No selects, no divergent branches in the step loop.
+template <int FAST, int ZH>
 __global__ __launch_bounds__(kResidentThreads) void GS_SUFFIX(gs_run_resident_k)(GsStepArgs a, int steps, int to_out)
 {
+    if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0); // half_diff: MODE.IEEE = 0
     extern __shared__ float lds[];
-    const int cells = a.rows * a.cols, cols = a.cols;
-    // planes in LDS: U slot 0, U slot 1, V slot 0, V slot 1 -- addressed by offset (a select between
+    const int cells = a.rows * a.cols, cols = a.cols, P = cols + 2, plane = (a.rows + 2) * P;
+    // planes in LDS: U buffer 0, U buffer 1, V buffer 0, V buffer 1 -- addressed by offset (a select between
     // pointers would make the compiler lose the address space and emit flat_load)
     constexpr int CPT = (kResidentCells + kResidentThreads - 1) / kResidentThreads; // cells per thread, at most
-    int idx[CPT], up[CPT], down[CPT], lt[CPT], rt[CPT], grow[CPT], gcol[CPT];
-    bool mrow[CPT], prow[CPT];
-    uint32_t la[CPT], ra[CPT];
+    for (int i = threadIdx.x; i < 4 * plane; i += kResidentThreads) lds[i] = 0.0f;      // the rings (and everything else)
+    __syncthreads();
+    int o[CPT], g[CPT];
+    bool live[CPT];
+    float E[CPT][8];
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        idx[k] = (int)threadIdx.x + k * kResidentThreads;
-        const bool live = idx[k] < cells;
-        const int r = live ? idx[k] / cols : 0, c = live ? idx[k] - r * cols : 0;
-        grow[k] = r;
-        gcol[k] = c;
-        mrow[k] = r > 0;                       // the row above / below exists
-        prow[k] = r + 1 < a.rows;
-        la[k] = c == 0 ? 0xffffffffu : 0u;     // the left / right neighbour column is absent
-        ra[k] = c + 1 >= cols ? 0xffffffffu : 0u;
-        up[k] = mrow[k] ? -cols : 0;           // clamped offsets: absent neighbours read a valid word
-        down[k] = prow[k] ? cols : 0;
-        lt[k] = c > 0 ? -1 : 0;
-        rt[k] = c + 1 < cols ? 1 : 0;
-        if (live) {
-            lds[idx[k]] = a.in_u[(ptrdiff_t)r * a.pitch + c];
-            lds[2 * cells + idx[k]] = a.in_v[(ptrdiff_t)r * a.pitch + c];
+        const int idx = (int)threadIdx.x + k * kResidentThreads;
+        live[k] = idx < cells;
+        const int r = live[k] ? idx / cols : 0, c = live[k] ? idx - r * cols : 0;
+        o[k] = (r + 1) * P + c + 1;
+        g[k] = r * a.pitch + c;
+        if (ZH == 0) border_weights(a, r, c, E[k]);
+        if (live[k]) {
+            lds[o[k]] = a.in_u[g[k]];
+            lds[2 * plane + o[k]] = a.in_v[g[k]];
         }
     }
     __syncthreads();
     int cur = 0;
     for (int s = 0; s < steps; ++s) {
-        const int iu = cur * cells, iv = 2 * cells + cur * cells;
-        const int ou = (cur ^ 1) * cells, ov = 2 * cells + (cur ^ 1) * cells;
+        const float *su = lds + cur * plane, *sv = lds + (2 + cur) * plane;
+        float *du = lds + (cur ^ 1) * plane, *dv = lds + (2 + (cur ^ 1)) * plane;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
-            if (idx[k] >= cells) continue;
-            const int o = idx[k];
-            Row3 m, z, p;
-            const int rows3[3] = {o + up[k], o, o + down[k]};
-            Row3 *dst[3] = {&m, &z, &p};
+            if (!live[k]) continue;
+            Row3 R[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                dst[i]->u[0] = lds[iu + rows3[i] + lt[k]]; dst[i]->u[1] = lds[iu + rows3[i]]; dst[i]->u[2] = lds[iu + rows3[i] + rt[k]];
-                dst[i]->v[0] = lds[iv + rows3[i] + lt[k]]; dst[i]->v[1] = lds[iv + rows3[i]]; dst[i]->v[2] = lds[iv + rows3[i] + rt[k]];
+                const int q = o[k] + (i - 1) * P;
+                R[i].u[0] = su[q - 1]; R[i].u[1] = su[q]; R[i].u[2] = su[q + 1];
+                R[i].v[0] = sv[q - 1]; R[i].v[1] = sv[q]; R[i].v[2] = sv[q + 1];
             }
             float nu, nv;
-            cell<true, 0, Row3>(a, m, z, p, 1, mrow[k], prow[k], la[k], ra[k], nu, nv);
-            lds[ou + o] = nu;
-            lds[ov + o] = nv;
+            if (ZH == 0)
+                cell_border<FAST>(a, E[k], R[0], R[1], R[2], nu, nv);
+            else
+                cell<false, FAST, Row3>(a, R[0], R[1], R[2], 1, true, true, 0u, 0u, nu, nv);
+            du[o[k]] = nu;
+            dv[o[k]] = nv;
         }
         __syncthreads();
         cur ^= 1;
@@ -383,9 +429,9 @@ __global__ __launch_bounds__(kResidentThreads) void GS_SUFFIX(gs_run_resident_k)
     float *gv = to_out ? a.out_v : const_cast<float *>(a.in_v);
 #pragma unroll
     for (int k = 0; k < CPT; ++k)
-        if (idx[k] < cells) {
-            gu[(ptrdiff_t)grow[k] * a.pitch + gcol[k]] = lds[cur * cells + idx[k]];
-            gv[(ptrdiff_t)grow[k] * a.pitch + gcol[k]] = lds[2 * cells + cur * cells + idx[k]];
+        if (live[k]) {
+            gu[g[k]] = lds[cur * plane + o[k]];
+            gv[g[k]] = lds[(2 + cur) * plane + o[k]];
         }
 }
 #endif // !GS_TB_OP_ONLY
@@ -923,29 +969,6 @@ __host__ __device__ constexpr int tile_rows(int rpw) { return kTileWaves * rpw; 
 // 2 buffers x 2 species x (rows + the rows above and below the window) x pitch
 __host__ __device__ constexpr size_t tile_lds_bytes(int rpw) { return (size_t)4 * (tile_rows(rpw) + 2) * kTilePitch * sizeof(float); }
 
-// One cell of a window that touches the grid's border, clipped-window rule, with the eight neighbour weights
-// of THIS cell in E (row-major, centre left out): the reference indexes its weight table from the top-left
-// corner of the clipped window, so a cell without a row above / a column to its left uses the table shifted
-// by one row / column, and a neighbour outside the grid has no tap at all -- weight 0 here, which adds
-// +-0 to an accumulator that starts at +0: the same bits as no tap, as long as the neighbour's VALUE is
-// finite (cells outside the grid are kept at 0).  Every lane runs the same straight-line code: no selects.
-template <int FAST>
-__device__ __forceinline__ void cell_border(const GsStepArgs &a, const float (&E)[8], const Row3 &m, const Row3 &z, const Row3 &p,
-                                            float &out_u, float &out_v)
-{
-    const float u = z.u[1], v = z.v[1];
-    float acc_u = 0.0f, acc_v = 0.0f;
-    GS_TAP(acc_u, E[0], m.u[0], u); GS_TAP(acc_v, E[0], m.v[0], v);
-    GS_TAP(acc_u, E[1], m.u[1], u); GS_TAP(acc_v, E[1], m.v[1], v);
-    GS_TAP(acc_u, E[2], m.u[2], u); GS_TAP(acc_v, E[2], m.v[2], v);
-    GS_TAP(acc_u, E[3], z.u[0], u); GS_TAP(acc_v, E[3], z.v[0], v);
-    GS_TAP(acc_u, E[4], z.u[2], u); GS_TAP(acc_v, E[4], z.v[2], v);
-    GS_TAP(acc_u, E[5], p.u[0], u); GS_TAP(acc_v, E[5], p.v[0], v);
-    GS_TAP(acc_u, E[6], p.u[1], u); GS_TAP(acc_v, E[6], p.v[1], v);
-    GS_TAP(acc_u, E[7], p.u[2], u); GS_TAP(acc_v, E[7], p.v[2], v);
-    react<(FAST & 2) != 0>(a, u, v, acc_u, acc_v, out_u, out_v);
-}
-
 // K steps of a window.  EDGE: the window touches the grid's border.  Its cells outside the grid are zeros
 // and stay zeros; with the zero-halo rule (ZH = 1) that IS the rule and every cell runs the interior code;
 // with the clipped rule (ZH = 0) every cell runs cell_border with its own weights.  (The general flavour of
@@ -964,25 +987,7 @@ __device__ __forceinline__ void tile_steps(const GsStepArgs &a, float *lds, int 
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         inside[i] = !EDGE || (gr + i >= 0 && gr + i < a.rows && gc >= 0 && gc < a.cols);
-        if (EDGE && ZH == 0) {
-            // the table's shift for this cell: rows are wave-uniform (scalar selects), columns per lane
-            const int rs = gr + i == 0 ? 1 : 0;
-            const bool cs = gc == 0;
-            const bool left = gc - 1 >= 0 && gc - 1 < a.cols, right = gc + 1 >= 0 && gc + 1 < a.cols;
-            int t = 0;
-#pragma unroll
-            for (int dr = -1; dr <= 1; ++dr) {
-                const bool row_present = gr + i + dr >= 0 && gr + i + dr < a.rows;
-                const int ri = dr + 1 - rs < 0 ? 0 : dr + 1 - rs; // (-1 only for a row that does not exist)
-                float wrow[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    wrow[j] = !row_present ? 0.0f : (ri == 0 ? a.w[0][j] : (ri == 1 ? a.w[1][j] : a.w[2][j]));
-                E[i][t++] = left ? wrow[0] : 0.0f;                           // (no left neighbour at column 0)
-                if (dr != 0) E[i][t++] = cs ? wrow[0] : wrow[1];
-                E[i][t++] = right ? (cs ? wrow[1] : wrow[2]) : 0.0f;
-            }
-        }
+        if (EDGE && ZH == 0) border_weights(a, gr + i, gc, E[i]); // rows are wave-uniform: scalar selects
     }
 #pragma unroll
     for (int i = 0; i < RPW; ++i) { lds[o + i * P] = u[i]; lds[plane + o + i * P] = v[i]; }
@@ -1211,15 +1216,32 @@ hipError_t GS_SUFFIX(gs_launch_simple)(const GsStepArgs &a, hipStream_t s, const
 // the result is stored in the out-planes when steps is odd, else back in the in-planes.
 hipError_t GS_SUFFIX(gs_launch_resident)(const GsStepArgs &a, int steps, hipStream_t s, const char **name)
 {
-    if (name) *name = "resident-lds/" GS_MATH_NAME;
+    static const char *const names[2] = {"resident-lds/" GS_MATH_NAME, "resident-lds/" GS_MATH_NAME ".op"};
     const long cells = (long)a.rows * a.cols;
     if (a.rows <= 0 || a.cols <= 0 || cells > kResidentCells || steps < 0 || a.top_present || a.bottom_present)
         return hipErrorInvalidValue;
+    int fast = a.fast & (GS_MATH_FUSED ? 0 : 3);
+    if (fast != 3) fast = 0; // only the variant for the default parameters is built besides the general one
+    if (name) *name = names[fast ? 1 : 0];
+    const void *fn = nullptr;
+    const int zh = a.zero_halo ? 1 : 0;
+#define GS_RES_FN(F, Z) reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_resident_k)<F, Z>)
+    if (fast) fn = zh ? GS_RES_FN(GS_MATH_FUSED ? 0 : 3, 1) : GS_RES_FN(GS_MATH_FUSED ? 0 : 3, 0);
+    else fn = zh ? GS_RES_FN(0, 1) : GS_RES_FN(0, 0);
+#undef GS_RES_FN
+    const size_t lds = (size_t)4 * (a.rows + 2) * (a.cols + 2) * sizeof(float); // <= 74 KB (1 x 1536 cells)
+    if (lds > 64 * 1024) { // more than 64 KB of dynamic LDS needs the opt-in, per device function
+        static bool attr_set[2][2] = {{false, false}, {false, false}};
+        if (!attr_set[fast ? 1 : 0][zh]) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set[fast ? 1 : 0][zh] = true;
+        }
+    }
     GsStepArgs args = a;
     int to_out = steps & 1;
     void *kargs[] = {&args, &steps, &to_out};
-    return hipLaunchKernel(reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_resident_k)), dim3(1), dim3(kResidentThreads),
-                           kargs, (size_t)cells * 4 * sizeof(float), s);
+    return hipLaunchKernel(fn, dim3(1), dim3(kResidentThreads), kargs, lds, s);
 }
 
 // K <= kGsTileMaxSteps time steps of a single slab in one launch of gs_run_tile_k (in-planes -> out-planes).

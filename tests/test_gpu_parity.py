@@ -323,26 +323,25 @@ def test_tile_kernel_variants_and_auto_choice():
 # ---- small grids: the whole run in one launch, LDS-resident ----------------------------------------
 @pytest.mark.parametrize("boundary", [capi.GS_BOUNDARY_CLIPPED, capi.GS_BOUNDARY_ZERO_HALO])
 def test_resident_kernel_small_grids(boundary):
-    """Small grids run gs_run as ONE launch (gs_run_resident_k): up to 1536 cells by default (above, the
-    LDS-window kernel is faster), up to 4096 cells when a marching-kernel schedule is pinned; every shape
-    class, odd and even step counts (the result lands in the other slot), long runs, both boundary rules."""
-    for shape in [(1, 1), (1, 7), (7, 1), (2, 2), (3, 5), (8, 16), (16, 32), (17, 33), (32, 48), (32, 64), (64, 64), (1, 4096),
-                  (4096, 1), (5, 819)]:
+    """Grids of at most 1536 cells run gs_run as ONE launch (gs_run_resident_k; above, the LDS-window kernel
+    is faster): every shape class, odd and even step counts (the result lands in the other slot), long
+    runs, both boundary rules, default and general parameters (the specialised and the general variant)."""
+    for shape in [(1, 1), (1, 7), (7, 1), (2, 2), (3, 5), (8, 16), (16, 32), (17, 33), (32, 48), (1, 1536), (1536, 1), (5, 307)]:
         u0, v0 = stress_fields(shape, 16)
-        pin = dict(cols_per_lane=1) if shape[0] * shape[1] > 1536 else {}
         for steps in (1, 2, 9, 256):
             ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True, boundary=boundary)
-            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(boundary=boundary, **pin))
-            assert info[0].startswith("resident-lds/") and info[1] == 1, info      # one launch
-            if pin:  # ... and nothing pinned: the window kernel
-                tile_u, tile_v, tinfo = gpu_run(u0, v0, steps, args=args(boundary=boundary))
-                assert tinfo[0].startswith("tile"), tinfo
-                assert_bits_equal(tile_u, ref_u, f"window kernel U {shape} steps {steps}")
-                assert_bits_equal(tile_v, ref_v, f"window kernel V {shape} steps {steps}")
+            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(boundary=boundary))
+            assert info[0] == "resident-lds/strict.op" and info[1] == 1, info      # one launch
             assert_bits_equal(got_u, ref_u, f"resident U {shape} steps {steps}")
             assert_bits_equal(got_v, ref_v, f"resident V {shape} steps {steps}")
+        params = Parameters(feed_rate=0.03, kill_rate=0.06, time_step=0.5)
+        ref_u, ref_v = oracle.run(u0, v0, 9, params=oracle_params(params), ftz=True, boundary=boundary)
+        got_u, got_v, info = gpu_run(u0, v0, 9, params=params, args=args(boundary=boundary))
+        assert info[0] == "resident-lds/strict", info
+        assert_bits_equal(got_u, ref_u, f"resident U {shape}, general parameters")
+        assert_bits_equal(got_v, ref_v, f"resident V {shape}, general parameters")
     # just above the limit the ordinary kernels take over
-    u0, v0 = stress_fields((64, 65), 16)
+    u0, v0 = stress_fields((32, 49), 16)
     assert not gpu_run(u0, v0, 8, args=args(boundary=boundary))[2][0].startswith("resident")
 
 
