@@ -73,6 +73,40 @@ def test_golden_vectors():
         assert_bits_equal(in_v.make_scalar_view(sim.context), g[f"v_{steps}"], f"species_new V {steps}")
 
 
+@pytest.mark.parametrize("kw", [dict(kernel=capi.GS_KERNEL_SIMPLE), dict(kernel=capi.GS_KERNEL_STREAM), dict(kernel=capi.GS_KERNEL_LDS),
+                                dict(kernel=capi.GS_KERNEL_TB), dict(kernel=capi.GS_KERNEL_TB, cols_per_lane=1, rows_per_block=4),
+                                dict(kernel=capi.GS_KERNEL_TB, cols_per_lane=2, fuse_steps=3), dict(kernel=capi.GS_KERNEL_TB, cols_per_lane=4, fuse_steps=2),
+                                dict(kernel=capi.GS_KERNEL_TILE, tile_shape=1), dict(kernel=capi.GS_KERNEL_TILE, tile_shape=2),
+                                dict(kernel=capi.GS_KERNEL_TILE, tile_shape=3, fuse_steps=5), dict(devices=[0, 0, 0])],
+                         ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+def test_golden_vectors_every_kernel(kw):
+    """The committed fixtures (inputs and expected outputs, no oracle at run time) through every kernel
+    family and a slab chain, not only through what kernel = auto picks for their sizes."""
+    for path in sorted(glob.glob(os.path.join(GOLDEN, "stress_*.npz"))):
+        g = np.load(path)
+        if len(kw.get("devices", [0])) > g["u0"].shape[0]:
+            continue                                            # fewer rows than slabs
+        for steps in (1, 20):
+            got_u, got_v, _ = gpu_run(g["u0"], g["v0"], steps, args=args(**kw))
+            assert_bits_equal(got_u, g[f"u_{steps}"], f"{os.path.basename(path)} U {steps} {kw}")
+            assert_bits_equal(got_v, g[f"v_{steps}"], f"{os.path.basename(path)} V {steps} {kw}")
+    g = np.load(os.path.join(GOLDEN, "species_new_64x128.npz"))
+    sim = Simulation.new(Parameters(), args(**kw))
+    species = sim.make_species([64, 128])
+    done = 0
+    for steps in (1, 10, 100, 1000):
+        sim.perform_steps(species, steps - done)
+        done = steps
+        in_u, in_v, _, _ = species.in_out()
+        assert_bits_equal(in_u.make_scalar_view(sim.context), g[f"u_{steps}"], f"species_new U {steps} {kw}")
+        assert_bits_equal(in_v.make_scalar_view(sim.context), g[f"v_{steps}"], f"species_new V {steps} {kw}")
+    g = np.load(os.path.join(GOLDEN, "zero_halo_64x128.npz"))
+    for steps in (1, 20):
+        got_u, got_v, _ = gpu_run(g["stress_u0"], g["stress_v0"], steps, args=args(boundary=capi.GS_BOUNDARY_ZERO_HALO, **kw))
+        assert_bits_equal(got_u, g[f"stress_u_{steps}"], f"zero halo stress U {steps} {kw}")
+        assert_bits_equal(got_v, g[f"stress_v_{steps}"], f"zero halo stress V {steps} {kw}")
+
+
 def test_golden_vectors_zero_halo_and_stencils():
     """The committed fixtures of the widened rows, without the oracle at run time."""
     from grayscott_amd.simulation import STENCILS
