@@ -1,6 +1,9 @@
 """Randomised parity: hypothesis draws shapes, parameters, step counts and scheduling options
-(kernel, fused steps, unit height, row bands, in-process slabs); every combination must be
+(kernel incl. the LDS-window kernel and its window shapes, fused steps, unit height, row bands, in-process
+slabs, or nothing pinned at all: kernel = auto's own choice); every combination must be
 bit-identical to the oracle.  Scheduling options never change results -- that is the property."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
@@ -21,9 +24,10 @@ def cases(draw):
     cols = draw(st.one_of(st.integers(1, 40), st.integers(240, 270), st.integers(480, 530), st.integers(990, 1040)))
     steps = draw(st.integers(1, 13))
     seed = draw(st.integers(0, 2 ** 16))
-    kernel = draw(st.sampled_from([capi.GS_KERNEL_AUTO, capi.GS_KERNEL_STREAM, capi.GS_KERNEL_TB, capi.GS_KERNEL_SIMPLE,
-                                   capi.GS_KERNEL_LDS]))
-    fuse = draw(st.integers(0, 4))
+    kernel = draw(st.sampled_from([capi.GS_KERNEL_AUTO, capi.GS_KERNEL_AUTO, capi.GS_KERNEL_STREAM, capi.GS_KERNEL_TB, capi.GS_KERNEL_SIMPLE,
+                                   capi.GS_KERNEL_LDS, capi.GS_KERNEL_TILE]))
+    fuse = draw(st.integers(0, 8 if kernel == capi.GS_KERNEL_TILE else 4))
+    tile_shape = draw(st.integers(0, 3))
     rpb = draw(st.sampled_from([0, 1, 2, 3, 5, 8, 16, 33]))
     split = draw(st.integers(0, 4))
     slabs = draw(st.integers(1, 4))
@@ -41,13 +45,17 @@ def cases(draw):
                    kill_rate=draw(st.sampled_from([0.054, 0.06])),
                    time_step=draw(st.sampled_from([1.0, 0.5, 0.75])))
     tiny = draw(st.booleans())  # sprinkle values near the flush-to-zero threshold
-    return rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny, cpl, general, graph, boundary
+    if kernel == capi.GS_KERNEL_AUTO and draw(st.booleans()):
+        # nothing pinned, one slab: what kernel = auto picks by grid size (resident / window / marching kernel)
+        fuse = rpb = split = cpl = graph = 0
+        slabs = 1
+    return rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny, cpl, general, graph, boundary, tile_shape
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=int(os.environ.get("GS_PROPERTY_EXAMPLES", "80")), deadline=None, suppress_health_check=list(HealthCheck))
 @given(cases())
 def test_any_schedule_matches_the_oracle(built, case):
-    rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny, cpl, general, graph, boundary = case
+    rows, cols, steps, seed, kernel, fuse, rpb, split, slabs, p, tiny, cpl, general, graph, boundary, tile_shape = case
     steps = steps * 9 if graph else steps   # long enough for at least one batch of 16 passes
     slabs = min(slabs, rows)
     rng = np.random.default_rng(seed)
@@ -62,8 +70,9 @@ def test_any_schedule_matches_the_oracle(built, case):
     ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True, boundary=boundary)
     got_u, got_v, info = gpu_run(u0, v0, steps, params=p,
                                  args=args(kernel=kernel, fuse_steps=fuse, rows_per_block=rpb, split=split,
-                                           devices=[0] * slabs, cols_per_lane=cpl, general_kernels=general, use_graph=graph, boundary=boundary))
-    what = (f"{rows}x{cols} steps={steps} kernel={info[0]} fuse={fuse} rpb={rpb} split={split} slabs={slabs} "
+                                           devices=[0] * slabs, cols_per_lane=cpl, general_kernels=general, use_graph=graph, boundary=boundary,
+                                           tile_shape=tile_shape))
+    what = (f"{rows}x{cols} steps={steps} kernel={info[0]} fuse={fuse} rpb={rpb} split={split} slabs={slabs} tile_shape={tile_shape} "
             f"cpl={cpl} general={general} graph={graph} boundary={boundary} {p}")
     assert_bits_equal(got_u, ref_u, "U " + what)
     assert_bits_equal(got_v, ref_v, "V " + what)
