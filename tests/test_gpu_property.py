@@ -76,3 +76,41 @@ def test_any_schedule_matches_the_oracle(built, case):
             f"cpl={cpl} general={general} graph={graph} boundary={boundary} {p}")
     assert_bits_equal(got_u, ref_u, "U " + what)
     assert_bits_equal(got_v, ref_v, "V " + what)
+
+
+@st.composite
+def larger_cases(draw):
+    """Grids from 40 k to 2.7 M cells: the window kernel's three windows, its hand-over to the marching kernel at
+    1.5 M cells, single- and multi-round launches of the marching kernel (halved edge units, tapered tails)."""
+    rows = draw(st.integers(200, 1300))
+    cols = draw(st.integers(200, 2100))
+    steps = draw(st.integers(1, 12))
+    seed = draw(st.integers(0, 2 ** 16))
+    kernel = draw(st.sampled_from([capi.GS_KERNEL_AUTO, capi.GS_KERNEL_AUTO, capi.GS_KERNEL_TB, capi.GS_KERNEL_TILE]))
+    pinned = kernel != capi.GS_KERNEL_AUTO or draw(st.booleans())
+    fuse = draw(st.integers(0, 8 if kernel == capi.GS_KERNEL_TILE else 4)) if pinned else 0
+    rpb = draw(st.sampled_from([0, 0, 3, 8, 10, 16, 21, 39, 64])) if pinned else 0
+    cpl = draw(st.sampled_from([0, 1, 2, 4])) if pinned else 0
+    slabs = draw(st.sampled_from([1, 1, 2, 3])) if pinned else 1
+    tile_shape = draw(st.integers(0, 3))
+    boundary = draw(st.integers(0, 1))
+    default_params = draw(st.booleans())
+    return rows, cols, steps, seed, kernel, fuse, rpb, cpl, slabs, tile_shape, boundary, default_params
+
+
+@settings(max_examples=int(os.environ.get("GS_PROPERTY_EXAMPLES_LARGER", "12")), deadline=None, suppress_health_check=list(HealthCheck))
+@given(larger_cases())
+def test_any_schedule_matches_the_oracle_larger_grids(built, case):
+    rows, cols, steps, seed, kernel, fuse, rpb, cpl, slabs, tile_shape, boundary, default_params = case
+    rng = np.random.default_rng(seed)
+    u0 = rng.random((rows, cols), dtype=np.float32)
+    v0 = (rng.random((rows, cols), dtype=np.float32) * np.float32(0.5)).astype(np.float32)
+    p = Parameters() if default_params else Parameters(feed_rate=0.03, kill_rate=0.06, time_step=0.5)
+    ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True, boundary=boundary)
+    got_u, got_v, info = gpu_run(u0, v0, steps, params=p,
+                                 args=args(kernel=kernel, fuse_steps=fuse, rows_per_block=rpb, devices=[0] * slabs,
+                                           cols_per_lane=cpl, boundary=boundary, tile_shape=tile_shape))
+    what = (f"{rows}x{cols} steps={steps} kernel={info[0]} fuse={fuse} rpb={rpb} slabs={slabs} cpl={cpl} "
+            f"tile_shape={tile_shape} boundary={boundary} default_params={default_params}")
+    assert_bits_equal(got_u, ref_u, "U " + what)
+    assert_bits_equal(got_v, ref_v, "V " + what)
