@@ -381,14 +381,15 @@ __global__ __launch_bounds__(kResidentThreads) void GS_SUFFIX(gs_run_resident_k)
     // planes in LDS: U buffer 0, U buffer 1, V buffer 0, V buffer 1 -- addressed by offset (a select between
     // pointers would make the compiler lose the address space and emit flat_load)
     constexpr int CPT = (kResidentCells + kResidentThreads - 1) / kResidentThreads; // cells per thread, at most
-    for (int i = threadIdx.x; i < 4 * plane; i += kResidentThreads) lds[i] = 0.0f;      // the rings (and everything else)
+    const int nthreads = (int)blockDim.x; // as many waves as hold cells, at most kResidentThreads (the launcher)
+    for (int i = threadIdx.x; i < 4 * plane; i += nthreads) lds[i] = 0.0f;               // the rings (and everything else)
     __syncthreads();
     int o[CPT], g[CPT];
     bool live[CPT];
     float E[CPT][8];
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        const int idx = (int)threadIdx.x + k * kResidentThreads;
+        const int idx = (int)threadIdx.x + k * nthreads;
         live[k] = idx < cells;
         const int r = live[k] ? idx / cols : 0, c = live[k] ? idx - r * cols : 0;
         o[k] = (r + 1) * P + c + 1;
@@ -1241,7 +1242,9 @@ hipError_t GS_SUFFIX(gs_launch_resident)(const GsStepArgs &a, int steps, hipStre
     GsStepArgs args = a;
     int to_out = steps & 1;
     void *kargs[] = {&args, &steps, &to_out};
-    return hipLaunchKernel(fn, dim3(1), dim3(kResidentThreads), kargs, lds, s);
+    // only the waves that hold cells take part (and in the barrier of every step)
+    const long threads = cells >= kResidentThreads ? kResidentThreads : ((cells + 63) / 64) * 64;
+    return hipLaunchKernel(fn, dim3(1), dim3((unsigned)threads), kargs, lds, s);
 }
 
 // K <= kGsTileMaxSteps time steps of a single slab in one launch of gs_run_tile_k (in-planes -> out-planes).
