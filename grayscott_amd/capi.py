@@ -37,6 +37,7 @@ EXPORTS = (
     "gs_step", "gs_run", "gs_sync", "gs_timer_start", "gs_timer_stop", "gs_ctx_info",
     "gs_host_alloc", "gs_host_free", "gs_field_download_async", "gs_download_wait",
     "gs_ctx_get_tuned", "gs_ctx_set_tuned", "gs_ctx_comm_info", "gs_field_colormap",
+    "gs_ctx_stats", "gs_ctx_set_pass_timing",
 )
 
 
@@ -77,6 +78,22 @@ class GsOptions(ctypes.Structure):
         ("no_tune", ctypes.c_int32),
         ("tile_shape", ctypes.c_int32),
         ("reserved", ctypes.c_int32 * 4),
+    ]
+
+
+class GsStats(ctypes.Structure):
+    """``gs_stats`` (include/gs_hip.h)."""
+
+    _fields_ = [
+        ("passes", ctypes.c_uint64),
+        ("steps", ctypes.c_uint64),
+        ("launches", ctypes.c_uint64),
+        ("ghost_refreshes", ctypes.c_uint64),
+        ("timed_passes", ctypes.c_uint64),
+        ("halo_ms", ctypes.c_float),
+        ("interior_ms", ctypes.c_float),
+        ("halo_exposed_ms", ctypes.c_float),
+        ("reserved", ctypes.c_float),
     ]
 
 
@@ -130,6 +147,8 @@ def load() -> ctypes.CDLL:
         "gs_ctx_set_tuned": (i32, [vp, u64, u64, i32, i32, i32]),
         "gs_ctx_comm_info": (i32, [vp, P(i32), P(i32), P(i32)]),
         "gs_field_colormap": (i32, [vp, vp, f32, vp, i32, vp]),
+        "gs_ctx_stats": (i32, [vp, P(GsStats)]),
+        "gs_ctx_set_pass_timing": (i32, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

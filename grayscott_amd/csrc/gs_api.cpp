@@ -153,6 +153,10 @@ struct SlabRt {
     hipEvent_t staged = nullptr, copied = nullptr; // asynchronous downloads
     float *stage = nullptr;                        // dense device staging buffer
     size_t stage_floats = 0;
+    // gs_ctx_set_pass_timing: per timed pass, events around the halo stream's work (boundary-band kernel +
+    // ghost-row exchange: th0, th1) and around the interior kernel on the compute stream (tc0, tc1)
+    std::vector<hipEvent_t> th0, th1, tc0, tc1;
+    int timed = 0; // passes recorded since the timing was switched on
 };
 
 struct gs_ctx {
@@ -168,6 +172,8 @@ struct gs_ctx {
     ncclComm_t comm = nullptr;
     const char *last_kernel = "none";
     uint64_t launches = 0;
+    uint64_t passes = 0, steps_done = 0, ghost_refreshes = 0; // gs_ctx_stats
+    int pass_timing = 0;                                      // passes per slab still to be timed (0 = off)
     // Configuration of the temporally blocked kernel in force (tuned_rpu > 0): unit height, fused steps
     // per pass and columns per lane for slabs of tuned_rows x tuned_cols -- chosen by gs_run's on-line
     // tuner (single-slab contexts) or handed in through gs_ctx_set_tuned (slab chains).
@@ -342,6 +348,7 @@ int min_slab_rows(const gs_ctx *ctx, const gs_field *f)
 int32_t refresh_ghosts(gs_ctx *ctx, gs_field *f)
 {
     if (ctx->total_slabs() > 1) {
+        ctx->ghost_refreshes++;
         GS_TRY(sync_all(ctx));
         gs_field *planes[1] = {f};
         const int depth = min_slab_rows(ctx, f) < kGhostRows ? min_slab_rows(ctx, f) : kGhostRows;
@@ -669,6 +676,8 @@ int32_t step_bands(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u,
     }
     ctx->bands_active = true;
     ctx->step_no++;
+    ctx->passes++;
+    ctx->steps_done += (uint64_t)fuse;
     out_u->ghost_depth = fuse;
     out_v->ghost_depth = fuse;
     return GS_OK;
@@ -709,10 +718,18 @@ int32_t step_impl(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, 
             GS_HIP(hipSetDevice(sl.device));
             GsStepArgs a = make_args(ctx, in_u, in_v, out_u, out_v, i, fuse);
             const int n = a.rows;
+            // gs_ctx_set_pass_timing: events around this pass's halo-stream work and interior kernel
+            const bool timed = sl.timed < ctx->pass_timing;
+            if (timed && (int)sl.th0.size() <= sl.timed) {
+                hipEvent_t ev[4];
+                for (auto &e : ev) GS_HIP(hipEventCreate(&e));
+                sl.th0.push_back(ev[0]); sl.th1.push_back(ev[1]); sl.tc0.push_back(ev[2]); sl.tc1.push_back(ev[3]);
+            }
             // halo stream: boundary rows, then the exchange
             GS_HIP(hipStreamWaitEvent(sl.halo, sl.done[q], 0));
             if (i > 0) GS_HIP(hipStreamWaitEvent(sl.halo, ctx->slabs[i - 1].halod[q], 0));
             if (i < n_local - 1) GS_HIP(hipStreamWaitEvent(sl.halo, ctx->slabs[i + 1].halod[q], 0));
+            if (timed) GS_HIP(hipEventRecord(sl.th0[sl.timed], sl.halo));
             GsStepArgs b = a;
             b.ra0 = 0;
             b.ra1 = n <= 2 * fuse ? n : fuse;
@@ -722,17 +739,25 @@ int32_t step_impl(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, 
             GS_TRY(launch_rows(ctx, b, sl.halo, fuse));
             GS_TRY(push_halo(ctx, outs, 2, i, sl.halo, fuse));
             GS_HIP(hipEventRecord(sl.halod[p], sl.halo));
+            if (timed) GS_HIP(hipEventRecord(sl.th1[sl.timed], sl.halo));
             // compute stream: interior rows
             GS_HIP(hipStreamWaitEvent(sl.compute, sl.halod[q], 0));
+            if (timed) GS_HIP(hipEventRecord(sl.tc0[sl.timed], sl.compute));
             if (n > 2 * fuse) {
                 a.ra0 = fuse;
                 a.ra1 = n - fuse;
                 GS_TRY(launch_rows(ctx, a, sl.compute, fuse));
             }
             GS_HIP(hipEventRecord(sl.done[p], sl.compute));
+            if (timed) {
+                GS_HIP(hipEventRecord(sl.tc1[sl.timed], sl.compute));
+                sl.timed++;
+            }
         }
     }
     ctx->step_no++;
+    ctx->passes++;
+    ctx->steps_done += (uint64_t)fuse;
     out_u->ghost_depth = fuse;
     out_v->ghost_depth = fuse;
     return GS_OK;
@@ -1086,7 +1111,7 @@ int32_t replay_graph_batches(Run &r, int kk)
     if (!ctx->graph_exec || !(ctx->graph_key == key)) {
         if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
         if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
-        const uint64_t n0 = r.n, step0 = ctx->step_no, launches0 = ctx->launches;
+        const uint64_t n0 = r.n, step0 = ctx->step_no, launches0 = ctx->launches, passes0 = ctx->passes, sd0 = ctx->steps_done;
         const int in0 = r.in;
         GS_HIP(hipStreamBeginCapture(sl.compute, hipStreamCaptureModeThreadLocal));
         int32_t st = GS_OK;
@@ -1094,6 +1119,7 @@ int32_t replay_graph_batches(Run &r, int kk)
         const hipError_t e = hipStreamEndCapture(sl.compute, &ctx->graph);
         // nothing ran: the captured passes are accounted for when the graph is launched
         r.n = n0; ctx->step_no = step0; ctx->launches = launches0; r.in = in0;
+        ctx->passes = passes0; ctx->steps_done = sd0;
         if (st != GS_OK) return st;
         if (e != hipSuccess) return fail(GS_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
         GS_HIP(hipGraphInstantiate(&ctx->graph_exec, ctx->graph, nullptr, nullptr, 0));
@@ -1104,6 +1130,8 @@ int32_t replay_graph_batches(Run &r, int kk)
         r.n += (uint64_t)kGraphBatch * kk;
         ctx->step_no += kGraphBatch;
         ctx->launches += kGraphBatch;
+        ctx->passes += kGraphBatch;
+        ctx->steps_done += (uint64_t)kGraphBatch * kk;
     }
     for (int i = 0; i < 2; ++i) { // as after the last pass of a batch
         r.u[i]->ghost_depth = kk;
@@ -1190,6 +1218,9 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
         if (sl.t1) (void)hipEventDestroy(sl.t1);
         if (sl.staged) (void)hipEventDestroy(sl.staged);
         if (sl.copied) (void)hipEventDestroy(sl.copied);
+        for (auto *v : {&sl.th0, &sl.th1, &sl.tc0, &sl.tc1})
+            for (auto e : *v)
+                if (e) (void)hipEventDestroy(e);
         if (sl.copy) { (void)hipStreamSynchronize(sl.copy); (void)hipStreamDestroy(sl.copy); }
         if (sl.stage) (void)hipFree(sl.stage);
         if (sl.halo) (void)hipStreamDestroy(sl.halo);
@@ -1244,7 +1275,7 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
         ctx->o.cols_per_lane != 4)
         st = fail(GS_ERR_INVALID, "cols_per_lane must be 0 (auto), 1, 2 or 4, not %d", ctx->o.cols_per_lane);
     if (st == GS_OK && (ctx->o.tile_shape < 0 || ctx->o.tile_shape > 3))
-        st = fail(GS_ERR_INVALID, "tile_shape must be 0 (auto), 1 (32 x 64), 2 (16 x 32) or 3 (8 x 32), not %d", ctx->o.tile_shape);
+        st = fail(GS_ERR_INVALID, "tile_shape must be 0 (auto), 1 (32 x 64), 2 (16 x 64) or 3 (64 x 64), not %d", ctx->o.tile_shape);
     if (st == GS_OK && ctx->o.boundary != GS_BOUNDARY_CLIPPED && ctx->o.boundary != GS_BOUNDARY_ZERO_HALO)
         st = fail(GS_ERR_INVALID, "unknown boundary rule %d", ctx->o.boundary);
     if (st != GS_OK) { delete ctx; return st; }
@@ -1541,6 +1572,8 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
             if (e != hipSuccess) return fail(GS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
             ctx->last_kernel = name;
             ctx->launches++;
+            ctx->passes++;
+            ctx->steps_done += (uint64_t)n;
             ctx->step_no += (uint64_t)n;
             slot ^= n & 1;
             left -= (uint64_t)n;
@@ -1550,7 +1583,7 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     }
     // Mid-size grids (single slab): K <= 8 steps per launch on LDS-resident windows (gs_run_tile_k), where a
     // pass of the temporally blocked kernel is bound by the length of a wave's march and a launch per <= 4
-    // steps.  kernel = auto picks it between the resident kernel's 4096 cells and 1.5 M cells when nothing
+    // steps.  kernel = auto picks it between the resident kernel's 1536 cells and 1.5 M cells when nothing
     // is pinned, with the window and steps per launch of pick_tile_config (profiles/r02_sweeps.md, section
     // 10: 2.2x at 64 x 128 and 128 x 256, 1.8x at 256 x 512, 1.4x at 512 x 1024; at 1080 x 1920 the marching
     // kernel is ahead again); GS_KERNEL_TILE forces it (tile_shape and fuse_steps then choose the window
@@ -1587,6 +1620,8 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
             if (e != hipSuccess) return fail(GS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
             if (!full_name || n == kmax) full_name = name;
             ctx->launches++;
+            ctx->passes++;
+            ctx->steps_done += (uint64_t)n;
             ctx->step_no++;
             slot ^= 1;
             left -= (uint64_t)n;
@@ -1595,10 +1630,16 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
         if (result_slot) *result_slot = slot;
         return GS_OK;
     }
-    // The short pass (steps % fuse) goes first so that a run ends on a full-depth ghost exchange
-    // and the next run can start without a blocking refresh.
-    if (steps % (uint64_t)fuse) GS_TRY(r.advance(1, (int)(steps % (uint64_t)fuse)));
+    // The short pass goes first so that a run ends on a full pass -- a full-depth ghost exchange -- and the
+    // next run can start without a blocking refresh.  It is sized with the steps per pass in force (a
+    // configuration handed in through gs_ctx_set_tuned may fuse fewer steps than `fuse`), which is known
+    // before anything runs on a slab chain; a single slab may still change it below (on-line tuning), where
+    // a remainder pass at the end costs nothing.
     recall_tuned(ctx, u0, fuse);
+    {
+        const int kk0 = tuned_shape(ctx, u0, fuse) && ctx->tuned_k > 0 && ctx->tuned_k <= fuse ? ctx->tuned_k : fuse;
+        if (steps % (uint64_t)kk0) GS_TRY(r.advance(1, (int)(steps % (uint64_t)kk0)));
+    }
     if (single && fuse > 1 && ctx->o.rows_per_block == 0 && !ctx->o.no_tune && !tuned_shape(ctx, u0, fuse))
         GS_TRY(tune_online(r, fuse));
     // Steps per full pass: the tuned value -- on a slab chain every process must have been given the
@@ -1791,6 +1832,49 @@ int32_t gs_ctx_comm_info(const gs_ctx *ctx, int32_t *rccl_ranks, int32_t *rccl_r
     if (rccl_ranks) *rccl_ranks = n;
     if (rccl_rank) *rccl_rank = r;
     if (rccl_device) *rccl_device = d;
+    return GS_OK;
+}
+
+int32_t gs_ctx_set_pass_timing(gs_ctx *ctx, int32_t passes)
+{
+    if (!ctx) return fail(GS_ERR_INVALID, "null context");
+    if (passes < 0 || passes > 4096) return fail(GS_ERR_INVALID, "pass timing covers 0 to 4096 passes, not %d", passes);
+    GS_TRY(sync_all(ctx)); // the events of an earlier window must not be re-recorded while in flight
+    ctx->pass_timing = passes;
+    for (auto &sl : ctx->slabs) sl.timed = 0;
+    return GS_OK;
+}
+
+int32_t gs_ctx_stats(gs_ctx *ctx, gs_stats *out)
+{
+    if (!ctx || !out) return fail(GS_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof *out);
+    out->passes = ctx->passes;
+    out->steps = ctx->steps_done;
+    out->launches = ctx->launches;
+    out->ghost_refreshes = ctx->ghost_refreshes;
+    // timed passes (slab chains only): the slowest local slab's sums
+    for (auto &sl : ctx->slabs) {
+        if (sl.timed == 0) continue;
+        GS_HIP(hipSetDevice(sl.device));
+        GS_HIP(hipEventSynchronize(sl.th1[sl.timed - 1]));
+        GS_HIP(hipEventSynchronize(sl.tc1[sl.timed - 1]));
+        double halo = 0.0, interior = 0.0, exposed = 0.0;
+        for (int k = 0; k < sl.timed; ++k) {
+            float h = 0.f, c = 0.f, x = 0.f;
+            GS_HIP(hipEventElapsedTime(&h, sl.th0[k], sl.th1[k]));
+            GS_HIP(hipEventElapsedTime(&c, sl.tc0[k], sl.tc1[k]));
+            // how long after the interior kernel's end the halo stream's work ended (<= 0: hidden)
+            GS_HIP(hipEventElapsedTime(&x, sl.tc1[k], sl.th1[k]));
+            halo += h; interior += c; exposed += x > 0.f ? x : 0.f;
+        }
+        if (interior + exposed >= (double)out->interior_ms + (double)out->halo_exposed_ms) {
+            out->timed_passes = (uint64_t)sl.timed;
+            out->halo_ms = (float)halo;
+            out->interior_ms = (float)interior;
+            out->halo_exposed_ms = (float)exposed;
+        }
+    }
     return GS_OK;
 }
 

@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
 // ------------------------------------------------------------------------------------
 // Mid-size grids: K <= 8 time steps per launch on LDS-resident windows, one cell per lane and row.
 //
-// Between the single-workgroup resident kernel (<= 4096 cells) and grids that fill the chip with
+// Between the single-workgroup resident kernel (<= 1536 cells) and grids that fill the chip with
 // marching waves (~1 M cells and up), a pass of gs_step_tb_k is bound by the LENGTH of a wave's march
 // (unit height + 2K ticks of K levels, one wave per SIMD issuing every 4th cycle) plus a dependent
 // launch per K <= 4 steps: 2.3-3.4 us per step whatever the grid (profiles/r02_criterion_grid.md).
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
 // ------------------------------------------------------------------------------------
 constexpr int kTileMaxK = kGsTileMaxSteps;
 constexpr int kTileCols = 64;                 // window columns = lanes
-constexpr int kTilePitch = kTileCols + 2;     // + window columns -1 and 64 (never valid, only addressable)
+constexpr int kTilePitch = kTileCols + 2;     // + window columns -1 and 64 (never valid, only addressable; zeroed)
 constexpr int kTileWaves = 16;                // 1024 threads
 __host__ __device__ constexpr int tile_rows(int rpw) { return kTileWaves * rpw; }
 // 2 buffers x 2 species x (rows + the rows above and below the window) x pitch
@@ -989,6 +989,22 @@ __device__ __forceinline__ void tile_steps(const GsStepArgs &a, float *lds, int 
     for (int i = 0; i < RPW; ++i) {
         inside[i] = !EDGE || (gr + i >= 0 && gr + i < a.rows && gc >= 0 && gc < a.cols);
         if (EDGE && ZH == 0) border_weights(a, gr + i, gc, E[i]); // rows are wave-uniform: scalar selects
+    }
+    // The ring around the window (rows -1 and H, columns -1 and 64 of all four planes) is only ever read
+    // into cells whose values are discarded; it is zeroed once per launch so that nothing -- not even a
+    // discarded value -- depends on what an earlier workgroup left in LDS.
+    {
+        const int ring_row = wave == 0 ? 0 : H + 1; // waves 0 and 15 also own the row above / below the window
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (lane < 2)
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) lds[b * plane + (wave * RPW + 1 + i) * P + lane * (P - 1)] = 0.0f;
+            if (wave == 0 || wave == kTileWaves - 1) {
+                lds[b * plane + ring_row * P + lane + 1] = 0.0f;
+                if (lane < 2) lds[b * plane + ring_row * P + lane * (P - 1)] = 0.0f;
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < RPW; ++i) { lds[o + i * P] = u[i]; lds[plane + o + i * P] = v[i]; }
@@ -1199,6 +1215,50 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_lds_k)(GsStepArgs a)
 } // namespace
 
 #if !GS_TB_OP_ONLY
+// Opt-in for more than 64 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize).  The attribute
+// belongs to the device function ON THE CURRENT DEVICE, so what has been set is remembered per (device,
+// function): a process that drives several GPUs (device_ids = 0, 1, ...; two contexts) opts in on each.
+// Contexts on different threads launch through here: the table has a lock, like tb_waves_of's.
+static bool dyn_lds_seen(int device, const void *fn, int bytes, bool record)
+{
+    struct Entry { int device; const void *fn; int bytes; };
+    static Entry table[256];
+    static int n = 0;
+    static std::mutex lock;
+    std::lock_guard<std::mutex> guard(lock);
+    for (int i = 0; i < n; ++i)
+        if (table[i].device == device && table[i].fn == fn) {
+            if (table[i].bytes >= bytes) return true;
+            if (record) table[i].bytes = bytes;
+            return false;
+        }
+    if (record && n < 256) table[n++] = Entry{device, fn, bytes};
+    return false;
+}
+static hipError_t ensure_dyn_lds(const void *fn, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return hipSuccess;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    if (dyn_lds_seen(device, fn, (int)bytes, false)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) (void)dyn_lds_seen(device, fn, (int)bytes, true);
+    return e;
+}
+// What the table above keys on, for the unit test of the key (tests/test_capi_cpu.py): 1 when (device, fn
+// slot, bytes) is new, and it is recorded; 0 when a launch on that device would skip the call.
+#if !GS_MATH_FUSED
+extern "C" int32_t gs_debug_dyn_lds_key(int32_t device, int32_t slot, int32_t bytes)
+{
+    static const char slots[16] = {0};
+    if (slot < 0 || slot >= 16) return -1;
+    if (dyn_lds_seen(-1000 - device, &slots[slot], bytes, false)) return 0;
+    (void)dyn_lds_seen(-1000 - device, &slots[slot], bytes, true);
+    return 1;
+}
+#endif
+
 hipError_t GS_SUFFIX(gs_launch_simple)(const GsStepArgs &a, hipStream_t s, const char **name)
 {
     if (name) *name = "simple/" GS_MATH_NAME;
@@ -1231,13 +1291,9 @@ hipError_t GS_SUFFIX(gs_launch_resident)(const GsStepArgs &a, int steps, hipStre
     else fn = zh ? GS_RES_FN(0, 1) : GS_RES_FN(0, 0);
 #undef GS_RES_FN
     const size_t lds = (size_t)4 * (a.rows + 2) * (a.cols + 2) * sizeof(float); // <= 74 KB (1 x 1536 cells)
-    if (lds > 64 * 1024) { // more than 64 KB of dynamic LDS needs the opt-in, per device function
-        static bool attr_set[2][2] = {{false, false}, {false, false}};
-        if (!attr_set[fast ? 1 : 0][zh]) {
-            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            if (e != hipSuccess) return e;
-            attr_set[fast ? 1 : 0][zh] = true;
-        }
+    { // more than 64 KB of dynamic LDS needs the opt-in, per device and device function
+        const hipError_t e = ensure_dyn_lds(fn, lds > 64 * 1024 ? (size_t)80 * 1024 : lds);
+        if (e != hipSuccess) return e;
     }
     GsStepArgs args = a;
     int to_out = steps & 1;
@@ -1274,13 +1330,9 @@ hipError_t GS_SUFFIX(gs_launch_tile)(const GsStepArgs &a, int k, int shape, hipS
     size_t lds = tile_lds_bytes(rpw[shape]);
     static const int lds_floor = std::getenv("GS_HIP_TILE_LDS_FLOOR") ? std::atoi(std::getenv("GS_HIP_TILE_LDS_FLOOR")) : 0;
     if (lds < (size_t)lds_floor) lds = (size_t)lds_floor; // experiment: limit the workgroups per CU
-    if (lds > 64 * 1024) { // more than 64 KB of dynamic LDS needs the opt-in, per device function
-        static bool attr_set[3][2] = {{false, false}, {false, false}, {false, false}};
-        if (!attr_set[shape][fast ? 1 : 0]) {
-            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_set[shape][fast ? 1 : 0] = true;
-        }
+    { // more than 64 KB of dynamic LDS needs the opt-in, per device and device function
+        const hipError_t e = ensure_dyn_lds(fn, lds);
+        if (e != hipSuccess) return e;
     }
     GsStepArgs args = a;
     void *kargs[] = {&args, &k};

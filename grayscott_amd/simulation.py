@@ -173,6 +173,16 @@ class HipContext:
         capi.check(self._lib.gs_ctx_comm_info(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return int(a.value), int(b.value), int(c.value)
 
+    def stats(self) -> dict:
+        """``gs_ctx_stats``: passes / steps / launches / ghost_refreshes since the context was created and,
+        for the passes timed with ``set_pass_timing``, the halo-stream and interior-kernel times (ms)."""
+        st = capi.GsStats()
+        capi.check(self._lib.gs_ctx_stats(self.handle, ctypes.byref(st)))
+        return {name: getattr(st, name) for name, _ in capi.GsStats._fields_ if name != "reserved"}
+
+    def set_pass_timing(self, passes: int) -> None:
+        capi.check(self._lib.gs_ctx_set_pass_timing(self.handle, passes))
+
     def info(self) -> Tuple[str, int]:
         buf = ctypes.create_string_buffer(64)
         n = ctypes.c_uint64(0)

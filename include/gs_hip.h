@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 2
+#define GS_ABI_VERSION 3
 
 typedef enum gs_status {
     GS_OK = 0,
@@ -256,6 +256,27 @@ int32_t gs_ctx_set_tuned(gs_ctx *ctx, uint64_t slab_rows, uint64_t cols, int32_t
 /* What RCCL itself reports for this context's communicator (ncclCommCount / ncclCommUserRank /
  * ncclCommCuDevice): the number of ranks, this rank and its device; 0, -1, -1 for a single process. */
 int32_t gs_ctx_comm_info(const gs_ctx *ctx, int32_t *rccl_ranks, int32_t *rccl_rank, int32_t *rccl_device);
+
+/* Counters of a context since its creation, and -- on slab chains -- where the time of the passes timed
+ * with gs_ctx_set_pass_timing went.  Not part of the reference's interface: what bench.py and the tests
+ * read instead of inferring it from launch counts. */
+typedef struct gs_stats {
+    uint64_t passes;          /* passes over the planes enqueued (one pass advances 1..8 time steps)        */
+    uint64_t steps;           /* time steps enqueued                                                       */
+    uint64_t launches;        /* step-kernel launches (slab chains: boundary band + interior per slab)     */
+    uint64_t ghost_refreshes; /* blocking ghost-row refreshes (slab chains: after fill / upload, or when a  *
+                               * pass needs deeper ghost rows than the previous one left)                  */
+    uint64_t timed_passes;    /* passes covered by the three sums below (the slowest local slab's)         */
+    float halo_ms;            /* halo stream: boundary-band kernel + ghost-row exchange, summed             */
+    float interior_ms;        /* compute stream: interior kernel, summed                                   */
+    float halo_exposed_ms;    /* sum over passes of max(0, end of the halo stream's work - end of the      *
+                               * interior kernel): what the exchange did NOT hide behind the interior      */
+    float reserved;
+} gs_stats;
+int32_t gs_ctx_stats(gs_ctx *ctx, gs_stats *out);
+/* Time the next `passes` passes (0..4096; 0 = off) of every local slab of a slab chain with HIP events on
+ * the halo and compute streams; gs_ctx_stats waits for them and reports the sums.  Waits for enqueued work. */
+int32_t gs_ctx_set_pass_timing(gs_ctx *ctx, int32_t passes);
 
 /* Introspection for tests and the bench: name of the kernel variant last launched
  * ("tb-k4/strict@32x2" = 4 fused steps, strict math, tuned: 32-row units, 2 row bands) and the number of

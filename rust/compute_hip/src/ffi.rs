@@ -1,4 +1,4 @@
-//! `extern "C"` view of include/gs_hip.h (ABI version 2).  Field order and widths must match
+//! `extern "C"` view of include/gs_hip.h (ABI version 3).  Field order and widths must match
 //! the header exactly; `tests/test_capi_cpu.py::test_struct_layouts` pins the C side.
 #![allow(non_camel_case_types)]
 

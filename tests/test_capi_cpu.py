@@ -27,7 +27,7 @@ def test_header_symbols_all_exported(built):
     assert set(names) == set(capi.EXPORTS)
     for n in names:
         assert hasattr(lib, n), f"libgs_hip.so does not export {n}"
-    assert lib.gs_abi_version() == 2
+    assert lib.gs_abi_version() == 3
 
 
 def test_library_has_gfx950_code_object_and_no_oracle(built):
@@ -60,6 +60,25 @@ def test_struct_layouts(built):
 
     assert ctypes.sizeof(capi.GsParams) == 14 * 4
     assert ctypes.sizeof(capi.GsOptions) == 16 * 4
+    assert ctypes.sizeof(capi.GsStats) == 5 * 8 + 4 * 4      # gs_stats: 5 x uint64 + 4 x float
+
+
+def test_dynamic_lds_opt_in_is_keyed_by_device_and_function(built):
+    """The > 64 KB dynamic-LDS opt-in (hipFuncSetAttribute) belongs to a device function ON ONE DEVICE: the
+    launchers remember it per (device, function, bytes), so a second device -- or a larger request -- sets it
+    again, and a repeat does not (process-wide flags skipped it on the second GPU)."""
+    from grayscott_amd import capi
+
+    key = capi.load().gs_debug_dyn_lds_key
+    key.restype = ctypes.c_int32
+    key.argtypes = [ctypes.c_int32] * 3
+    assert key(0, 0, 70000) == 1      # first launch on device 0: the attribute is set
+    assert key(0, 0, 70000) == 0      # again: skipped
+    assert key(1, 0, 70000) == 1      # the same function on device 1: set there too
+    assert key(0, 1, 70000) == 1      # another function on device 0
+    assert key(0, 0, 80000) == 1      # a larger request on device 0
+    assert key(0, 0, 75000) == 0      # ... covers smaller ones
+    assert key(1, 0, 70000) == 0
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful without a GPU")
