@@ -117,17 +117,43 @@ def cpu_baseline(target_seconds: float = 12.0):
     return info
 
 
-def measured_counters(kernel_name: str):
-    """Per-launch PMC figures of the committed rocprofv3 profile of this kernel at 2^28 cells per GPU
-    (profiles/counters.json, written by tools/summarize_profile.py from separate --pmc passes):
-    {"traffic": HBM bytes, "valu_insts": SQ_INSTS_VALU wave-instructions, "source": ...}; {} if absent."""
+def measured_counters(kernel_name: str, rows: int, cols: int, tuned):
+    """Per-launch PMC figures of the committed rocprofv3 profile of this kernel on this grid
+    (profiles/counters.json, a list written by tools/summarize_profile.py from separate --pmc passes; every
+    entry names the layout it was measured with):
+    {"traffic": HBM bytes, "valu_insts": SQ_INSTS_VALU wave-instructions, "launch_ms": rocprofv3's average
+    launch duration, "rows_per_unit", "cols_per_lane", "steps_per_pass", "source"}; {} when no profile of
+    this kernel on this grid is committed."""
     path = os.path.join(ROOT, "profiles", "counters.json")
     try:
         with open(path) as f:
             data = json.load(f)
-        return data.get(kernel_name.split("@")[0]) or {}
     except (OSError, ValueError):
         return {}
+    label = kernel_name.split("@")[0]
+    best = {}
+    for e in data if isinstance(data, list) else []:
+        if e.get("kernel") == label and e.get("rows") == rows and e.get("cols") == cols:
+            if not best or e.get("rows_per_unit") == tuned[0]:
+                best = e
+    return best
+
+
+def scaled_valu_insts(pmc, tuned):
+    """SQ_INSTS_VALU of the committed profile, re-scaled when this run's tuner picked another unit height of
+    the same lane layout: a unit of h rows computes 4 h + 12 level-rows for 4 h stored ones (the 2K apron rows
+    of the level pipeline), everything else is the same instruction stream.  Returns (instructions, how)."""
+    insts = pmc.get("valu_insts")
+    if not insts:
+        return None, None
+    h0, h = pmc.get("rows_per_unit"), tuned[0]
+    if not h0 or not h or h0 == h:
+        return insts, "measured (profile of this layout)"
+    if pmc.get("cols_per_lane") != tuned[2] or pmc.get("steps_per_pass") != tuned[1]:
+        return None, f"profile is for {pmc.get('cols_per_lane')} col/lane, {pmc.get('steps_per_pass')} steps/pass"
+    k = tuned[1] or 4
+    return insts * ((k * h + k * (k - 1)) / (k * h)) / ((k * h0 + k * (k - 1)) / (k * h0)), \
+        f"scaled from the profile's {h0}-row units to this run's {h}-row units"
 
 
 def developed_species(sim, rows, cols, develop_steps=4000):
@@ -212,6 +238,8 @@ def main() -> int:
     ap.add_argument("--grid", default="", help="ROWSxCOLS: override the grid of the chosen scaling mode")
     ap.add_argument("--rows", type=int, default=0, help="override the grid (diagnostics only)")
     ap.add_argument("--cols", type=int, default=0)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps steps each, back to back; `value` is their median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the informational legs (fused flavour, developed pattern)")
@@ -271,79 +299,179 @@ def main() -> int:
     hip_args = HipArgs(devices=[local_rank], rank=rank, world=world, unique_id=unique_id)
     sim = Simulation.new(Parameters(), hip_args)
     ctx = sim.context
+    cells = rows * cols
+    cells_per_gpu = cells / args.gpus
+    single = args.gpus == 1
+    with_extra = single and not args.no_extra
+
+    # Everything the timed regions touch exists BEFORE the first of them: the timed Species (Species::new on
+    # the device, HBM-resident) and, for the co-headline, the developed pattern.  Nothing is allocated, freed
+    # or filled between tuning and timing -- round 2's line read 8 % low because 4 GiB of planes were created
+    # in that gap and the first launches after it ran on an idle chip's clocks.
+    species = sim.make_species([rows, cols])
+    sp_dev = developed_species(sim, rows, cols) if with_extra else None     # 4000 steps: also tunes the context
     tuned = (0, 0, 0)
     if world == 1:
-        # gs_run chooses unit height / fused steps / columns per lane on line, from timed passes of
-        # the simulation itself (per context and shape).  Let it finish on a scratch set of planes,
-        # so that neither the W warm-up steps nor the K timed ones contain tuning passes whatever
-        # W and K are.
-        scratch = sim.make_species([rows, cols])
+        # gs_run chooses unit height / fused steps / columns per lane on line, from timed passes of the
+        # simulation itself (per context and shape).  It finishes here, on passes of the timed Species, so
+        # that neither the W warm-up steps nor the K timed ones contain tuning passes whatever W and K are.
         for _ in range(8):
-            sim.perform_steps(scratch, 400)
             tuned = ctx.get_tuned(rows, cols)
             if tuned[0] > 0:
                 break
-        del scratch
+            sim.perform_steps(species, 400)
     else:
         # A slab chain does not tune on line: rank 0 tunes on a throw-away single slab of the slab's
         # shape and every rank is handed the same configuration (grayscott_amd/dist.py).
         tuned = gsd.share_tuning(sim, rows // world, cols, rank, world, device=red_dev, local_device=local_rank)
-    species = sim.make_species([rows, cols])        # Species::new on the device, HBM-resident
 
     def barrier():
         if world > 1:
             dist.barrier()
 
     def timed_run(sp, steps):
-        """(wall seconds, HIP-event ms, kernel launches) of `steps` steps bracketed as the contract says."""
+        """(wall seconds, HIP-event ms, passes) of `steps` steps bracketed as the contract says."""
         ctx.sync()
         barrier()
         torch.cuda.synchronize()
-        _, n0 = ctx.info()
+        p0 = ctx.stats()["passes"]
         t0 = time.perf_counter()
         ctx.timer_start()                               # HIP events on the library's own stream
         sim.prepare_steps(sp, steps)
         ms = ctx.timer_stop()
-        _, n1 = ctx.info()
         ctx.sync()
         torch.cuda.synchronize()
         barrier()
-        return time.perf_counter() - t0, ms, n1 - n0
+        return time.perf_counter() - t0, ms, ctx.stats()["passes"] - p0
 
+    def repeated(sp, steps, repeats):
+        """`repeats` timed regions of `steps` steps each, back to back; per region the maximum over ranks."""
+        runs = []
+        for _ in range(repeats):
+            wall, ms, passes = timed_run(sp, steps)
+            if world > 1:
+                t = torch.tensor([wall, ms], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                wall, ms = float(t[0]), float(t[1])
+            runs.append((wall, ms, passes))
+        return runs
+
+    def median_run(runs):
+        return sorted(runs, key=lambda r: r[0])[len(runs) // 2]
+
+    def warm(sp):
+        """At least 50 ms of untimed steps right before a warm-up, no host gap: the timed launches meet the
+        clocks and caches of a running simulation, which is what the number claims to describe."""
+        rate = 4.0e11 if cells_per_gpu >= (1 << 24) else 1.0e11        # cell-steps per second, a low guess
+        sim.perform_steps(sp, max(16, int(0.05 * rate / cells_per_gpu)))
+
+    warm(species)
     sim.perform_steps(species, args.warmup)
-    wall, event_ms, launches = timed_run(species, args.steps)
+    runs = repeated(species, args.steps, args.repeats)
+    wall, event_ms, passes = median_run(runs)
+    walls = [r[0] for r in runs]
 
+    per_rank, comm = [], []
     if world > 1:
-        t = torch.tensor([wall, event_ms], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, event_ms = float(t[0]), float(t[1])
-        # what RCCL itself says about the communicator, and where every rank runs
-        mine = torch.tensor(list(ctx.comm_info()) + [local_rank], dtype=torch.int32, device=red_dev)
+        # Per rank: its own launch time, and -- in an untimed repeat with HIP events on the halo and compute
+        # streams (gs_ctx_set_pass_timing) -- whether the boundary band + ghost-row exchange hid behind the
+        # interior kernel.  Then what RCCL itself says about the communicator, and where every rank runs.
+        _, my_ms, my_passes = median_run([timed_run(species, args.steps) for _ in range(3)])
+        n_timed = min(64, max(1, my_passes))
+        ctx.set_pass_timing(n_timed)
+        timed_run(species, args.steps)
+        st = ctx.stats()
+        ctx.set_pass_timing(0)
+        tp = max(1, st["timed_passes"])
+        mine = torch.tensor([my_ms / max(1, my_passes), st["halo_ms"] / tp, st["interior_ms"] / tp,
+                             st["halo_exposed_ms"] / tp, float(st["timed_passes"])] +
+                            [float(x) for x in ctx.comm_info()] + [float(local_rank)],
+                            dtype=torch.float64, device=red_dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        comm = [[int(x) for x in r.cpu()] for r in allr]
-    else:
-        comm = []
+        for r in allr:
+            x = [float(v) for v in r.cpu()]
+            per_rank.append({"launch_ms": x[0], "halo_stream_ms_per_pass": x[1], "interior_ms_per_pass": x[2],
+                             "halo_exposed_ms_per_pass": x[3], "timed_passes": int(x[4]),
+                             "rccl_rank": int(x[6]), "rccl_device": int(x[7]), "local_rank": int(x[8])})
+            comm.append(int(x[5]))
 
     kernel_name, _ = ctx.info()
-    cells = rows * cols
     value = cells * args.steps / wall / 1e6
-    # The dominant kernel: one launch of the step kernel per pass over one GPU's slab (plus, on a slab
-    # chain, the small boundary-band launch); a pass advances `steps / passes` time steps (temporal
-    # blocking).
-    passes = launches if args.gpus == 1 else launches // 2
+    steps_per_launch = args.steps / passes
+    pmc = measured_counters(kernel_name, int(rows // args.gpus), cols, tuned)
+    valu_insts, valu_how = scaled_valu_insts(pmc, tuned)
+
+    def roofline_of(event_ms, passes):
+        """The roofline object of one timed region (its own launch time; the committed profile's counters)."""
+        launch_s = event_ms * 1e-3 / passes
+        algo_bytes = BYTES_PER_CELL_STEP * cells_per_gpu * steps_per_launch
+        algo_gbs = algo_bytes / launch_s / 1e9
+        traffic = pmc.get("traffic")
+        hbm_physical = traffic / launch_s / 1e9 / HBM_PEAK_GBS if traffic else None
+        valu_rate = valu_insts * 64 / launch_s / 1e12 if valu_insts else None
+        useful_rate = USEFUL_VALU_PER_CELL_STEP * cells_per_gpu * steps_per_launch / launch_s / 1e12
+        # Which roof binds: with K >= 3 steps fused per HBM pass the kernel moves ~16 B per cell for K
+        # steps and is bound by VALU issue; a single-step pass is bound by HBM.
+        valu_bound = steps_per_launch >= 3
+        if valu_bound:
+            # issued VALU lane-instructions (PMC SQ_INSTS_VALU x 64, committed profile of this layout) per
+            # launch time against the chip's plain-f32 issue rate; without a matching profile, the useful
+            # instructions alone (computed from this run: a lower bound of what was issued)
+            achieved = valu_rate if valu_rate else useful_rate
+            frac = achieved / VALU_PEAK_TLANEOPS
+        else:
+            achieved = traffic / launch_s / 1e9 if traffic else algo_gbs
+            frac = hbm_physical if hbm_physical else algo_gbs / HBM_PEAK_GBS
+        return {
+            "bound": "valu-issue" if valu_bound else "hbm",
+            "achieved": achieved,
+            "peak": VALU_PEAK_TLANEOPS if valu_bound else HBM_PEAK_GBS,
+            "unit": "T lane-ops/s" if valu_bound else "GB/s",
+            "frac": frac,
+            "frac_source": (valu_how if valu_rate else "useful instructions only (no profile of this layout committed)")
+                           if valu_bound else ("PMC traffic" if traffic else "algorithmic bytes"),
+            "valu": valu_rate / VALU_PEAK_TLANEOPS if valu_rate else None,
+            "useful_valu": useful_rate / VALU_PEAK_TLANEOPS,
+            "hbm_physical": hbm_physical,
+            # SURVEY section 8(d)'s algorithmic figure (16 B per cell-step): a throughput in GB/s-equivalents,
+            # NOT a fraction of the HBM roof once K steps share one HBM pass (it exceeds the peak by design)
+            "algorithmic_GBps": algo_gbs,
+            "algorithmic_frac": algo_gbs / HBM_PEAK_GBS,
+            "algorithmic_frac_of_copy_ceiling": algo_gbs / HBM_COPY_CEILING_GBS,
+            "launch_ms": launch_s * 1e3,
+            # rocprofv3's average duration of the same kernel in the committed profile (profiling lowers clocks)
+            "profile_launch_ms": pmc.get("launch_ms"),
+            "launches": passes,
+            "steps_per_launch": steps_per_launch,
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "traffic": traffic,                      # HBM bytes per launch, PMC (null: not profiled)
+            "valu_insts_per_launch": valu_insts,     # SQ_INSTS_VALU per launch, PMC (null: not profiled)
+            "counters_source": pmc.get("source"),
+            "counters_layout": ({"rows_per_unit": pmc.get("rows_per_unit"), "steps_per_pass": pmc.get("steps_per_pass"),
+                                 "cols_per_lane": pmc.get("cols_per_lane")} if pmc else None),
+        }
+
+    roofline = roofline_of(event_ms, passes)
     extra, developed, clocks = None, None, None
-    if args.gpus == 1 and not args.no_extra:
+    if with_extra:
+        # co-headline: the same kernel, same context, same launches on a developed spot pattern (the chip
+        # sustains a lower clock on non-trivial operands; BASELINE.md asks for "random/real data not zeros")
+        warm(sp_dev)
+        sim.perform_steps(sp_dev, args.warmup)
+        runs_dev = repeated(sp_dev, args.steps, args.repeats)
+        w_dev, ms_dev, p_dev = median_run(runs_dev)
+        developed = {"value": cells * args.steps / w_dev / 1e6,
+                     "value_min": cells * args.steps / max(r[0] for r in runs_dev) / 1e6,
+                     "value_max": cells * args.steps / min(r[0] for r in runs_dev) / 1e6,
+                     "repeats": len(runs_dev),
+                     "roofline": {k: v for k, v in roofline_of(ms_dev, p_dev).items()
+                                  if k in ("bound", "achieved", "peak", "unit", "frac", "frac_source", "valu", "useful_valu",
+                                           "hbm_physical", "algorithmic_GBps", "launch_ms")}}
         # informational: shader clock and socket power while the same kernel runs (rocm-smi samples next to
         # an untimed repeat of the timed run; the VALU roof is priced at the nominal 2.4 GHz, the chip
         # sustains less on its power limit)
         clocks = sample_clock_and_power(lambda: timed_run(species, max(args.steps, 8000)), local_rank)
-        # informational: the same kernel, same context, on a developed spot pattern (the chip sustains
-        # a lower clock on non-trivial operands; BASELINE.md asks for "random/real data not zeros")
-        sp_dev = developed_species(sim, rows, cols)
-        w_dev, _, _ = timed_run(sp_dev, args.steps)
-        developed = cells * args.steps / w_dev / 1e6
-        del sp_dev
         # informational: the fused-tap flavour (GS_MATH_FUSED: bit-identical wherever no sub-normal
         # intermediate occurs, |diff| <= 1e-37 elsewhere -- inside north_star's 1e-5 tolerance)
         sim_c = Simulation.new(Parameters(), HipArgs(devices=[local_rank], math=capi.GS_MATH_FUSED))
@@ -355,49 +483,11 @@ def main() -> int:
         extra = {"kernel": sim_c.context.info()[0], "value": rows * cols * args.steps / tc / 1e6}
         sim_c.context.close()
         del species_c, sim_c
-    launch_s = event_ms * 1e-3 / passes
-    steps_per_launch = args.steps / passes
-    cells_per_gpu = cells / args.gpus
-    algo_bytes = BYTES_PER_CELL_STEP * cells_per_gpu * steps_per_launch
-    algo_gbs = algo_bytes / launch_s / 1e9
-    pmc = measured_counters(kernel_name) if cells // args.gpus == 16384 * 16384 else {}
-    traffic, valu_insts = pmc.get("traffic"), pmc.get("valu_insts")
-    hbm_physical = traffic / launch_s / 1e9 / HBM_PEAK_GBS if traffic else None
-    valu_rate = valu_insts * 64 / launch_s / 1e12 if valu_insts else None
-    useful_rate = USEFUL_VALU_PER_CELL_STEP * cells_per_gpu * steps_per_launch / launch_s / 1e12
-    # Which roof binds: with K >= 3 steps fused per HBM pass the kernel moves ~16 B per cell for K
-    # steps and is bound by VALU issue; a single-step pass is bound by HBM.
-    valu_bound = steps_per_launch >= 3
-    roofline = {
-        "bound": "valu-issue" if valu_bound else "hbm",
-        # the binding roof: issued VALU lane-instructions (PMC SQ_INSTS_VALU x 64, committed profile)
-        # per launch time against the chip's plain-f32 issue rate; HBM bytes (PMC) against 8 TB/s
-        "achieved": (valu_rate if valu_bound else (traffic / launch_s / 1e9 if traffic else algo_gbs)),
-        "peak": VALU_PEAK_TLANEOPS if valu_bound else HBM_PEAK_GBS,
-        "unit": "T lane-ops/s" if valu_bound else "GB/s",
-        "frac": ((valu_rate / VALU_PEAK_TLANEOPS if valu_rate else None) if valu_bound
-                 else (hbm_physical if hbm_physical else algo_gbs / HBM_PEAK_GBS)),
-        "valu": valu_rate / VALU_PEAK_TLANEOPS if valu_rate else None,
-        "useful_valu": useful_rate / VALU_PEAK_TLANEOPS,
-        "hbm_physical": hbm_physical,
-        # SURVEY section 8(d)'s algorithmic figure (16 B per cell-step): a throughput in GB/s-equivalents,
-        # NOT a fraction of the HBM roof once K steps share one HBM pass (it exceeds the peak by design)
-        "algorithmic_GBps": algo_gbs,
-        "algorithmic_frac": algo_gbs / HBM_PEAK_GBS,
-        "algorithmic_frac_of_copy_ceiling": algo_gbs / HBM_COPY_CEILING_GBS,
-        "launch_ms": launch_s * 1e3,
-        "launches": passes,
-        "steps_per_launch": steps_per_launch,
-        "algorithmic_bytes_per_launch": algo_bytes,
-        "traffic": traffic,                      # HBM bytes per launch, PMC (null: not profiled)
-        "valu_insts_per_launch": valu_insts,     # SQ_INSTS_VALU per launch, PMC (null: not profiled)
-        "counters_source": pmc.get("source"),
-    }
     result = {
         # BASELINE.json's metric, verbatim; `value` is its first quantity, the `roofline` object
         # carries the second
         "metric": "Mcells×steps/s and achieved HBM GB/s (% of roofline), 16384² f32 grid",
-        "value": value,
+        "value": value,                                   # the median of `repeats` timed regions
         "unit": "Mcells×steps/s",
         "n_gpus": args.gpus,
         "steps": args.steps,
@@ -408,31 +498,36 @@ def main() -> int:
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic" if not args.rehearsal else "synthetic (REHEARSAL: ranks share one GPU, not a measurement)",
+        "repeats": len(runs),
+        "value_min": cells * args.steps / max(walls) / 1e6,
+        "value_max": cells * args.steps / min(walls) / 1e6,
         "config": {
             "workload": f"{rows}x{cols} f32 (rows x cols), Species::new init, default feed/kill, "
                         f"double-buffered U/V in HBM",
+            "grid": [rows, cols],
             "cells_per_gpu": cells // args.gpus,
             "kernel": kernel_name,
             "tuned": {"rows_per_unit": tuned[0], "steps_per_pass": tuned[1], "cols_per_lane": tuned[2]},
-            "launches_per_pass": 1 if args.gpus == 1 else 2,
-            "partition": "single GPU" if args.gpus == 1 else
+            "launches_per_pass": 1 if single else 2,
+            "partition": "single GPU" if single else
                          f"{args.gpus} row slabs, RCCL send/recv ghost rows",
         },
         "roofline": roofline,
     }
-    if comm:
-        result["rccl_ranks"] = comm[0][0]
-        result["ranks"] = [{"rccl_rank": c[1], "rccl_device": c[2], "local_rank": c[3]} for c in comm]
+    if per_rank:
+        result["rccl_ranks"] = comm[0]
+        result["ranks"] = per_rank
     if clocks:
         roofline["sclk_MHz_under_load"] = clocks["sclk_MHz"]
         roofline["socket_power_W_under_load"] = clocks["power_W"]
-        if valu_rate and valu_bound:
-            roofline["valu_at_sustained_clock"] = valu_rate / (VALU_PEAK_TLANEOPS * clocks["sclk_MHz"] / NOMINAL_SCLK_MHZ)
+        if roofline["valu"] and roofline["bound"] == "valu-issue":
+            roofline["valu_at_sustained_clock"] = roofline["valu"] / (clocks["sclk_MHz"] / NOMINAL_SCLK_MHZ)
     if developed is not None:
-        result["value_developed_pattern"] = developed
+        result["value_developed_pattern"] = developed["value"]
+        result["developed_pattern"] = developed
     if extra is not None:
         result["fused_flavour"] = extra
-    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and single and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(result, ensure_ascii=False))

@@ -37,7 +37,7 @@ EXPORTS = (
     "gs_step", "gs_run", "gs_sync", "gs_timer_start", "gs_timer_stop", "gs_ctx_info",
     "gs_host_alloc", "gs_host_free", "gs_field_download_async", "gs_download_wait",
     "gs_ctx_get_tuned", "gs_ctx_set_tuned", "gs_ctx_comm_info", "gs_field_colormap",
-    "gs_ctx_stats", "gs_ctx_set_pass_timing",
+    "gs_ctx_stats", "gs_ctx_set_pass_timing", "gs_field_mark_written",
 )
 
 
@@ -149,6 +149,7 @@ def load() -> ctypes.CDLL:
         "gs_field_colormap": (i32, [vp, vp, f32, vp, i32, vp]),
         "gs_ctx_stats": (i32, [vp, P(GsStats)]),
         "gs_ctx_set_pass_timing": (i32, [vp, i32]),
+        "gs_field_mark_written": (i32, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -713,6 +713,10 @@ int32_t step_impl(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, 
         if (in_v->ghost_depth < fuse) GS_TRY(refresh_ghosts(ctx, in_v));
         const int p = (int)(ctx->step_no & 1), q = p ^ 1;
         gs_field *outs[2] = {out_u, out_v};
+        // Rows per boundary band and per exchange: as deep as the ghost rows go (4, or the smallest slab),
+        // whatever this pass fuses -- so the planes it leaves behind serve a pass of any depth, and a short
+        // pass (a remainder, a single gs_step) is never followed by a blocking refresh.
+        const int depth = min_slab_rows(ctx, in_u) < kGhostRows ? min_slab_rows(ctx, in_u) : kGhostRows;
         for (int i = 0; i < n_local; ++i) {
             SlabRt &sl = ctx->slabs[i];
             GS_HIP(hipSetDevice(sl.device));
@@ -732,20 +736,20 @@ int32_t step_impl(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, 
             if (timed) GS_HIP(hipEventRecord(sl.th0[sl.timed], sl.halo));
             GsStepArgs b = a;
             b.ra0 = 0;
-            b.ra1 = n <= 2 * fuse ? n : fuse;
-            b.rb0 = n <= 2 * fuse ? 0 : n - fuse;
-            b.rb1 = n <= 2 * fuse ? 0 : n;
-            b.rows_per_unit = fuse; // one unit per boundary band and strip
+            b.ra1 = n <= 2 * depth ? n : depth;
+            b.rb0 = n <= 2 * depth ? 0 : n - depth;
+            b.rb1 = n <= 2 * depth ? 0 : n;
+            b.rows_per_unit = depth; // one unit per boundary band and strip
             GS_TRY(launch_rows(ctx, b, sl.halo, fuse));
-            GS_TRY(push_halo(ctx, outs, 2, i, sl.halo, fuse));
+            GS_TRY(push_halo(ctx, outs, 2, i, sl.halo, depth));
             GS_HIP(hipEventRecord(sl.halod[p], sl.halo));
             if (timed) GS_HIP(hipEventRecord(sl.th1[sl.timed], sl.halo));
             // compute stream: interior rows
             GS_HIP(hipStreamWaitEvent(sl.compute, sl.halod[q], 0));
             if (timed) GS_HIP(hipEventRecord(sl.tc0[sl.timed], sl.compute));
-            if (n > 2 * fuse) {
-                a.ra0 = fuse;
-                a.ra1 = n - fuse;
+            if (n > 2 * depth) {
+                a.ra0 = depth;
+                a.ra1 = n - depth;
                 GS_TRY(launch_rows(ctx, a, sl.compute, fuse));
             }
             GS_HIP(hipEventRecord(sl.done[p], sl.compute));
@@ -758,8 +762,9 @@ int32_t step_impl(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, 
     ctx->step_no++;
     ctx->passes++;
     ctx->steps_done += (uint64_t)fuse;
-    out_u->ghost_depth = fuse;
-    out_v->ghost_depth = fuse;
+    // (a chain exchanged min(4, smallest slab) rows; fuse never exceeds that)
+    out_u->ghost_depth = S > 1 ? kGhostRows : fuse;
+    out_v->ghost_depth = S > 1 ? kGhostRows : fuse;
     return GS_OK;
 }
 
@@ -1256,8 +1261,14 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
     if (world < 1 || rank < 0 || rank >= world) return fail(GS_ERR_INVALID, "bad rank %d / world %d", rank, world);
     if (n_local < 0 || (n_local > 0 && !device_ids)) return fail(GS_ERR_INVALID, "bad device list");
     if (world > 1 && !unique_id) return fail(GS_ERR_INVALID, "world > 1 needs the RCCL unique id of rank 0");
-    if (world > 1 && n_local > 1)
-        return fail(GS_ERR_UNSUPPORTED, "multi-process contexts drive one slab (one GPU) per process");
+    // One slab per process is the deployment (one process per GPU).  A process of a chain may also hold
+    // several consecutive slabs as long as they live on ONE device -- the communicator is bound to it -- which
+    // is how an 8-slab chain is rehearsed on boxes that admit fewer processes than slabs.
+    if (world > 1)
+        for (int i = 1; i < n_local; ++i)
+            if (device_ids[i] != device_ids[0])
+                return fail(GS_ERR_UNSUPPORTED, "a process of a multi-process chain drives slabs of one device "
+                                                "(one process per GPU); got devices %d and %d", device_ids[0], device_ids[i]);
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1527,6 +1538,13 @@ int32_t gs_field_device_ptr(const gs_field *f, int32_t slab, void **ptr, uint64_
     if (slab_row0) *slab_row0 = f->s[slab].g_row0;
     if (slab_rows) *slab_rows = (uint64_t)f->s[slab].rows;
     if (device) *device = f->ctx->slabs[slab].device;
+    return GS_OK;
+}
+
+int32_t gs_field_mark_written(gs_ctx *ctx, gs_field *f)
+{
+    if (!ctx || !f || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad handle");
+    f->ghost_depth = 0; // as after gs_field_upload: the next step (or gs_field_finalize) refreshes the ghost rows
     return GS_OK;
 }
 

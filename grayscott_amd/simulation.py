@@ -278,6 +278,26 @@ class HipConcentration:
         capi.check(context._lib.gs_field_upload(context.handle, self.handle,
                                                 host.ctypes.data_as(ctypes.c_void_p)))
 
+    def device_slabs(self):
+        """``gs_field_device_ptr`` for every local slab: ``(address, pitch in f32, global row0, rows, device)``
+        tuples, top to bottom -- for zero-copy consumers / producers (a producer calls ``mark_written``)."""
+        out = []
+        lib = self._ctx._lib
+        i = 0
+        while True:
+            ptr, pitch, r0, rows = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+            dev = ctypes.c_int32()
+            if lib.gs_field_device_ptr(self.handle, i, ctypes.byref(ptr), ctypes.byref(pitch), ctypes.byref(r0),
+                                       ctypes.byref(rows), ctypes.byref(dev)) != capi.GS_OK:
+                break
+            out.append((int(ptr.value or 0), int(pitch.value), int(r0.value), int(rows.value), int(dev.value)))
+            i += 1
+        return out
+
+    def mark_written(self, context: HipContext) -> None:
+        """``gs_field_mark_written``: cells were written through ``device_slabs`` addresses."""
+        capi.check(context._lib.gs_field_mark_written(context.handle, self.handle))
+
     def make_scalar_view(self, context: HipContext) -> np.ndarray:
         """Owned dense copy of this process's rows (mod.rs:261-275)."""
         r0, r1 = self.local_rows()

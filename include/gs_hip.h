@@ -193,6 +193,12 @@ int32_t gs_field_download(gs_ctx *ctx, gs_field *f, float *host);
 int32_t gs_field_device_ptr(const gs_field *f, int32_t slab, void **ptr, uint64_t *pitch,
                             uint64_t *slab_row0, uint64_t *slab_rows, int32_t *device);
 
+/* Tell the library that the caller has written cells of `f` through gs_field_device_ptr (a zero-copy
+ * producer): the copies of its boundary rows in the neighbouring slabs' ghost rows are stale, exactly as
+ * after gs_field_upload.  The caller orders its writes before the next library call itself (the library's
+ * streams do not know about them). */
+int32_t gs_field_mark_written(gs_ctx *ctx, gs_field *f);
+
 /* One time step: reads (in_u, in_v), writes (out_u, out_v).  Asynchronous.  The caller
  * flips its handles afterwards, as Species::flip does (concentration/mod.rs:88-92). */
 int32_t gs_step(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs_field *out_v);

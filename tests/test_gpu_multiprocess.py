@@ -30,7 +30,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, rows, cols, steps, out_dir, transport_lib, seed):
+def _worker(rank, world, port, rows, cols, steps, out_dir, transport_lib, seed, local_slabs=1):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
@@ -46,14 +46,16 @@ def _worker(rank, world, port, rows, cols, steps, out_dir, transport_lib, seed):
     ndev = capi.device_count()
     device = rank if ndev >= world else 0
     try:
-        sim = Simulation.new(Parameters(), HipArgs(devices=[device], rank=info.rank, world=info.world,
+        sim = Simulation.new(Parameters(), HipArgs(devices=[device] * local_slabs, rank=info.rank, world=info.world,
                                                    unique_id=info.unique_id))
     except GsError as e:
         if transport_lib:
             raise                      # the double has no reason to refuse
         open(os.path.join(out_dir, f"skip{rank}"), "w").write(str(e))
         return
-    r0, r1 = gsd.slab_range(rows, world, rank)
+    r0, r1 = gsd.slab_range(rows, world, rank) if local_slabs == 1 else \
+        (gsd.slab_range(rows, world * local_slabs, rank * local_slabs)[0],
+         gsd.slab_range(rows, world * local_slabs, (rank + 1) * local_slabs - 1)[1])
     if seed is None:
         species = sim.make_species([rows, cols])
     else:                              # stress fields: every slab boundary carries signal from step 1
@@ -106,10 +108,21 @@ def test_shm_ranks_match_oracle(tmp_path, built, shm_transport, world, rows, col
     _ranks_match_oracle(tmp_path, world, rows, cols, steps, shm_transport, seed)
 
 
-def _ranks_match_oracle(tmp_path, world, rows, cols, steps, transport_lib, seed):
+@pytest.mark.parametrize("world,local_slabs,rows,cols,steps,seed", [
+    (2, 2, 96, 300, 22, 0),      # 4 slabs as 2 processes x 2: copies inside a process, send / recv between them
+    (3, 2, 1030, 777, 41, 1),    # 6 uneven slabs (171 / 172 rows)
+    (2, 3, 13, 50, 9, 2),        # 2- and 3-row slabs: passes fuse 2 steps
+])
+def test_shm_ranks_with_several_local_slabs(tmp_path, built, shm_transport, world, local_slabs, rows, cols, steps, seed):
+    """A process of a multi-process chain may hold several consecutive slabs of one device (how an 8-slab
+    chain is rehearsed on a box that admits 6 GPU processes: tests/test_gpu_baseline_configs.py)."""
+    _ranks_match_oracle(tmp_path, world, rows, cols, steps, shm_transport, seed, local_slabs)
+
+
+def _ranks_match_oracle(tmp_path, world, rows, cols, steps, transport_lib, seed, local_slabs=1):
     import oracle
 
-    mp.spawn(_worker, args=(world, _free_port(), rows, cols, steps, str(tmp_path), transport_lib, seed),
+    mp.spawn(_worker, args=(world, _free_port(), rows, cols, steps, str(tmp_path), transport_lib, seed, local_slabs),
              nprocs=world, join=True)
     skips = [p for p in os.listdir(tmp_path) if p.startswith("skip")]
     if skips:

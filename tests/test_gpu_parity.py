@@ -835,6 +835,81 @@ def test_row_slabs_species_new_and_stepwise():
         sim.make_species([3, 16])  # fewer rows than slabs
 
 
+def test_slab_chain_never_refreshes_between_runs():
+    """with a handed-in configuration of 3 steps per pass the leading short pass used to be
+    sized with steps % 4, the run ended on a remainder and EVERY following gs_run started with a blocking,
+    collective ghost refresh.  Now the short pass is sized with the steps per pass in force and every pass
+    exchanges ghost-depth rows: the only refreshes are the two after the upload."""
+    shape = (240, 500)
+    u0, v0 = stress_fields(shape, 5)
+    sim = Simulation.new(Parameters(), args(devices=[0, 0, 0], no_tune=1))
+    sim.context.set_tuned(shape[0] // 3, shape[1], 16, 3, 2)
+    sp = species_from_arrays(sim, u0, v0)
+    base = sim.context.stats()
+    total = 0
+    for n in (10, 7, 9, 1, 12, 5):        # remainders of every kind, a single step in between
+        sim.perform_steps(sp, n)
+        total += n
+    sim.perform_step(sp)
+    sim.perform_steps(sp, 8)
+    total += 9
+    st = sim.context.stats()
+    assert st["ghost_refreshes"] - base["ghost_refreshes"] == 2, (base, st)
+    assert st["steps"] - base["steps"] == total
+    assert sim.context.info()[0].startswith("tb-k3c2/")
+    ref_u, ref_v = oracle.run(u0, v0, total, ftz=True)
+    iu, iv, _, _ = sp.in_out()
+    assert_bits_equal(iu.make_scalar_view(sim.context), ref_u, "U")
+    assert_bits_equal(iv.make_scalar_view(sim.context), ref_v, "V")
+    sim.context.close()
+
+
+def test_pass_timing_reports_halo_and_interior_times():
+    """gs_ctx_set_pass_timing / gs_ctx_stats on a slab chain: what bench.py prints per rank for N > 1."""
+    sim = Simulation.new(Parameters(), args(devices=[0, 0]))
+    sp = sim.make_species([4096, 2048])
+    sim.perform_steps(sp, 40)
+    sim.context.set_pass_timing(6)
+    sim.perform_steps(sp, 40)          # 10 passes, the first 6 timed
+    st = sim.context.stats()
+    assert st["timed_passes"] == 6 and st["interior_ms"] > 0.0 and st["halo_ms"] > 0.0, st
+    assert st["halo_exposed_ms"] >= 0.0 and st["halo_exposed_ms"] < st["interior_ms"] + st["halo_ms"] + 1.0
+    sim.context.set_pass_timing(0)
+    sim.perform_steps(sp, 8)
+    assert sim.context.stats()["timed_passes"] == 0
+    u0, v0 = oracle.init_species(4096, 2048)
+    # the timed passes are ordinary passes: the state is the oracle's (crop around the seed and the seam)
+    ref_u, ref_v = oracle.run(u0[1500:2300], v0[1500:2300], 88, ftz=True)
+    iu, iv, _, _ = sp.in_out()
+    got_u, got_v = iu.make_scalar_view(sim.context), iv.make_scalar_view(sim.context)
+    assert_bits_equal(got_u[1500 + 88:2300 - 88], ref_u[88:-88], "U around the seam")
+    assert_bits_equal(got_v[1500 + 88:2300 - 88], ref_v[88:-88], "V around the seam")
+    sim.context.close()
+
+
+def test_two_contexts_launch_the_large_lds_kernels():
+    """The kernels that need more than 64 KB of dynamic LDS (64 x 64 windows: what AUTO picks for 600 x 900;
+    the resident kernel on a 1 x 1536 grid) from two contexts and two slab-chain entries of one process: the
+    opt-in is remembered per (device, function) -- tests/test_capi_cpu.py pins the key -- and a second
+    context (on this 1-GPU box: the same device) still launches."""
+    for shape, steps in (((600, 900), 24), ((1, 1536), 9)):
+        u0, v0 = stress_fields(shape, 9)
+        ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True)
+        sims = [Simulation.new(Parameters(), args()) for _ in range(2)]
+        if capi.device_count() >= 2:
+            sims.append(Simulation.new(Parameters(), args(devices=[1])))
+        for k, sim in enumerate(sims):
+            sp = species_from_arrays(sim, u0, v0)
+            sim.perform_steps(sp, steps)
+            label = sim.context.info()[0]
+            assert label.startswith("tile64x64/") or label.startswith("resident-lds/"), label
+            iu, iv, _, _ = sp.in_out()
+            assert_bits_equal(iu.make_scalar_view(sim.context), ref_u, f"U context {k} {shape}")
+            assert_bits_equal(iv.make_scalar_view(sim.context), ref_v, f"V context {k} {shape}")
+        for sim in sims:
+            sim.context.close()
+
+
 # ---- large grids: size-independent properties + GPU-vs-GPU equivalence chain ----------------
 def test_large_grid_properties_4096():
     """4096 x 4096 (BASELINE config 2): (a) stream kernel == simple kernel bit for bit,

@@ -4,8 +4,9 @@ summaries committed under profiles/:
 
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
   profiles/<tag>_summary.md         per-kernel time + HBM traffic per launch of the step kernel
-  profiles/counters.json            {"<bench kernel label>": {"traffic": HBM bytes per launch, "valu_insts":
-                                    SQ_INSTS_VALU per launch, "source": ...}, ...} read by bench.py
+  profiles/counters.json            [{"kernel": bench label, "rows", "cols", "rows_per_unit", "steps_per_pass",
+                                    "cols_per_lane", "traffic": HBM bytes per launch, "valu_insts": SQ_INSTS_VALU per
+                                    launch, "launch_ms": rocprofv3 average, "source"}, ...] read by bench.py
 
 HBM bytes per launch follow MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE come from
 separate --pmc passes, both are in KiB, and on gfx950 FETCH_SIZE reports exactly half of the
@@ -33,7 +34,11 @@ def counter_values(path, needle, counter):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    label = sys.argv[3] if len(sys.argv) > 3 else "default"
+    # the layout the profiled launches were pinned to (written by tools/profile_gpu.sh)
+    try:
+        layout = json.load(open(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "layout.json")))
+    except (OSError, ValueError):
+        layout = {}
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     bench0 = json.loads(open(os.path.join(src, "bench_stats.json")).read().strip().splitlines()[-1])
     auto = "gs_step_tb_k" if bench0["config"]["kernel"].startswith("tb-") else "gs_step_stream_k"
@@ -120,14 +125,27 @@ def main():
                         lines.append(f"| {k} / SQ_WAVE_CYCLES | {100*med[k]/med['SQ_WAVE_CYCLES']:.0f} % | {what} |")
             lines.append("")
     open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))
+    # profiles/counters.json: a list, one entry per (kernel label, grid, layout) profiled
     cpath = os.path.join(dst, "counters.json")
     try:
         counters = json.load(open(cpath))
+        if not isinstance(counters, list):
+            counters = []
     except (OSError, ValueError):
-        counters = {}
-    counters[bench["config"]["kernel"].split("@")[0]] = entry
-    if label != "default":
-        counters[label] = entry
+        counters = []
+    cfg = bench["config"]
+    grid = cfg.get("grid") or [int(x) for x in cfg["workload"].split()[0].split("x")]
+    tuned = cfg.get("tuned") or {}
+    pinned = layout.get("rows_per_unit") or tuned.get("rows_per_unit", 0)
+    entry.update({"kernel": cfg["kernel"].split("@")[0], "rows": int(grid[0]) // int(bench.get("n_gpus", 1)), "cols": int(grid[1]),
+                  "rows_per_unit": pinned, "steps_per_pass": int(round(bench["roofline"].get("steps_per_launch", 1))),
+                  "cols_per_lane": layout.get("cols_per_lane") or tuned.get("cols_per_lane", 0) or
+                                   (2 if "c2/" in cfg["kernel"] else (1 if "c1/" in cfg["kernel"] else 4)),
+                  "launch_ms": avg_ms})
+    counters = [e for e in counters if not (e.get("kernel") == entry["kernel"] and e.get("rows") == entry["rows"] and
+                                            e.get("cols") == entry["cols"] and e.get("rows_per_unit") == entry["rows_per_unit"])]
+    counters.append(entry)
+    counters.sort(key=lambda e: (e["kernel"], e["rows"], e["cols"], e["rows_per_unit"]))
     json.dump(counters, open(cpath, "w"), indent=1, sort_keys=True)
     print("\n".join(lines))
 
