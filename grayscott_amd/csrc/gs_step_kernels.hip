@@ -703,8 +703,30 @@ __device__ __forceinline__ void store_cols_buf(__amdgpu_buffer_rsrc_t r, int vof
     }
 }
 
+// GS_TB_TRACE (diagnostic builds only, tools/wave_timeline.py): every wave of gs_step_tb_k leaves five
+// timestamps of the 100 MHz real-time counter -- entry, first level-0 rows used (tick 3), level pipeline full
+// (tick 2K), last level-0 row taken (tick nticks - 2K), exit -- its hardware id and its unit in a device
+// buffer that gs_debug_trace_read() copies out.  The shipped build never defines it.
+#if defined(GS_TB_TRACE)
+constexpr int kTraceWords = 8, kTraceUnits = 1 << 17;
+__device__ unsigned long long gs_trace_buf[kTraceWords * kTraceUnits];
+__device__ __forceinline__ unsigned long long trace_now()
+{
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define GS_TRACE_AT(COND, SLOT) do { if (COND) ts[SLOT] = trace_now(); } while (0)
+#else
+#define GS_TRACE_AT(COND, SLOT) do { } while (0)
+#endif
+
 template <int K, bool EDGE, int FAST, int CPL, int ZH = -1>
-__device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, int strip, int lane)
+__device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, int strip, int lane
+#if defined(GS_TB_TRACE)
+                                         , unsigned long long (&ts)[5]
+#endif
+                                         )
 {
     constexpr int S = tb_sacrificial_lanes(K, CPL), W = tb_cols_per_wave(K, CPL);
     const int c = strip * W + (lane - S) * CPL; // first column of this lane (may be negative)
@@ -794,6 +816,9 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
             const int tick = t + s3;
             if (tick < nticks) {
                 const int l0 = first + tick; // level-0 row entering the pipeline
+                GS_TRACE_AT(tick == 3, 1);
+                GS_TRACE_AT(tick == 2 * K, 2);
+                GS_TRACE_AT(tick == nticks - 2 * K, 3);
                 w[0][s3] = widen_tb<CPL>(q[s3].u, q[s3].v);
                 if constexpr (!LATE) q[s3] = fetch(l0 + 3);
 #pragma unroll
@@ -930,12 +955,31 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     }
     const bool edge = (strip == 0) || ((strip + 1) * W + S * CPL >= a.cols) ||
                       (ur0 - K < 0 && !a.top_present) || (ur1 + K > a.rows && !a.bottom_present);
+#if defined(GS_TB_TRACE)
+    unsigned long long ts[5] = {trace_now(), 0, 0, 0, 0};
+#define GS_TRACE_ARG , ts
+#else
+#define GS_TRACE_ARG
+#endif
     if (!edge)
-        tb_march<K, false, FAST, CPL>(a, ur0, ur1, strip, lane);
+        tb_march<K, false, FAST, CPL>(a, ur0, ur1, strip, lane GS_TRACE_ARG);
     else if (a.zero_halo) // one branch per unit, one instantiation per boundary rule (see cell<>)
-        tb_march<K, true, FAST, CPL, 1>(a, ur0, ur1, strip, lane);
+        tb_march<K, true, FAST, CPL, 1>(a, ur0, ur1, strip, lane GS_TRACE_ARG);
     else
-        tb_march<K, true, FAST, CPL, 0>(a, ur0, ur1, strip, lane);
+        tb_march<K, true, FAST, CPL, 0>(a, ur0, ur1, strip, lane GS_TRACE_ARG);
+#undef GS_TRACE_ARG
+#if defined(GS_TB_TRACE)
+    ts[4] = trace_now();
+    if (lane == 0 && unit < kTraceUnits) {
+        unsigned long long *rec = gs_trace_buf + (size_t)unit * kTraceWords;
+        for (int i = 0; i < 5; ++i) rec[i] = ts[i];
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
+        rec[5] = ((unsigned long long)xcc << 32) | hw;
+        rec[6] = ((unsigned long long)(unsigned)ur0 << 32) | (unsigned)((ur1 - ur0) | (edge ? 0x40000000 : 0));
+        rec[7] = (unsigned)strip;
+    }
+#endif
 }
 
 #if !GS_TB_OP_ONLY
@@ -1534,6 +1578,25 @@ hipError_t GS_SUFFIX(gs_launch_lds)(const GsStepArgs &a, hipStream_t s, const ch
                            dim3(256), kargs, 0, s);
 }
 #endif // !GS_TB_OP_ONLY
+
+#if defined(GS_TB_TRACE)
+// Copies the trace buffer of THIS translation unit's kernels out (diagnostic builds only).
+#if GS_TB_OP_ONLY
+extern "C" int32_t gs_debug_trace_read_op(unsigned long long *dst, int32_t units, int32_t clear)
+#else
+extern "C" int32_t GS_SUFFIX(gs_debug_trace_read)(unsigned long long *dst, int32_t units, int32_t clear)
+#endif
+{
+    if (units > kTraceUnits) units = kTraceUnits;
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(gs_trace_buf), (size_t)units * kTraceWords * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(gs_trace_buf)) != hipSuccess) return -1;
+        if (hipMemset(p, 0, (size_t)units * kTraceWords * sizeof(unsigned long long)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 #if GS_TB_OP_ONLY
 // Kernel entry of the specialised variant for K fused steps, `fast` in {1, 3} (GsStepArgs::fast)

@@ -1,0 +1,70 @@
+#!/bin/bash
+# One parameterised script for the GPU box (run through gpurun), instead of a one-off script per run:
+#   tools/gpu_run.sh TAG STAGE [STAGE ...]
+# Logs and JSON lines land under gpurun_out/TAG/ (scratch; what is to be judged is copied to profiles/).
+# A failing stage ends the call (no GPU step is started after a failed or timed-out one).
+# Stages:
+#   newtests        this round's new GPU tests first (fast failure)
+#   tests           the whole GPU suite
+#   bench           bench.py as the driver runs it (--steps 20 --warmup 5) and with its defaults
+#   timeline:RxC[:key=value,...]   tools/wave_timeline.py on the diagnostic build (variants/libgs_hip_trace.so)
+#   sweep:RxC:STEPS:VARIANT;VARIANT...   tools/sweep.py (VARIANT = key=value,key=value)
+#   libsweep:NAME:RxC:STEPS:VARIANT;...  the same against grayscott_amd/variants/libgs_hip_NAME.so
+#   profile:TAG[:bench extra args]       tools/profile_gpu.sh
+#   configs         tools/baseline_configs.py
+#   criterion       tools/criterion_grid.py
+#   rehearsal       tools/rehearsal.sh
+#   py:SCRIPT[:args]  any python tool of this repository
+set -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=$1; shift
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$ROOT"
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+for stage in "$@"; do
+  name=${stage%%:*}
+  rest=${stage#*:}; [ "$rest" = "$stage" ] && rest=""
+  echo "=== stage $stage ($(date +%T))"
+  case $name in
+    newtests)
+      timeout -k 10 1100 python -m pytest tests/test_gpu_baseline_configs.py tests/test_gpu_multiprocess.py tests/test_gpu_parity.py -m gpu -x -q \
+        -k "baseline_configs or full_size or several_local or never_refreshes or pass_timing or two_contexts or row_slabs or shm" \
+        > "$OUT/newtests.log" 2>&1; rc=$?; tail -15 "$OUT/newtests.log" ;;
+    tests)
+      timeout -k 10 1100 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; rc=$?; tail -8 "$OUT/pytest_gpu.log" ;;
+    bench)
+      timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_style.json" 2> "$OUT/bench_driver_style.err"; rc=$?
+      tail -c 3000 "$OUT/bench_driver_style.json"; tail -3 "$OUT/bench_driver_style.err"
+      if [ $rc -eq 0 ]; then
+        timeout -k 10 600 python bench.py > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"; rc=$?
+        tail -c 3000 "$OUT/bench_unprofiled.json"
+      fi ;;
+    timeline)
+      IFS=: read -r grid kv <<< "$rest"
+      GS_HIP_LIBRARY=$ROOT/grayscott_amd/variants/libgs_hip_trace.so timeout -k 10 300 python tools/wave_timeline.py ${grid%x*} ${grid#*x} ${kv//,/ } \
+        > "$OUT/timeline_${grid}_${kv//[=,]/_}.log" 2>&1; rc=$?; cat "$OUT/timeline_${grid}_${kv//[=,]/_}.log" ;;
+    sweep)
+      IFS=: read -r grid steps variants <<< "$rest"
+      timeout -k 10 600 python tools/sweep.py --rows ${grid%x*} --cols ${grid#*x} --steps "$steps" --rounds 5 ${variants//;/ } 2>&1 | tee -a "$OUT/sweep.log"; rc=$? ;;
+    libsweep)
+      IFS=: read -r lib grid steps variants <<< "$rest"
+      echo "--- library variant $lib" | tee -a "$OUT/sweep.log"
+      GS_HIP_LIBRARY=$ROOT/grayscott_amd/variants/libgs_hip_$lib.so timeout -k 10 600 python tools/sweep.py --rows ${grid%x*} --cols ${grid#*x} --steps "$steps" --rounds 5 ${variants//;/ } 2>&1 | tee -a "$OUT/sweep.log"; rc=$? ;;
+    profile)
+      IFS=: read -r ptag extra <<< "$rest"
+      GS_BENCH_EXTRA="$extra" timeout -k 10 1100 bash tools/profile_gpu.sh "$ptag" 400 > "$OUT/profile_$ptag.log" 2>&1; rc=$?; tail -5 "$OUT/profile_$ptag.log" ;;
+    configs)
+      timeout -k 10 1100 python tools/baseline_configs.py > "$OUT/baseline_configs.log" 2>&1; rc=$?; tail -30 "$OUT/baseline_configs.log" ;;
+    criterion)
+      timeout -k 10 1100 python tools/criterion_grid.py > "$OUT/criterion_grid.log" 2>&1; rc=$?; tail -40 "$OUT/criterion_grid.log" ;;
+    rehearsal)
+      timeout -k 10 1100 bash tools/rehearsal.sh > "$OUT/rehearsal.log" 2>&1; rc=$?; tail -12 "$OUT/rehearsal.log" ;;
+    py)
+      IFS=: read -r script pyargs <<< "$rest"
+      timeout -k 10 900 python "$script" ${pyargs//,/ } > "$OUT/$(basename "$script" .py).log" 2>&1; rc=$?; tail -40 "$OUT/$(basename "$script" .py).log" ;;
+    *) echo "unknown stage $stage"; rc=2 ;;
+  esac
+  echo "=== stage $stage rc=$rc"
+  [ $rc -eq 0 ] || exit $rc
+done
