@@ -97,6 +97,7 @@ def run_schedule(sim, species):
     sim.perform_steps(species, STEPS_B)
     for _ in range(SINGLE):
         sim.perform_step(species)
+    sim.context.sync()      # gs_step only enqueues: the torch views below read on another stream
 
 
 def expected_passes(k):
