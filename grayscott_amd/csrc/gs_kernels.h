@@ -71,7 +71,8 @@ GS_DECLARE_LAUNCHERS(fused)
 
 // Entry points of the parameter-specialised temporal-blocking kernels (strict flavour only; their
 // own translation unit, see gs_step_kernels.hip: GS_TB_OP_ONLY).  nullptr for an unknown variant.
-const void *gs_tb_op_kernel_strict(int k, int fast, int cpl);
+// wg: waves per workgroup, 4 or 16 (the fair-progress form of one-round launches: K = 4, cpl 1 or 2 only).
+const void *gs_tb_op_kernel_strict(int k, int fast, int cpl, int wg);
 
 // Plane utilities (math-agnostic, defined once in gs_util_kernels.hip).
 hipError_t gs_launch_colormap(const float *row0, int32_t pitch, int32_t rows, int32_t cols, float scale,

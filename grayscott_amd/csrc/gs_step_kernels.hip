@@ -721,8 +721,23 @@ __device__ __forceinline__ unsigned long long trace_now()
 #define GS_TRACE_AT(COND, SLOT) do { } while (0)
 #endif
 
-template <int K, bool EDGE, int FAST, int CPL, int ZH = -1>
-__device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, int strip, int lane
+// Fair progress in launches of about one round of wave slots (FAIR, 16-wave workgroups).  The SIMD's issue
+// arbitration is priority, then AGE: of four waves with equal work the two oldest take nearly every slot, and
+// the four finish one after the other -- the last one alone on its SIMD for 15-20 % of the launch, where a
+// lone wave issues at most every 4th cycle, half the SIMD's rate (tools/wave_timeline.py, profiles/r03_sweeps.md
+// section 1).  With all 16 waves of a CU in one workgroup every wave publishes its progress (256ths of its
+// ticks) in an LDS word per tick and reads the words of the waves that share its SIMD: whoever is ahead of
+// another runs at priority 0, the others at 3, so the four stay within a tick of each other and end together.
+// Nobody ever waits for anybody: the board only steers s_setprio.
+struct FairBoard {
+    int *progress;           // LDS: one word per wave of the workgroup, 0 ... 256, INT_MAX once a wave has finished
+    unsigned long long group; // lanes (= wave indices) of the waves on this wave's SIMD
+    int wave;
+};
+
+template <int K, bool EDGE, int FAST, int CPL, int ZH = -1, bool FAIR = false>
+__device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, int strip, int lane,
+                                         const FairBoard &fb
 #if defined(GS_TB_TRACE)
                                          , unsigned long long (&ts)[5]
 #endif
@@ -801,6 +816,7 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
     RowQ<CPL> q[3];    // prefetch queue of level-0 rows, 3 ticks deep
     const int first = ur0 - K; // level-0 row of tick 0
     const int nticks = (ur1 - ur0) + 2 * K;
+    const int fair_scale = FAIR ? (256 << 16) / nticks : 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) q[i] = fetch(first + i);
 #pragma unroll
@@ -819,6 +835,14 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                 GS_TRACE_AT(tick == 3, 1);
                 GS_TRACE_AT(tick == 2 * K, 2);
                 GS_TRACE_AT(tick == nticks - 2 * K, 3);
+                if constexpr (FAIR) {
+                    const int mine = tick * fair_scale >> 16;       // 0 ... 256
+                    if (lane == 0) fb.progress[fb.wave] = mine;
+                    const int theirs = fb.progress[lane & 15];
+                    const unsigned long long behind = __builtin_amdgcn_ballot_w64(theirs < mine) & fb.group;
+                    if (behind) __builtin_amdgcn_s_setprio(0);
+                    else __builtin_amdgcn_s_setprio(3);
+                }
                 w[0][s3] = widen_tb<CPL>(q[s3].u, q[s3].v);
                 if constexpr (!LATE) q[s3] = fetch(l0 + 3);
 #pragma unroll
@@ -872,17 +896,32 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
     }
 }
 
-template <int K, int FAST, int CPL>
-__global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
+// WG: waves per workgroup.  4 independent waves, or all 16 of a CU with the progress board of tb_march<FAIR>.
+template <int K, int FAST, int CPL, int WG = 4>
+__global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
 {
     // half_diff needs MODE.IEEE = 0: hwreg(HW_REG_MODE, offset 9, width 1).  The bit only governs
     // the quieting of signalling NaNs otherwise, which parity does not cover.
     if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0);
     constexpr int W = tb_cols_per_wave(K, CPL), S = tb_sacrificial_lanes(K, CPL);
+    constexpr bool FAIR = WG == 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, see above
+    FairBoard fb{nullptr, 0ull, wave};
+    if constexpr (FAIR) {
+        // the board: words 0..15 progress, 16..31 the SIMD each wave runs on (HW_REG_HW_ID bits 5:4).  Every
+        // wave passes the barrier before any of them can leave the kernel.
+        __shared__ int board[32];
+        const int simd = (int)(__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)));
+        if (lane == 0) { board[wave] = 0; board[16 + wave] = simd; }
+        __syncthreads();
+        fb.progress = board;
+        fb.group = __builtin_amdgcn_ballot_w64(lane < 16 && board[16 + (lane & 15)] == simd);
+    }
+    // a wave without a unit marks itself finished (never "behind") and leaves
+#define GS_TB_LEAVE do { if constexpr (FAIR) { if (lane == 0) fb.progress[wave] = 0x7fffffff; } return; } while (0)
     const int strips = (a.cols + W - 1) / W;
-    const int unit = blockIdx.x * 4 + wave;
+    const int unit = blockIdx.x * WG + wave;
     const int rpu = a.rows_per_unit;
     const int small = a.small_rpu;
     const int rest_a = a.ra1 - a.ra0 - a.big_chunks * rpu; // rows of range a behind the full-height chunks
@@ -903,7 +942,7 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     const int es = a.edge_split == 2 ? 2 : 1;
     int chunk, strip, half = -1;
     if (strips <= ne) {
-        if (unit >= chunks * strips * es) return; // wave-uniform
+        if (unit >= chunks * strips * es) GS_TB_LEAVE; // wave-uniform
         chunk = unit / (strips * es);
         const int rem = unit - chunk * strips * es;
         strip = rem / es;
@@ -924,7 +963,7 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         } else {
             v -= nec * ni * es;
             chunk = nec + v / ni;
-            if (chunk >= chunks) return; // wave-uniform
+            if (chunk >= chunks) GS_TB_LEAVE; // wave-uniform
             strip = 1 + (v - (v / ni) * ni);
         }
     }
@@ -951,7 +990,7 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         const int hh = (ur1 - ur0 + 1) >> 1;
         if (half == 0) ur1 = min(ur0 + hh, ur1);
         else ur0 = ur0 + hh;
-        if (ur0 >= ur1) return; // a one-row chunk has no second half (wave-uniform)
+        if (ur0 >= ur1) GS_TB_LEAVE; // a one-row chunk has no second half (wave-uniform)
     }
     const bool edge = (strip == 0) || ((strip + 1) * W + S * CPL >= a.cols) ||
                       (ur0 - K < 0 && !a.top_present) || (ur1 + K > a.rows && !a.bottom_present);
@@ -962,12 +1001,14 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
 #define GS_TRACE_ARG
 #endif
     if (!edge)
-        tb_march<K, false, FAST, CPL>(a, ur0, ur1, strip, lane GS_TRACE_ARG);
+        tb_march<K, false, FAST, CPL, -1, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
     else if (a.zero_halo) // one branch per unit, one instantiation per boundary rule (see cell<>)
-        tb_march<K, true, FAST, CPL, 1>(a, ur0, ur1, strip, lane GS_TRACE_ARG);
+        tb_march<K, true, FAST, CPL, 1, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
     else
-        tb_march<K, true, FAST, CPL, 0>(a, ur0, ur1, strip, lane GS_TRACE_ARG);
+        tb_march<K, true, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
 #undef GS_TRACE_ARG
+    if constexpr (FAIR) { if (lane == 0) fb.progress[wave] = 0x7fffffff; }
+#undef GS_TB_LEAVE
 #if defined(GS_TB_TRACE)
     ts[4] = trace_now();
     if (lane == 0 && unit < kTraceUnits) {
@@ -1401,14 +1442,24 @@ hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const
 
 // K fused steps over the row ranges of GsStepArgs; on slab seams the ghost rows must be K deep.
 // Kernel entry for k fused steps, specialisation `fast` (already reduced to {0, 1, 3}) and cpl columns per lane.
-static const void *tb_entry(int k, int fast, int cpl)
+static const void *tb_entry(int k, int fast, int cpl, int wg = 4)
 {
     const void *fn = nullptr;
 #define GS_TB_CASE(KK, CC)                                                                      \
     case (KK) * 8 + (CC): fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<KK, 0, CC>); break;
+    if (wg == 16) { // the fair-progress form: 4 fused steps, 1 or 2 columns per lane (128 registers at most)
+        if (k != 4 || (cpl != 1 && cpl != 2)) return nullptr;
+        if (fast) {
+#if !GS_MATH_FUSED
+            return gs_tb_op_kernel_strict(k, fast, cpl, 16);
+#endif
+        }
+        return cpl == 1 ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 0, 1, 16>)
+                        : reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 0, 2, 16>);
+    }
     if (fast) {
 #if !GS_MATH_FUSED
-        fn = gs_tb_op_kernel_strict(k, fast, cpl);
+        fn = gs_tb_op_kernel_strict(k, fast, cpl, 4);
 #endif
     } else {
         switch (k * 8 + cpl) {
@@ -1474,6 +1525,9 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
       "tb-k4" C "/" GS_MATH_NAME ".op"}}
     static const char *const names[3][2][4] = {GS_TB_NAMES("c1"), GS_TB_NAMES("c2"), GS_TB_NAMES("")};
 #undef GS_TB_NAMES
+    // "f": the fair-progress form (16-wave workgroups) of one-round launches
+    static const char *const names16[2][2] = {{"tb-k4c1f/" GS_MATH_NAME, "tb-k4c1f/" GS_MATH_NAME ".op"},
+                                              {"tb-k4c2f/" GS_MATH_NAME, "tb-k4c2f/" GS_MATH_NAME ".op"}};
     if (k < 1 || k > 4 || a.cols <= 0 || a.rows_per_unit <= 0) return hipErrorInvalidValue;
     const int cpl = a.cpl == 0 ? 4 : a.cpl;
     if (cpl != 1 && cpl != 2 && cpl != 4) return hipErrorInvalidValue;
@@ -1556,9 +1610,18 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
             units = chunks * ne * 2 + nec * (strips - ne) * 2 + (chunks - nec) * (strips - ne);
         }
     }
+    // A launch that fits the chip in ONE round of 16-wave workgroups (one per CU, 4 waves per SIMD) runs the
+    // fair-progress form of the kernel (tb_march<FAIR>): every unit starts at once there and, left to the
+    // SIMDs' oldest-first arbitration, the waves of a SIMD finish one after the other, the last one alone.
+    static const int fair_env = std::getenv("GS_HIP_FAIR") ? std::atoi(std::getenv("GS_HIP_FAIR")) : -1;
+    const void *fair_fn = units <= 4096 && units > 1024 && fair_env != 0 ? tb_entry(k, fast, cpl, 16) : nullptr;
+    void *kargs[] = {&args};
+    if (fair_fn) {
+        if (name) *name = names16[cpl == 1 ? 0 : 1][fast ? 1 : 0];
+        return hipLaunchKernel(fair_fn, dim3((unsigned)((units + 15) / 16)), dim3(1024), kargs, 0, s);
+    }
     const long blocks = (units + 3) / 4;
     if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
-    void *kargs[] = {&args};
     return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), kargs, 0, s);
 }
 
@@ -1601,8 +1664,16 @@ extern "C" int32_t GS_SUFFIX(gs_debug_trace_read)(unsigned long long *dst, int32
 #if GS_TB_OP_ONLY
 // Kernel entry of the specialised variant for K fused steps, `fast` in {1, 3} (GsStepArgs::fast)
 // and `cpl` columns per lane.
-const void *gs_tb_op_kernel_strict(int k, int fast, int cpl)
+const void *gs_tb_op_kernel_strict(int k, int fast, int cpl, int wg)
 {
+    if (wg == 16) {
+        if (k != 4 || (cpl != 1 && cpl != 2) || (fast != 1 && fast != 3)) return nullptr;
+        if (fast == 1)
+            return cpl == 1 ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 1, 1, 16>)
+                            : reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 1, 2, 16>);
+        return cpl == 1 ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 3, 1, 16>)
+                        : reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 3, 2, 16>);
+    }
 #define GS_TB_CASE(KK, FF, CC)                                                                  \
     case ((KK) * 4 + (FF)) * 8 + (CC): return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<KK, FF, CC>);
 #define GS_TB_CASES(FF, CC) GS_TB_CASE(1, FF, CC) GS_TB_CASE(2, FF, CC) GS_TB_CASE(3, FF, CC) GS_TB_CASE(4, FF, CC)
