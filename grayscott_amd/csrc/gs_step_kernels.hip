@@ -917,6 +917,19 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         __syncthreads();
         fb.progress = board;
         fb.group = __builtin_amdgcn_ballot_w64(lane < 16 && board[16 + (lane & 15)] == simd);
+        if (a.fair_mode == 2) {
+            // pairs: the waves of a SIMD in dispatch order (0, 1), (2, 3) -- each pair keeps step, the pairs
+            // stay out of phase with each other (the older pair gets the slots first: its memory-bound first
+            // ticks overlap the younger pair's, and a pair alone on a SIMD still fills the issue slots)
+            unsigned long long rest = fb.group, mine = 0;
+            int rank = 0, my_rank = 0;
+            for (unsigned long long g = rest; g; g &= g - 1, ++rank)
+                if ((g & (0ull - g)) == (1ull << wave)) my_rank = rank;
+            rank = 0;
+            for (unsigned long long g = rest; g; g &= g - 1, ++rank)
+                if ((rank >> 1) == (my_rank >> 1)) mine |= g & (0ull - g);
+            fb.group = mine;
+        }
     }
     // a wave without a unit marks itself finished (never "behind") and leaves
 #define GS_TB_LEAVE do { if constexpr (FAIR) { if (lane == 0) fb.progress[wave] = 0x7fffffff; } return; } while (0)
@@ -1615,6 +1628,7 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // SIMDs' oldest-first arbitration, the waves of a SIMD finish one after the other, the last one alone.
     static const int fair_env = std::getenv("GS_HIP_FAIR") ? std::atoi(std::getenv("GS_HIP_FAIR")) : -1;
     const void *fair_fn = units <= 4096 && units > 1024 && fair_env != 0 ? tb_entry(k, fast, cpl, 16) : nullptr;
+    args.fair_mode = fair_env == 2 ? 2 : 1;
     void *kargs[] = {&args};
     if (fair_fn) {
         if (name) *name = names16[cpl == 1 ? 0 : 1][fast ? 1 : 0];
