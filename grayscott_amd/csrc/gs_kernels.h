@@ -48,9 +48,6 @@ struct GsStepArgs {
     int32_t fast;
     // Columns per lane of the temporal-blocking kernel: 4 (0 means 4), 2 or 1.
     int32_t cpl;
-    // Fair-progress form (16-wave workgroups; filled in by the launcher): 1 = the waves of a SIMD keep step,
-    // 2 = they keep step in pairs.
-    int32_t fair_mode;
     // Boundary rule on global edges: 0 = naive's clipped window (weights anchored at the window's
     // top-left corner), 1 = full window with zeros outside the grid (gs_boundary in gs_hip.h).
     int32_t zero_halo;

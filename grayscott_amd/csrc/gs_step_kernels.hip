@@ -917,19 +917,6 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         __syncthreads();
         fb.progress = board;
         fb.group = __builtin_amdgcn_ballot_w64(lane < 16 && board[16 + (lane & 15)] == simd);
-        if (a.fair_mode == 2) {
-            // pairs: the waves of a SIMD in dispatch order (0, 1), (2, 3) -- each pair keeps step, the pairs
-            // stay out of phase with each other (the older pair gets the slots first: its memory-bound first
-            // ticks overlap the younger pair's, and a pair alone on a SIMD still fills the issue slots)
-            unsigned long long rest = fb.group, mine = 0;
-            int rank = 0, my_rank = 0;
-            for (unsigned long long g = rest; g; g &= g - 1, ++rank)
-                if ((g & (0ull - g)) == (1ull << wave)) my_rank = rank;
-            rank = 0;
-            for (unsigned long long g = rest; g; g &= g - 1, ++rank)
-                if ((rank >> 1) == (my_rank >> 1)) mine |= g & (0ull - g);
-            fb.group = mine;
-        }
     }
     // a wave without a unit marks itself finished (never "behind") and leaves
 #define GS_TB_LEAVE do { if constexpr (FAIR) { if (lane == 0) fb.progress[wave] = 0x7fffffff; } return; } while (0)
@@ -1626,9 +1613,14 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // A launch that fits the chip in ONE round of 16-wave workgroups (one per CU, 4 waves per SIMD) runs the
     // fair-progress form of the kernel (tb_march<FAIR>): every unit starts at once there and, left to the
     // SIMDs' oldest-first arbitration, the waves of a SIMD finish one after the other, the last one alone.
+    // Not for short marches: there most of a unit's ticks are the memory-bound filling of the level pipeline,
+    // and waves left out of phase by the oldest-first arbitration hide each other's waits (1080 x 1920, 10-row
+    // units, 1 column per lane: 430 k as they come, 390 k in step, 377 k in step in pairs; 19-row units of
+    // 2048 x 4096: 687 k / 738 k / 718 k; profiles/r03_sweeps.md, section 2).  GS_HIP_FAIR = 0 / 1 forces it off / on.
     static const int fair_env = std::getenv("GS_HIP_FAIR") ? std::atoi(std::getenv("GS_HIP_FAIR")) : -1;
-    const void *fair_fn = units <= 4096 && units > 1024 && fair_env != 0 ? tb_entry(k, fast, cpl, 16) : nullptr;
-    args.fair_mode = fair_env == 2 ? 2 : 1;
+    static const int fair_min_rows = std::getenv("GS_HIP_FAIR_MIN_ROWS") ? std::atoi(std::getenv("GS_HIP_FAIR_MIN_ROWS")) : 16;
+    const bool fair = units <= 4096 && units > 1024 && (fair_env < 0 ? rpu >= fair_min_rows : fair_env != 0);
+    const void *fair_fn = fair ? tb_entry(k, fast, cpl, 16) : nullptr;
     void *kargs[] = {&args};
     if (fair_fn) {
         if (name) *name = names16[cpl == 1 ? 0 : 1][fast ? 1 : 0];
