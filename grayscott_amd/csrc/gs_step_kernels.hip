@@ -671,17 +671,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
 }
+// GS_TB_AUX_LOAD / GS_TB_AUX_STORE: cache-policy bits of every plane access of the marching kernel (gfx950:
+// 1 = sc0, 2 = nt, 16 = sc1).  0 in the shipped build; 16 / 16 is the timing experiment "what would accesses that
+// other CUs can observe inside a launch cost" (profiles/r03_sweeps.md, section 3).
+#ifndef GS_TB_AUX_LOAD
+#define GS_TB_AUX_LOAD 0
+#endif
+#ifndef GS_TB_AUX_STORE
+#define GS_TB_AUX_STORE 0
+#endif
 template <int CPL>
 __device__ __forceinline__ void load_cols_buf(__amdgpu_buffer_rsrc_t r, int voff, int soff, float (&out)[CPL])
 {
     if constexpr (CPL == 4) {
-        const auto x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        const auto x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, GS_TB_AUX_LOAD);
         __builtin_memcpy(out, &x, sizeof x);
     } else if constexpr (CPL == 2) {
-        const auto x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        const auto x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, GS_TB_AUX_LOAD);
         __builtin_memcpy(out, &x, sizeof x);
     } else {
-        const auto x = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+        const auto x = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, GS_TB_AUX_LOAD);
         __builtin_memcpy(out, &x, sizeof x);
     }
 }
@@ -691,15 +700,15 @@ __device__ __forceinline__ void store_cols_buf(__amdgpu_buffer_rsrc_t r, int vof
     if constexpr (CPL == 4) {
         decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) x;
         __builtin_memcpy(&x, in, sizeof x);
-        __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, GS_TB_AUX_STORE);
     } else if constexpr (CPL == 2) {
         decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0)) x;
         __builtin_memcpy(&x, in, sizeof x);
-        __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, GS_TB_AUX_STORE);
     } else {
         decltype(__builtin_amdgcn_raw_buffer_load_b32(r, 0, 0, 0)) x;
         __builtin_memcpy(&x, in, sizeof x);
-        __builtin_amdgcn_raw_buffer_store_b32(x, r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(x, r, voff, soff, GS_TB_AUX_STORE);
     }
 }
 
