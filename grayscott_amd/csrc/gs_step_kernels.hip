@@ -1622,13 +1622,14 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // A launch that fits the chip in ONE round of 16-wave workgroups (one per CU, 4 waves per SIMD) runs the
     // fair-progress form of the kernel (tb_march<FAIR>): every unit starts at once there and, left to the
     // SIMDs' oldest-first arbitration, the waves of a SIMD finish one after the other, the last one alone.
-    // Not for short marches: there most of a unit's ticks are the memory-bound filling of the level pipeline,
-    // and waves left out of phase by the oldest-first arbitration hide each other's waits (1080 x 1920, 10-row
-    // units, 1 column per lane: 430 k as they come, 390 k in step, 377 k in step in pairs; 19-row units of
-    // 2048 x 4096: 687 k / 738 k / 718 k; profiles/r03_sweeps.md, section 2).  GS_HIP_FAIR = 0 / 1 forces it off / on.
+    // Not for short marches of the 1-column layout: there most of a unit's ticks are the memory-bound filling
+    // of the level pipeline, and waves left out of phase by the oldest-first arbitration hide each other's
+    // waits.  Free-running / in step, same box (profiles/r03_sweeps.md, section 2): 1 column per lane, 10-row
+    // units 430 k / 390 k, 12 rows 465 k / 443 k, 16 rows 524 k / 514 k, 20 rows 565 k / 573 k, 40 rows 677 k / 705 k;
+    // 2 columns per lane, 10 rows 523 k / 537 k, 15 rows 615 k / 633 k, 19 rows 687 k / 738 k, 38 rows 782 k / 865 k.
+    // GS_HIP_FAIR = 0 / 1 forces it off / on.
     static const int fair_env = std::getenv("GS_HIP_FAIR") ? std::atoi(std::getenv("GS_HIP_FAIR")) : -1;
-    static const int fair_min_rows = std::getenv("GS_HIP_FAIR_MIN_ROWS") ? std::atoi(std::getenv("GS_HIP_FAIR_MIN_ROWS")) : 16;
-    const bool fair = units <= 4096 && units > 1024 && (fair_env < 0 ? rpu >= fair_min_rows : fair_env != 0);
+    const bool fair = units <= 4096 && units > 1024 && (fair_env < 0 ? (cpl == 2 || rpu >= 20) : fair_env != 0);
     const void *fair_fn = fair ? tb_entry(k, fast, cpl, 16) : nullptr;
     void *kargs[] = {&args};
     if (fair_fn) {
