@@ -57,7 +57,10 @@ for stage in "$@"; do
     configs)
       timeout -k 10 1100 python tools/baseline_configs.py > "$OUT/baseline_configs.log" 2>&1; rc=$?; tail -30 "$OUT/baseline_configs.log" ;;
     criterion)
-      timeout -k 10 1100 python tools/criterion_grid.py > "$OUT/criterion_grid.log" 2>&1; rc=$?; tail -40 "$OUT/criterion_grid.log" ;;
+      timeout -k 10 1100 python tools/criterion_grid.py --cpu > "$OUT/criterion_grid.log" 2>&1; rc=$?; tail -14 "$OUT/criterion_grid.log"
+      if [ $rc -eq 0 ]; then
+        timeout -k 10 1100 python tools/criterion_grid.py --full > "$OUT/criterion_grid_full.log" 2>&1; rc=$?; tail -14 "$OUT/criterion_grid_full.log"
+      fi ;;
     rehearsal)
       timeout -k 10 1100 bash tools/rehearsal.sh > "$OUT/rehearsal.log" 2>&1; rc=$?; tail -12 "$OUT/rehearsal.log" ;;
     py)
