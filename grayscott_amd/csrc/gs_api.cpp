@@ -533,6 +533,7 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
     a.ghost = kGhostRows;
     a.rows_per_unit = pick_rows_per_unit(ctx, a.rows, a.cols, fuse);
     a.cpl = pick_cols_per_lane(ctx, a.rows, a.cols, fuse);
+    a.allow_fair = ctx->total_slabs() == 1;
     a.zero_halo = ctx->o.boundary == GS_BOUNDARY_ZERO_HALO;
     std::memcpy(a.w, ctx->p.w, sizeof a.w);
     a.du = ctx->p.du;
@@ -646,6 +647,7 @@ int32_t step_bands(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u,
         SlabRt &b = ctx->bands[k];
         const int r0 = (int)((int64_t)k * n / V), r1 = (int)((int64_t)(k + 1) * n / V);
         GsStepArgs a = full;
+        a.allow_fair = 0; // several launches share the chip
         const ptrdiff_t off = (ptrdiff_t)r0 * full.pitch;
         a.in_u += off; a.in_v += off; a.out_u += off; a.out_v += off;
         a.rows = r1 - r0;

@@ -48,6 +48,11 @@ struct GsStepArgs {
     int32_t fast;
     // Columns per lane of the temporal-blocking kernel: 4 (0 means 4), 2 or 1.
     int32_t cpl;
+    // 1 = this launch has the GPU to itself (a single slab, no row bands): a launch of one round may then run
+    // as 16-wave workgroups that keep step (gs_launch_tb).  0 on slab chains and row bands: workgroups that
+    // own whole CUs until all their waves end would keep the boundary-band kernel, the ghost-row copies and
+    // RCCL's kernels out until the end of the launch (8 slabs on one GPU: 0.79 instead of 0.88 of one slab).
+    int32_t allow_fair;
     // Boundary rule on global edges: 0 = naive's clipped window (weights anchored at the window's
     // top-left corner), 1 = full window with zeros outside the grid (gs_boundary in gs_hip.h).
     int32_t zero_halo;

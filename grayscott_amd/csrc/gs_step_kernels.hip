@@ -1629,7 +1629,7 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // 2 columns per lane, 10 rows 523 k / 537 k, 15 rows 615 k / 633 k, 19 rows 687 k / 738 k, 38 rows 782 k / 865 k.
     // GS_HIP_FAIR = 0 / 1 forces it off / on.
     static const int fair_env = std::getenv("GS_HIP_FAIR") ? std::atoi(std::getenv("GS_HIP_FAIR")) : -1;
-    const bool fair = units <= 4096 && units > 1024 && (fair_env < 0 ? (cpl == 2 || rpu >= 20) : fair_env != 0);
+    const bool fair = a.allow_fair && units <= 4096 && units > 1024 && (fair_env < 0 ? (cpl == 2 || rpu >= 20) : fair_env != 0);
     const void *fair_fn = fair ? tb_entry(k, fast, cpl, 16) : nullptr;
     void *kargs[] = {&args};
     if (fair_fn) {
