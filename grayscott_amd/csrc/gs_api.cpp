@@ -455,7 +455,19 @@ int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fu
 {
     if (ctx->o.rows_per_block > 0) return ctx->o.rows_per_block;
     if (tuned_for(ctx, rows, cols, fuse)) return ctx->tuned_rpu;
-    return model_rows_per_unit(ctx, rows, cols, fuse, pick_cols_per_lane(ctx, rows, cols, fuse));
+    // Several slabs of one process on ONE device share its wave slots: their launches run side by side and
+    // together fill many rounds, so the unit height follows the rows the device holds, not the slab's own
+    // (8 slabs of 2048 x 16384 on one GPU: 71-row units, one round per slab, 885 k; 96-128 rows 981-987 k
+    // = 0.95 of the single slab; 4 slabs 970 k -> 1006 k; profiles/r03_sweeps.md, section 5).
+    int64_t rows_on_device = rows;
+    if (ctx->slabs.size() > 1) {
+        int same = 0;
+        for (const auto &sl : ctx->slabs) same += sl.device == ctx->slabs[0].device;
+        rows_on_device = (int64_t)rows * same;
+        if (rows_on_device > 0x7fffffff) rows_on_device = 0x7fffffff;
+    }
+    const int32_t h = model_rows_per_unit(ctx, (int32_t)rows_on_device, cols, fuse, pick_cols_per_lane(ctx, rows, cols, fuse));
+    return h > rows ? (rows > 0 ? rows : 1) : h;
 }
 
 // ... for a given lane layout, from the launch geometry alone (also the tuner's first candidate).

@@ -22,7 +22,7 @@ from oracle import cpu_oracle, cpu_parallel  # noqa: E402
 def gpu_rows():
     print("| grid (rows x cols) | steps | kernel | median of 5, Mcells×steps/s | min .. max | ms/step |")
     print("|---|---|---|---|---|---|")
-    for rows, cols, steps in ((1080, 1920, 1000), (4096, 4096, 1000), (16384, 16384, 10000)):
+    for rows, cols, steps in ((1080, 1920, 1000), (2048, 4096, 1000), (4096, 4096, 1000), (8192, 4096, 1000), (16384, 16384, 10000)):
         sim = Simulation.new(Parameters(), HipArgs(devices=[0]))
         scratch = sim.make_species([rows, cols])
         sim.perform_steps(scratch, 4000 if rows < 16384 else 400)       # finish the on-line tuning
