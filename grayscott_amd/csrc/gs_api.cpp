@@ -455,19 +455,23 @@ int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fu
 {
     if (ctx->o.rows_per_block > 0) return ctx->o.rows_per_block;
     if (tuned_for(ctx, rows, cols, fuse)) return ctx->tuned_rpu;
+    const int cpl = pick_cols_per_lane(ctx, rows, cols, fuse);
+    const int32_t own = model_rows_per_unit(ctx, rows, cols, fuse, cpl);
     // Several slabs of one process on ONE device share its wave slots: their launches run side by side and
-    // together fill many rounds, so the unit height follows the rows the device holds, not the slab's own
-    // (8 slabs of 2048 x 16384 on one GPU: 71-row units, one round per slab, 885 k; 96-128 rows 981-987 k
-    // = 0.95 of the single slab; 4 slabs 970 k -> 1006 k; profiles/r03_sweeps.md, section 5).
-    int64_t rows_on_device = rows;
-    if (ctx->slabs.size() > 1) {
+    // together fill many rounds.  Where a slab alone is too small for a decent unit height in whole rounds
+    // (under 96 rows), the height follows the rows the device holds instead (8 slabs of 2048 x 16384 on one
+    // GPU: 71-76-row units, one round per slab, 865-885 k; 96-128 rows 981-1030 k = 0.95-0.98 of the single
+    // slab; 2 slabs keep their own 142 rows = two rounds each, 1077 k against 1000 k with 122;
+    // profiles/r03_sweeps.md, section 5).
+    if (ctx->slabs.size() > 1 && own < 96 && fuse > 1) {
         int same = 0;
         for (const auto &sl : ctx->slabs) same += sl.device == ctx->slabs[0].device;
-        rows_on_device = (int64_t)rows * same;
+        int64_t rows_on_device = (int64_t)rows * same;
         if (rows_on_device > 0x7fffffff) rows_on_device = 0x7fffffff;
+        const int32_t h = model_rows_per_unit(ctx, (int32_t)rows_on_device, cols, fuse, cpl);
+        if (h > own) return h > rows ? (rows > 0 ? rows : 1) : h;
     }
-    const int32_t h = model_rows_per_unit(ctx, (int32_t)rows_on_device, cols, fuse, pick_cols_per_lane(ctx, rows, cols, fuse));
-    return h > rows ? (rows > 0 ? rows : 1) : h;
+    return own;
 }
 
 // ... for a given lane layout, from the launch geometry alone (also the tuner's first candidate).
@@ -524,6 +528,11 @@ int32_t launch_rows(gs_ctx *ctx, const GsStepArgs &a, hipStream_t stream, int fu
     if (e != hipSuccess) return fail(GS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     ctx->last_kernel = name;
     ctx->launches++;
+    static const bool trace = std::getenv("GS_HIP_TRACE_LAUNCH") != nullptr;
+    static int traced = 0;
+    if (trace && traced < 64 && ++traced)
+        std::fprintf(stderr, "gs_hip launch %s: slab of %d rows x %d cols, rows [%d, %d) + [%d, %d), unit %d rows, %d col/lane, %d step(s)\n",
+                     name, a.rows, a.cols, a.ra0, a.ra1, a.rb0, a.rb1, a.rows_per_unit, a.cpl, fuse);
     return GS_OK;
 }
 
