@@ -37,7 +37,7 @@ EXPORTS = (
     "gs_step", "gs_run", "gs_sync", "gs_timer_start", "gs_timer_stop", "gs_ctx_info",
     "gs_host_alloc", "gs_host_free", "gs_field_download_async", "gs_download_wait",
     "gs_ctx_get_tuned", "gs_ctx_set_tuned", "gs_ctx_comm_info", "gs_field_colormap",
-    "gs_ctx_stats", "gs_ctx_set_pass_timing", "gs_field_mark_written",
+    "gs_ctx_stats", "gs_ctx_set_pass_timing", "gs_field_mark_written", "gs_rccl_selftest",
 )
 
 
@@ -150,6 +150,7 @@ def load() -> ctypes.CDLL:
         "gs_ctx_stats": (i32, [vp, P(GsStats)]),
         "gs_ctx_set_pass_timing": (i32, [vp, i32]),
         "gs_field_mark_written": (i32, [vp, vp]),
+        "gs_rccl_selftest": (i32, [i32, u64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
@@ -181,6 +182,11 @@ def device_count() -> int:
     n = ctypes.c_int32(0)
     status = load().gs_device_count(ctypes.byref(n))
     return int(n.value) if status == GS_OK else 0
+
+
+def rccl_selftest(device: int = 0, floats: int = 1 << 16) -> None:
+    """``gs_rccl_selftest``: raises ``GsError`` when RCCL cannot be loaded or a one-rank send / receive fails."""
+    check(load().gs_rccl_selftest(device, floats))
 
 
 def get_unique_id() -> bytes:

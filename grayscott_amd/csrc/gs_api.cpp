@@ -1223,6 +1223,52 @@ int32_t gs_get_unique_id(void *out128)
     return GS_OK;
 }
 
+int32_t gs_rccl_selftest(int32_t device, uint64_t floats)
+{
+    Rccl *R = rccl();
+    if (!R) return fail(GS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+    if (floats == 0 || floats > (1ull << 28)) return fail(GS_ERR_INVALID, "message of %llu floats", (unsigned long long)floats);
+    GS_HIP(hipSetDevice(device));
+    ncclUniqueId id;
+    GS_NCCL(R, R->GetUniqueId(&id));
+    ncclComm_t comm = nullptr;
+    GS_NCCL(R, R->CommInitRank(&comm, 1, id, 0));
+    float *src = nullptr, *dst = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<float> host(floats), back(floats);
+    for (uint64_t i = 0; i < floats; ++i) host[i] = (float)(i % 65521) * 0.25f + 1.0f;
+    int32_t st = GS_OK;
+    auto step = [&](hipError_t e, const char *what) {
+        if (st == GS_OK && e != hipSuccess) st = fail(GS_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    };
+    int least = 0, greatest = 0;
+    step(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+    step(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
+    step(hipMalloc(reinterpret_cast<void **>(&src), floats * sizeof(float)), "hipMalloc");
+    step(hipMalloc(reinterpret_cast<void **>(&dst), floats * sizeof(float)), "hipMalloc");
+    step(hipMemcpy(src, host.data(), floats * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy");
+    step(hipMemset(dst, 0, floats * sizeof(float)), "hipMemset");
+    if (st == GS_OK) {
+        // the call pattern of push_halo: one group, a send and the matching receive, on the halo stream
+        ncclResult_t r = R->GroupStart();
+        if (r == ncclSuccess) r = R->Send(src, (size_t)floats, ncclFloat, 0, comm, stream);
+        if (r == ncclSuccess) r = R->Recv(dst, (size_t)floats, ncclFloat, 0, comm, stream);
+        const ncclResult_t e = R->GroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) st = fail(GS_ERR_RCCL, "grouped ncclSend / ncclRecv to self failed: %s", R->GetErrorString(r));
+    }
+    step(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    step(hipMemcpy(back.data(), dst, floats * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy");
+    if (st == GS_OK && std::memcmp(back.data(), host.data(), floats * sizeof(float)) != 0)
+        st = fail(GS_ERR_RCCL, "the message came back altered");
+    if (stream) (void)hipStreamDestroy(stream);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    R->CommDestroy(comm);
+    (void)hipGetLastError();
+    return st;
+}
+
 int32_t gs_ctx_destroy(gs_ctx *ctx)
 {
     if (!ctx) return GS_OK;

@@ -155,6 +155,12 @@ int32_t gs_device_count(int32_t *out);
 #define GS_UNIQUE_ID_BYTES 128
 int32_t gs_get_unique_id(void *out128);
 
+/* Is RCCL usable from this process?  Loads the library exactly as a multi-process context does (GS_RCCL_LIBRARY,
+ * else librccl), creates a ONE-rank communicator on `device` and moves a message of `floats` f32 to itself with the
+ * call pattern of the ghost-row exchange (one group: ncclSend + ncclRecv, on a high-priority stream), then compares
+ * it.  For a maintainer's first multi-GPU run; no context is needed. */
+int32_t gs_rccl_selftest(int32_t device, uint64_t floats);
+
 /* SimulateCreate::new(params, args) (compute/shared/src/lib.rs:42-45).
  *   device_ids / n_local : local slabs, top to bottom (NULL / 0 = one slab on device 0)
  *   rank, world          : this process's place in the row-wise chain (0, 1 = single process)

@@ -92,6 +92,39 @@ def shm_transport(built):
     return lib
 
 
+def _selftest_worker(out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    os.environ.pop("GS_RCCL_LIBRARY", None)
+    from grayscott_amd import GsError, capi
+
+    try:
+        for floats in (1, 4 * 16384, 4 * 32768):      # the smallest message and the K-row messages of the BASELINE grids
+            capi.rccl_selftest(0, floats)
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    except GsError as e:
+        open(os.path.join(out_dir, "error"), "w").write(str(e))
+
+
+def test_real_rccl_moves_a_ghost_row_message_on_one_gpu(tmp_path, built):
+    """The REAL librccl on a 1-GPU box: a one-rank communicator, the grouped ncclSend + ncclRecv pattern of the
+    ghost-row exchange on a high-priority stream (gs_rccl_selftest).  It cannot check a neighbour exchange
+    (RCCL refuses two ranks on one device), but it does check that the loader finds the library, that every
+    entry point the exchange uses binds and runs in this image, and that a K-row message survives.  In its own
+    process: RCCL's initialisation should not meet torch's."""
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_selftest_worker, args=(str(tmp_path),))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0, p.exitcode
+    if (tmp_path / "error").exists():
+        msg = open(tmp_path / "error").read()
+        if "to self" in msg:
+            pytest.skip("this RCCL build does not loop a message back to its own rank: " + msg[:200])
+        raise AssertionError(msg)
+    assert (tmp_path / "ok").exists()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_rccl_ranks_match_oracle(tmp_path, built, world):
     _ranks_match_oracle(tmp_path, world, 96, 300, 22, "", None)

@@ -239,6 +239,37 @@ def test_temporal_blocking_large_grid_vs_stream():
         assert_bits_equal(got[1], ref[1], f"TB{fuse} vs stream V")
 
 
+@pytest.mark.parametrize("case", [
+    dict(rows=1100, cols=1920, cpl=1, rpu=20),                       # 1 column per lane, 1925 units + edge halves
+    dict(rows=1024, cols=2048, cpl=2, rpu=10),                       # 2 columns per lane, short units
+    dict(rows=1500, cols=1500, cpl=2, rpu=12, boundary=capi.GS_BOUNDARY_ZERO_HALO),
+    dict(rows=1300, cols=1700, cpl=2, rpu=16, math=capi.GS_MATH_FUSED),
+    dict(rows=1300, cols=1700, cpl=1, rpu=33, general=True),         # non-default parameters: the general kernels
+    dict(rows=2000, cols=130, cpl=2, rpu=2),                         # two strips, both edge strips, 2-row units in halves
+])
+def test_in_step_workgroups_bit_exact(case):
+    """The form of the marching kernel that launches of one round run on a single slab: 16-wave workgroups
+    whose waves keep step through an LDS progress board and s_setprio (tb-k4c?f).  Same arithmetic, same
+    unit decomposition -- the results must be the oracle's bit for bit, edge units, ragged right end,
+    remainder passes and both boundary rules included."""
+    rows, cols = case["rows"], case["cols"]
+    u0, v0 = stress_fields((rows, cols), 21)
+    p = Parameters(feed_rate=0.03, kill_rate=0.06, time_step=0.5, diffusion_rate_u=0.2) if case.get("general") else Parameters()
+    kw = dict(kernel=capi.GS_KERNEL_TB, fuse_steps=4, rows_per_block=case["rpu"], cols_per_lane=case["cpl"],
+              boundary=case.get("boundary", capi.GS_BOUNDARY_CLIPPED), math=case.get("math", capi.GS_MATH_STRICT))
+    steps = 11                                                        # a 3-step pass, then two in-step passes
+    ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True,
+                              boundary=oracle.ZERO_HALO if kw["boundary"] == capi.GS_BOUNDARY_ZERO_HALO else oracle.CLIPPED)
+    got_u, got_v, info = gpu_run(u0, v0, steps, params=p, args=args(**kw))
+    assert info[0].startswith("tb-k4c%df/" % case["cpl"]), info
+    if kw["math"] == capi.GS_MATH_STRICT:
+        assert_bits_equal(got_u, ref_u, f"U {case}")
+        assert_bits_equal(got_v, ref_v, f"V {case}")
+    else:
+        # stress fields hold no sub-normal intermediates in 11 steps: the fused taps agree bit for bit too
+        assert np.max(np.abs(got_u.astype(np.float64) - ref_u)) <= 1e-37 and np.max(np.abs(got_v.astype(np.float64) - ref_v)) <= 1e-37
+
+
 # ---- in-place row bands of a single slab (cross-pass overlap schedule) --------------------------
 @pytest.mark.parametrize("split", [2, 3, 5])
 def test_single_slab_row_bands_bit_exact(split):
