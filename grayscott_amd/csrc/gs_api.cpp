@@ -458,18 +458,22 @@ int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fu
     const int cpl = pick_cols_per_lane(ctx, rows, cols, fuse);
     const int32_t own = model_rows_per_unit(ctx, rows, cols, fuse, cpl);
     // Several slabs of one process on ONE device share its wave slots: their launches run side by side and
-    // together fill many rounds.  Where a slab alone is too small for a decent unit height in whole rounds
-    // (under 96 rows), the height follows the rows the device holds instead (8 slabs of 2048 x 16384 on one
-    // GPU: 71-76-row units, one round per slab, 865-885 k; 96-128 rows 981-1030 k = 0.95-0.98 of the single
-    // slab; 2 slabs keep their own 142 rows = two rounds each, 1077 k against 1000 k with 122;
-    // profiles/r03_sweeps.md, section 5).
-    if (ctx->slabs.size() > 1 && own < 96 && fuse > 1) {
-        int same = 0;
-        for (const auto &sl : ctx->slabs) same += sl.device == ctx->slabs[0].device;
-        int64_t rows_on_device = (int64_t)rows * same;
-        if (rows_on_device > 0x7fffffff) rows_on_device = 0x7fffffff;
-        const int32_t h = model_rows_per_unit(ctx, (int32_t)rows_on_device, cols, fuse, cpl);
-        if (h > own) return h > rows ? (rows > 0 ? rows : 1) : h;
+    // together fill many rounds.  Where a slab's own height is its ONE-round height (the slab alone does not
+    // fill two rounds), the height follows the rows the device holds instead.  16384^2 as N slabs on one GPU,
+    // own / device-wide height: 8 slabs (76 / 122 rows) 865-885 k / 1000-1030 k = 0.94-0.98 of the single slab,
+    // 4 slabs (152 / 122) 935-970 k / 1007-1015 k; 2 slabs keep their own 142 rows = two rounds each: 1019-1077 k
+    // against 1000-1008 k with 122 (profiles/r03_sweeps.md, section 5).
+    if (ctx->slabs.size() > 1 && fuse > 1) {
+        int fit[2];
+        const int nf = fit_heights(ctx, rows, cols, fuse, cpl, fast_of(ctx), fit, 2);
+        if (nf > 0 && own == fit[0]) {
+            int same = 0;
+            for (const auto &sl : ctx->slabs) same += sl.device == ctx->slabs[0].device;
+            int64_t rows_on_device = (int64_t)rows * same;
+            if (rows_on_device > 0x7fffffff) rows_on_device = 0x7fffffff;
+            const int32_t h = model_rows_per_unit(ctx, (int32_t)rows_on_device, cols, fuse, cpl);
+            return h > rows ? (rows > 0 ? rows : 1) : h;
+        }
     }
     return own;
 }
