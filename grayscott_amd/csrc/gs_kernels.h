@@ -53,6 +53,9 @@ struct GsStepArgs {
     // own whole CUs until all their waves end would keep the boundary-band kernel, the ghost-row copies and
     // RCCL's kernels out until the end of the launch (8 slabs on one GPU: 0.79 instead of 0.88 of one slab).
     int32_t allow_fair;
+    // In-step form: the progress (0 ... 256) from which a wave's priority is steered; before, the waves run as
+    // the arbitration leaves them (filled in by the launcher).
+    int32_t fair_from;
     // Boundary rule on global edges: 0 = naive's clipped window (weights anchored at the window's
     // top-left corner), 1 = full window with zeros outside the grid (gs_boundary in gs_hip.h).
     int32_t zero_halo;

@@ -847,10 +847,12 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                 if constexpr (FAIR) {
                     const int mine = tick * fair_scale >> 16;       // 0 ... 256
                     if (lane == 0) fb.progress[fb.wave] = mine;
-                    const int theirs = fb.progress[lane & 15];
-                    const unsigned long long behind = __builtin_amdgcn_ballot_w64(theirs < mine) & fb.group;
-                    if (behind) __builtin_amdgcn_s_setprio(0);
-                    else __builtin_amdgcn_s_setprio(3);
+                    if (mine >= a.fair_from) { // (before: free-running, out of phase as the arbitration leaves them)
+                        const int theirs = fb.progress[lane & 15];
+                        const unsigned long long behind = __builtin_amdgcn_ballot_w64(theirs < mine) & fb.group;
+                        if (behind) __builtin_amdgcn_s_setprio(0);
+                        else __builtin_amdgcn_s_setprio(3);
+                    }
                 }
                 w[0][s3] = widen_tb<CPL>(q[s3].u, q[s3].v);
                 if constexpr (!LATE) q[s3] = fetch(l0 + 3);
@@ -1631,6 +1633,8 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     static const int fair_env = std::getenv("GS_HIP_FAIR") ? std::atoi(std::getenv("GS_HIP_FAIR")) : -1;
     const bool fair = a.allow_fair && units <= 4096 && units > 1024 && (fair_env < 0 ? (cpl == 2 || rpu >= 20) : fair_env != 0);
     const void *fair_fn = fair ? tb_entry(k, fast, cpl, 16) : nullptr;
+    static const int fair_from_env = std::getenv("GS_HIP_FAIR_FROM") ? std::atoi(std::getenv("GS_HIP_FAIR_FROM")) : -1;
+    args.fair_from = fair_from_env >= 0 ? fair_from_env : 0;
     void *kargs[] = {&args};
     if (fair_fn) {
         if (name) *name = names16[cpl == 1 ? 0 : 1][fast ? 1 : 0];
