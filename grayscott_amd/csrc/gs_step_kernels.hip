@@ -932,7 +932,12 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     // a wave without a unit marks itself finished (never "behind") and leaves
 #define GS_TB_LEAVE do { if constexpr (FAIR) { if (lane == 0) fb.progress[wave] = 0x7fffffff; } return; } while (0)
     const int strips = (a.cols + W - 1) / W;
-    const int unit = blockIdx.x * WG + wave;
+    // Units in dispatch order (edge units first).  4-wave workgroups take four consecutive ones; the dispatcher
+    // deals the workgroups over the CUs.  A 16-wave workgroup takes every gridDim.x-th unit instead: with
+    // consecutive units the first 31 workgroups would hold nothing but edge units, whose half-height general-path
+    // marches are not as long as the interior's (13 ticks x 1.6 against 18 at 10-row units: those CUs end 15 %
+    // late; 27 x 1.57 against 46 at 38 rows: early) -- dealt like this every CU gets its share of them.
+    const int unit = FAIR ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * WG + wave;
     const int rpu = a.rows_per_unit;
     const int small = a.small_rpu;
     const int rest_a = a.ra1 - a.ra0 - a.big_chunks * rpu; // rows of range a behind the full-height chunks
