@@ -739,8 +739,8 @@ __device__ __forceinline__ unsigned long long trace_now()
 // another runs at priority 0, the others at 3, so the four stay within a tick of each other and end together.
 // Nobody ever waits for anybody: the board only steers s_setprio.
 struct FairBoard {
-    int *progress;           // LDS: one word per wave of the workgroup, 0 ... 256, INT_MAX once a wave has finished
-    unsigned long long group; // lanes (= wave indices) of the waves on this wave's SIMD
+    int *progress; // LDS: words 0..15 progress per wave (0 ... 256, INT_MAX once finished), 16..31 the SIMD it runs on
+    int simd;      // this wave's SIMD (HW_REG_HW_ID bits 5:4)
     int wave;
 };
 
@@ -848,8 +848,8 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                     const int mine = tick * fair_scale >> 16;       // 0 ... 256
                     if (lane == 0) fb.progress[fb.wave] = mine;
                     if (mine >= a.fair_from) { // (before: free-running, out of phase as the arbitration leaves them)
-                        const int theirs = fb.progress[lane & 15];
-                        const unsigned long long behind = __builtin_amdgcn_ballot_w64(theirs < mine) & fb.group;
+                        const int theirs = fb.progress[lane & 15], their_simd = fb.progress[16 + (lane & 15)];
+                        const unsigned long long behind = __builtin_amdgcn_ballot_w64(their_simd == fb.simd && theirs < mine);
                         if (behind) __builtin_amdgcn_s_setprio(0);
                         else __builtin_amdgcn_s_setprio(3);
                     }
@@ -918,16 +918,16 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     constexpr bool FAIR = WG == 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, see above
-    FairBoard fb{nullptr, 0ull, wave};
+    FairBoard fb{nullptr, 0, wave};
     if constexpr (FAIR) {
-        // the board: words 0..15 progress, 16..31 the SIMD each wave runs on (HW_REG_HW_ID bits 5:4).  Every
-        // wave passes the barrier before any of them can leave the kernel.
+        // The board.  No barrier: a wave starts marching as soon as it is dispatched (a barrier here held every
+        // wave until the 16th of its workgroup had arrived: -2 ... -7 % on a whole pass).  What a wave reads of a
+        // peer that has not started yet is whatever the previous workgroup left in LDS -- a wrong guess at a
+        // priority for a few ticks, never at a result.
         __shared__ int board[32];
-        const int simd = (int)(__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)));
-        if (lane == 0) { board[wave] = 0; board[16 + wave] = simd; }
-        __syncthreads();
+        fb.simd = (int)(__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)));
+        if (lane == 0) { board[wave] = 0; board[16 + wave] = fb.simd; }
         fb.progress = board;
-        fb.group = __builtin_amdgcn_ballot_w64(lane < 16 && board[16 + (lane & 15)] == simd);
     }
     // a wave without a unit marks itself finished (never "behind") and leaves
 #define GS_TB_LEAVE do { if constexpr (FAIR) { if (lane == 0) fb.progress[wave] = 0x7fffffff; } return; } while (0)
