@@ -928,6 +928,8 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         fb.simd = (int)(__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)));
         if (lane == 0) { board[wave] = 0; board[16 + wave] = fb.simd; }
         fb.progress = board;
+        // experiment (GS_HIP_FAIR_STAGGER): the 2nd, 3rd and 4th wave of a SIMD start 1, 2, 3 x stagger x 0.22 us late
+        for (int i = 0; i < (wave >> 2) * a.fair_stagger; ++i) __builtin_amdgcn_s_sleep(8);
     }
     // a wave without a unit marks itself finished (never "behind") and leaves
 #define GS_TB_LEAVE do { if constexpr (FAIR) { if (lane == 0) fb.progress[wave] = 0x7fffffff; } return; } while (0)
@@ -1640,6 +1642,8 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     const void *fair_fn = fair ? tb_entry(k, fast, cpl, 16) : nullptr;
     static const int fair_from_env = std::getenv("GS_HIP_FAIR_FROM") ? std::atoi(std::getenv("GS_HIP_FAIR_FROM")) : -1;
     args.fair_from = fair_from_env >= 0 ? fair_from_env : 0;
+    static const int fair_stagger_env = std::getenv("GS_HIP_FAIR_STAGGER") ? std::atoi(std::getenv("GS_HIP_FAIR_STAGGER")) : 0;
+    args.fair_stagger = fair_stagger_env;
     void *kargs[] = {&args};
     if (fair_fn) {
         if (name) *name = names16[cpl == 1 ? 0 : 1][fast ? 1 : 0];
