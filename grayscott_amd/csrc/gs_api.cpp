@@ -153,7 +153,6 @@ struct SlabRt {
     hipEvent_t staged = nullptr, copied = nullptr; // asynchronous downloads
     float *stage = nullptr;                        // dense device staging buffer
     size_t stage_floats = 0;
-    int32_t *board = nullptr;                      // GsStepArgs::board of this slab's device
     // gs_ctx_set_pass_timing: per timed pass, events around the halo stream's work (boundary-band kernel +
     // ghost-row exchange: th0, th1) and around the interior kernel on the compute stream (tc0, tc1)
     std::vector<hipEvent_t> th0, th1, tc0, tc1;
@@ -560,7 +559,6 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
     a.rows_per_unit = pick_rows_per_unit(ctx, a.rows, a.cols, fuse);
     a.cpl = pick_cols_per_lane(ctx, a.rows, a.cols, fuse);
     a.allow_fair = ctx->total_slabs() == 1;
-    a.board = ctx->slabs[i].board;
     a.zero_halo = ctx->o.boundary == GS_BOUNDARY_ZERO_HALO;
     std::memcpy(a.w, ctx->p.w, sizeof a.w);
     a.du = ctx->p.du;
@@ -1303,7 +1301,6 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
                 if (e) (void)hipEventDestroy(e);
         if (sl.copy) { (void)hipStreamSynchronize(sl.copy); (void)hipStreamDestroy(sl.copy); }
         if (sl.stage) (void)hipFree(sl.stage);
-        if (sl.board) (void)hipFree(sl.board);
         if (sl.halo) (void)hipStreamDestroy(sl.halo);
         if (sl.compute) (void)hipStreamDestroy(sl.compute);
     }
@@ -1402,8 +1399,6 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
         }
         GS_HIP_B(hipEventCreate(&sl.t0));
         GS_HIP_B(hipEventCreate(&sl.t1));
-        GS_HIP_B(hipMalloc(reinterpret_cast<void **>(&sl.board), (size_t)kGsBoardWords * sizeof(int32_t)));
-        GS_HIP_B(hipMemset(sl.board, 0x7f, (size_t)kGsBoardWords * sizeof(int32_t)));
     }
     // Peer access between neighbouring local slabs on different devices (best effort: the
     // copies fall back to staged transfers when it is unavailable).

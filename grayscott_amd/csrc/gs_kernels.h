@@ -11,8 +11,6 @@
 // Largest grid (cells) gs_launch_resident_* takes (4 planes of (rows + 2) x (cols + 2) floats in LDS: at most
 // 74 KB).  Above, the LDS-window kernel with its many workgroups is faster (profiles/r02_sweeps.md, section 10).
 constexpr int kGsResidentCells = 1536;
-// Words of GsStepArgs::board: 8 XCCs x 8 SEs x 2 SHs x 16 CUs (the hardware id fields, sparse) x 4 SIMDs x 8 wave slots.
-constexpr int kGsBoardWords = 8 * 8 * 2 * 16 * 4 * 8;
 // gs_launch_tile_*: the most time steps one launch advances its tiles by.
 constexpr int kGsTileMaxSteps = 8;
 
@@ -58,10 +56,6 @@ struct GsStepArgs {
     // In-step form: the progress (0 ... 256) from which a wave's priority is steered; before, the waves run as
     // the arbitration leaves them (filled in by the launcher).
     int32_t fair_from;
-    int32_t fair_stagger; // experiment: start offset between the waves of a SIMD, in units of 512 cycles
-    // Progress board of the 4-wave in-step form: kGsBoardWords ints in device memory, 8 per SIMD (one per wave
-    // slot), indexed by the hardware ids of the CU; 0x7f7f7f7f-filled at creation ("finished").
-    int32_t *board;
     // Boundary rule on global edges: 0 = naive's clipped window (weights anchored at the window's
     // top-left corner), 1 = full window with zeros outside the grid (gs_boundary in gs_hip.h).
     int32_t zero_halo;

@@ -742,13 +742,9 @@ struct FairBoard {
     int *progress; // LDS: words 0..15 progress per wave (0 ... 256, INT_MAX once finished), 16..31 the SIMD it runs on
     int simd;      // this wave's SIMD (HW_REG_HW_ID bits 5:4)
     int wave;
-    // the board in global memory (4-wave workgroups: the waves of a SIMD belong to different workgroups):
-    // 8 words per SIMD, one per wave slot; `soff` = byte offset of this SIMD's words, `slot` = this wave's word
-    __amdgpu_buffer_rsrc_t rsrc;
-    int soff, slot;
 };
 
-template <int K, bool EDGE, int FAST, int CPL, int ZH = -1, int FAIR = 0>
+template <int K, bool EDGE, int FAST, int CPL, int ZH = -1, bool FAIR = false>
 __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, int strip, int lane,
                                          const FairBoard &fb
 #if defined(GS_TB_TRACE)
@@ -830,8 +826,6 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
     const int first = ur0 - K; // level-0 row of tick 0
     const int nticks = (ur1 - ur0) + 2 * K;
     const int fair_scale = FAIR ? (256 << 16) / nticks : 0;
-    int fair_theirs = 0x7fffffff, fair_mine = 0;
-    (void)fair_theirs; (void)fair_mine;
 #pragma unroll
     for (int i = 0; i < 3; ++i) q[i] = fetch(first + i);
 #pragma unroll
@@ -850,7 +844,7 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                 GS_TRACE_AT(tick == 3, 1);
                 GS_TRACE_AT(tick == 2 * K, 2);
                 GS_TRACE_AT(tick == nticks - 2 * K, 3);
-                if constexpr (FAIR == 1) {
+                if constexpr (FAIR) {
                     const int mine = tick * fair_scale >> 16;       // 0 ... 256
                     if (lane == 0) fb.progress[fb.wave] = mine;
                     if (mine >= a.fair_from) { // (before: free-running, out of phase as the arbitration leaves them)
@@ -859,14 +853,6 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                         if (behind) __builtin_amdgcn_s_setprio(0);
                         else __builtin_amdgcn_s_setprio(3);
                     }
-                }
-                if constexpr (FAIR == 2) {
-                    // the same through memory: publish, and ask for the eight words of this SIMD (sc1: past the L1);
-                    // the answer is read at the end of the tick, behind the tick's arithmetic
-                    const int mine = tick * fair_scale >> 16;
-                    if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(mine, fb.rsrc, fb.slot, fb.soff, 16);
-                    fair_theirs = __builtin_amdgcn_raw_buffer_load_b32(fb.rsrc, (lane & 7) * 4, fb.soff, 16);
-                    fair_mine = mine;
                 }
                 w[0][s3] = widen_tb<CPL>(q[s3].u, q[s3].v);
                 if constexpr (!LATE) q[s3] = fetch(l0 + 3);
@@ -915,45 +901,25 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                         }
                     }
                 }
-                if constexpr (FAIR == 2) {
-                    if (fair_mine >= a.fair_from) {
-                        const unsigned long long behind = __builtin_amdgcn_ballot_w64(fair_theirs < fair_mine);
-                        if (behind) __builtin_amdgcn_s_setprio(0);
-                        else __builtin_amdgcn_s_setprio(3);
-                    }
-                }
                 if constexpr (LATE) q[s3] = fetch(l0 + 3); // two rows in flight while the levels are computed
             }
         }
     }
 }
 
-// MODE: 4 = workgroups of 4 independent waves; 16 = all 16 waves of a CU in one workgroup, kept in step through a
-// progress board in LDS (tb_march<FAIR = 1>); 2 = workgroups of 4 waves kept in step through a board in global
-// memory (FAIR = 2: the waves of a SIMD belong to different workgroups and share no LDS).
-template <int K, int FAST, int CPL, int MODE = 4>
-__global__ __launch_bounds__((MODE == 16 ? 16 : 4) * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
+// WG: waves per workgroup.  4 independent waves, or all 16 of a CU with the progress board of tb_march<FAIR>.
+template <int K, int FAST, int CPL, int WG = 4>
+__global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
 {
-    constexpr int WG = MODE == 16 ? 16 : 4;
     // half_diff needs MODE.IEEE = 0: hwreg(HW_REG_MODE, offset 9, width 1).  The bit only governs
     // the quieting of signalling NaNs otherwise, which parity does not cover.
     if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0);
     constexpr int W = tb_cols_per_wave(K, CPL), S = tb_sacrificial_lanes(K, CPL);
-    constexpr int FAIR = MODE == 16 ? 1 : (MODE == 2 ? 2 : 0);
+    constexpr bool FAIR = WG == 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, see above
-    FairBoard fb{nullptr, 0, wave, plane_rsrc(nullptr), 0, 0};
-    if constexpr (FAIR == 2) {
-        // HW_REG_HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]; HW_REG_XCC_ID [2:0]
-        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11));
-        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (2 << 11));
-        const unsigned cu = (((xcc & 7) * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 15);
-        fb.rsrc = plane_rsrc(reinterpret_cast<const float *>(a.board));
-        fb.soff = (int)((cu * 4 + ((hw >> 4) & 3)) * 8 * sizeof(int));
-        fb.slot = (int)((hw & 7) * sizeof(int));
-        if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(0, fb.rsrc, fb.slot, fb.soff, 16);
-    }
-    if constexpr (FAIR == 1) {
+    FairBoard fb{nullptr, 0, wave};
+    if constexpr (FAIR) {
         // The board.  No barrier: a wave starts marching as soon as it is dispatched (a barrier here held every
         // wave until the 16th of its workgroup had arrived: -2 ... -7 % on a whole pass).  What a wave reads of a
         // peer that has not started yet is whatever the previous workgroup left in LDS -- a wrong guess at a
@@ -962,22 +928,17 @@ __global__ __launch_bounds__((MODE == 16 ? 16 : 4) * 64) void GS_SUFFIX(gs_step_
         fb.simd = (int)(__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)));
         if (lane == 0) { board[wave] = 0; board[16 + wave] = fb.simd; }
         fb.progress = board;
-        // experiment (GS_HIP_FAIR_STAGGER): the 2nd, 3rd and 4th wave of a SIMD start 1, 2, 3 x stagger x 0.22 us late
-        for (int i = 0; i < (wave >> 2) * a.fair_stagger; ++i) __builtin_amdgcn_s_sleep(8);
     }
     // a wave without a unit marks itself finished (never "behind") and leaves
-#define GS_TB_FINISHED do {                                                                                  \
-        if constexpr (FAIR == 1) { if (lane == 0) fb.progress[wave] = 0x7fffffff; }                            \
-        if constexpr (FAIR == 2) { if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(0x7fffffff, fb.rsrc, fb.slot, fb.soff, 16); } \
-    } while (0)
-#define GS_TB_LEAVE do { GS_TB_FINISHED; return; } while (0)
+#define GS_TB_LEAVE do { if constexpr (FAIR) { if (lane == 0) fb.progress[wave] = 0x7fffffff; } return; } while (0)
     const int strips = (a.cols + W - 1) / W;
     // Units in dispatch order (edge units first).  4-wave workgroups take four consecutive ones; the dispatcher
-    // deals the workgroups over the CUs.  A 16-wave workgroup takes every gridDim.x-th unit instead: with
-    // consecutive units the first 31 workgroups would hold nothing but edge units, whose half-height general-path
-    // marches are not as long as the interior's (13 ticks x 1.6 against 18 at 10-row units: those CUs end 15 %
-    // late; 27 x 1.57 against 46 at 38 rows: early) -- dealt like this every CU gets its share of them.
-    const int unit = FAIR == 1 ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * WG + wave;
+    // deals the workgroups over the CUs.  A 16-wave workgroup of the 1-column layout takes every gridDim.x-th unit
+    // instead: with consecutive units the first 31 workgroups would hold nothing but edge units, whose half-height
+    // general-path marches are longer than the interior's when units are short (13 ticks x 1.6 against 18 at
+    // 10-row units: those CUs end 15 % late; 390 k -> 419 k).  With 2 columns per lane the edge halves are the
+    // shorter ones (27 x 1.57 against 46 ticks at 38 rows) and 16 neighbouring strips on one CU read 1 % faster.
+    const int unit = FAIR && CPL == 1 ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * WG + wave;
     const int rpu = a.rows_per_unit;
     const int small = a.small_rpu;
     const int rest_a = a.ra1 - a.ra0 - a.big_chunks * rpu; // rows of range a behind the full-height chunks
@@ -1063,9 +1024,8 @@ __global__ __launch_bounds__((MODE == 16 ? 16 : 4) * 64) void GS_SUFFIX(gs_step_
     else
         tb_march<K, true, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
 #undef GS_TRACE_ARG
-    GS_TB_FINISHED;
+    if constexpr (FAIR) { if (lane == 0) fb.progress[wave] = 0x7fffffff; }
 #undef GS_TB_LEAVE
-#undef GS_TB_FINISHED
 #if defined(GS_TB_TRACE)
     ts[4] = trace_now();
     if (lane == 0 && unit < kTraceUnits) {
@@ -1504,18 +1464,15 @@ static const void *tb_entry(int k, int fast, int cpl, int wg = 4)
     const void *fn = nullptr;
 #define GS_TB_CASE(KK, CC)                                                                      \
     case (KK) * 8 + (CC): fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<KK, 0, CC>); break;
-    if (wg == 16 || wg == 2) { // the in-step forms: 4 fused steps, 1 or 2 columns per lane (128 registers at most)
+    if (wg == 16) { // the fair-progress form: 4 fused steps, 1 or 2 columns per lane (128 registers at most)
         if (k != 4 || (cpl != 1 && cpl != 2)) return nullptr;
         if (fast) {
 #if !GS_MATH_FUSED
-            return gs_tb_op_kernel_strict(k, fast, cpl, wg);
+            return gs_tb_op_kernel_strict(k, fast, cpl, 16);
 #endif
         }
-        if (wg == 16)
-            return cpl == 1 ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 0, 1, 16>)
-                            : reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 0, 2, 16>);
-        return cpl == 1 ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 0, 1, 2>)
-                        : reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 0, 2, 2>);
+        return cpl == 1 ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 0, 1, 16>)
+                        : reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 0, 2, 16>);
     }
     if (fast) {
 #if !GS_MATH_FUSED
@@ -1588,9 +1545,6 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // "f": the fair-progress form (16-wave workgroups) of one-round launches
     static const char *const names16[2][2] = {{"tb-k4c1f/" GS_MATH_NAME, "tb-k4c1f/" GS_MATH_NAME ".op"},
                                               {"tb-k4c2f/" GS_MATH_NAME, "tb-k4c2f/" GS_MATH_NAME ".op"}};
-    // "g": in step through the board in global memory (4-wave workgroups)
-    static const char *const names2[2][2] = {{"tb-k4c1g/" GS_MATH_NAME, "tb-k4c1g/" GS_MATH_NAME ".op"},
-                                             {"tb-k4c2g/" GS_MATH_NAME, "tb-k4c2g/" GS_MATH_NAME ".op"}};
     if (k < 1 || k > 4 || a.cols <= 0 || a.rows_per_unit <= 0) return hipErrorInvalidValue;
     const int cpl = a.cpl == 0 ? 4 : a.cpl;
     if (cpl != 1 && cpl != 2 && cpl != 4) return hipErrorInvalidValue;
@@ -1684,21 +1638,13 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // GS_HIP_FAIR = 0 / 1 forces it off / on.
     static const int fair_env = std::getenv("GS_HIP_FAIR") ? std::atoi(std::getenv("GS_HIP_FAIR")) : -1;
     const bool fair = a.allow_fair && units <= 4096 && units > 1024 && (fair_env < 0 ? (cpl == 2 || rpu >= 20) : fair_env != 0);
-    // GS_HIP_FAIR = 2: the 4-wave-workgroup form with the board in global memory (needs GsStepArgs::board)
-    const int fair_mode = fair_env == 2 && a.board ? 2 : 16;
-    const void *fair_fn = fair ? tb_entry(k, fast, cpl, fair_mode) : nullptr;
+    const void *fair_fn = fair ? tb_entry(k, fast, cpl, 16) : nullptr;
     static const int fair_from_env = std::getenv("GS_HIP_FAIR_FROM") ? std::atoi(std::getenv("GS_HIP_FAIR_FROM")) : -1;
     args.fair_from = fair_from_env >= 0 ? fair_from_env : 0;
-    static const int fair_stagger_env = std::getenv("GS_HIP_FAIR_STAGGER") ? std::atoi(std::getenv("GS_HIP_FAIR_STAGGER")) : 0;
-    args.fair_stagger = fair_stagger_env;
     void *kargs[] = {&args};
-    if (fair_fn && fair_mode == 16) {
+    if (fair_fn) {
         if (name) *name = names16[cpl == 1 ? 0 : 1][fast ? 1 : 0];
         return hipLaunchKernel(fair_fn, dim3((unsigned)((units + 15) / 16)), dim3(1024), kargs, 0, s);
-    }
-    if (fair_fn) {
-        if (name) *name = names2[cpl == 1 ? 0 : 1][fast ? 1 : 0];
-        return hipLaunchKernel(fair_fn, dim3((unsigned)((units + 3) / 4)), dim3(256), kargs, 0, s);
     }
     const long blocks = (units + 3) / 4;
     if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
@@ -1746,12 +1692,13 @@ extern "C" int32_t GS_SUFFIX(gs_debug_trace_read)(unsigned long long *dst, int32
 // and `cpl` columns per lane.
 const void *gs_tb_op_kernel_strict(int k, int fast, int cpl, int wg)
 {
-    if (wg == 16 || wg == 2) {
+    if (wg == 16) {
         if (k != 4 || (cpl != 1 && cpl != 2) || (fast != 1 && fast != 3)) return nullptr;
-#define GS_TB_STEP(FF, CC, MM) reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, FF, CC, MM>)
-        if (wg == 16) return fast == 1 ? (cpl == 1 ? GS_TB_STEP(1, 1, 16) : GS_TB_STEP(1, 2, 16)) : (cpl == 1 ? GS_TB_STEP(3, 1, 16) : GS_TB_STEP(3, 2, 16));
-        return fast == 1 ? (cpl == 1 ? GS_TB_STEP(1, 1, 2) : GS_TB_STEP(1, 2, 2)) : (cpl == 1 ? GS_TB_STEP(3, 1, 2) : GS_TB_STEP(3, 2, 2));
-#undef GS_TB_STEP
+        if (fast == 1)
+            return cpl == 1 ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 1, 1, 16>)
+                            : reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 1, 2, 16>);
+        return cpl == 1 ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 3, 1, 16>)
+                        : reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 3, 2, 16>);
     }
 #define GS_TB_CASE(KK, FF, CC)                                                                  \
     case ((KK) * 4 + (FF)) * 8 + (CC): return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<KK, FF, CC>);

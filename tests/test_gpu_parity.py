@@ -261,8 +261,7 @@ def test_in_step_workgroups_bit_exact(case):
     ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True,
                               boundary=oracle.ZERO_HALO if kw["boundary"] == capi.GS_BOUNDARY_ZERO_HALO else oracle.CLIPPED)
     got_u, got_v, info = gpu_run(u0, v0, steps, params=p, args=args(**kw))
-    # "f": 16-wave workgroups, board in LDS; "g" (GS_HIP_FAIR=2): 4-wave workgroups, board in global memory
-    assert info[0].startswith(("tb-k4c%df/" % case["cpl"], "tb-k4c%dg/" % case["cpl"])), info
+    assert info[0].startswith("tb-k4c%df/" % case["cpl"]), info
     if kw["math"] == capi.GS_MATH_STRICT:
         assert_bits_equal(got_u, ref_u, f"U {case}")
         assert_bits_equal(got_v, ref_v, f"V {case}")
