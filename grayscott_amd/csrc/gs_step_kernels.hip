@@ -915,7 +915,11 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     // the quieting of signalling NaNs otherwise, which parity does not cover.
     if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0);
     constexpr int W = tb_cols_per_wave(K, CPL), S = tb_sacrificial_lanes(K, CPL);
+#if defined(GS_TB_WG16_PLAIN) /* timing experiment: 16-wave workgroups without the board */
+    constexpr bool FAIR = false;
+#else
     constexpr bool FAIR = WG == 16;
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, see above
     FairBoard fb{nullptr, 0, wave};
