@@ -919,6 +919,14 @@ int32_t tune_online(Run &r, int fuse)
     const int dflt = model_rows_per_unit(ctx, (int32_t)f->rows, (int32_t)f->cols, fuse, base_cpl);
     cand.erase(std::remove(cand.begin(), cand.end(), dflt), cand.end());
     cand.push_back(dflt);
+    // ... and, with 2 columns per lane, where it is the height of ONE round of 16-wave workgroups kept in step
+    // (gs_launch_tb): that form is 6-11 % ahead of every other height of such a grid, but two-pass windows of
+    // 20-80 us passes scatter by more than that while the tuning runs inside short calls (the criterion grid's
+    // 16-step calls left 2048 x 4096 on 24-row units, 627 k, where long calls find 19-20 rows, 730 k).
+    int one_round[1] = {0};
+    const bool prefer_model = large || (base_cpl == 2 && fuse == 4 &&
+                                        fit_heights(ctx, (int32_t)f->rows, (int32_t)f->cols, fuse, base_cpl, fast, one_round, 1) == 1 &&
+                                        one_round[0] == dflt);
     const int ncand = (int)cand.size();
     const int nalt = 0; // phase B is empty
     const int nk = ctx->o.fuse_steps == 0 ? (int)(sizeof altk / sizeof altk[0]) : 0;
@@ -1002,7 +1010,7 @@ int32_t tune_online(Run &r, int fuse)
             // (64 or 256 rows, 2-3 % below the plateau, in two of six runs): the model's height, timed last
             // in phase A, wins unless it is 2 % slower than the best of the ladder.
             float margin = t.k < tu->best_k ? 0.97f : (taller ? 0.998f : 0.99f);
-            if (large && t.rpu == dflt && t.cpl == base_cpl && t.k == fuse) margin = 1.02f;
+            if (prefer_model && t.rpu == dflt && t.cpl == base_cpl && t.k == fuse) margin = 1.02f;
             if (tu->best_rpu == 0 || ms < margin * tu->best_ms) {
                 tu->best_ms = ms;
                 tu->best_rpu = t.rpu;
