@@ -1241,15 +1241,39 @@ __device__ __forceinline__ void band_steps(const GsStepArgs &a, float *lds, int 
         for (int b = 0; b < 8; ++b)
             lds[(((b >> 1) * kTileWaves + wave) * 2 + (b & 1)) * P + (lane == 0 ? 1 : 129 + lane)] = 0.0f;
     const int wa = wave > 0 ? wave - 1 : 0, wb = wave < kTileWaves - 1 ? wave + 1 : kTileWaves - 1;
+    // the columns next to a lane's two come from the adjacent lanes by DPP wave shifts: VALU work (two issue
+    // slots each) instead of the LDS crossbar, which 16 waves in lock-step would all want at the same moment
+    // (20 ds_bpermute per wave and step: 0.8 us of crossbar per step and CU, exposed; 3.3 us -> ... per step)
+    auto widen_dpp = [](const float (&cu)[2], const float (&cv)[2]) {
+        RowT<2> w;
+        w.u[1] = cu[0]; w.u[2] = cu[1]; w.v[1] = cv[0]; w.v[2] = cv[1];
+        w.u[0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cu[1]), 0x138, 0xf, 0xf, true));
+        w.u[3] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cu[0]), 0x130, 0xf, 0xf, true));
+        w.v[0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cv[1]), 0x138, 0xf, 0xf, true));
+        w.v[3] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cv[0]), 0x130, 0xf, 0xf, true));
+        return w;
+    };
     for (int s = 1; s <= K; ++s) {
         const int buf = s & 1;
         *reinterpret_cast<float2 *>(row_of(buf, 0, wave, 0)) = make_float2(u[0][0], u[0][1]);
         *reinterpret_cast<float2 *>(row_of(buf, 1, wave, 0)) = make_float2(v[0][0], v[0][1]);
         *reinterpret_cast<float2 *>(row_of(buf, 0, wave, 1)) = make_float2(u[RPW - 1][0], u[RPW - 1][1]);
         *reinterpret_cast<float2 *>(row_of(buf, 1, wave, 1)) = make_float2(v[RPW - 1][0], v[RPW - 1][1]);
-        RowT<2> R[RPW + 2]; // R[0]: the row above the band, R[1 + r]: its row r, R[RPW + 1]: the row below
+        RowT<2> R[RPW + 2]; // R[0]: the row above the band, R[1 + r]: its row r (old values), R[RPW + 1]: the row below
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) R[1 + r] = widen_tb<2>(u[r], v[r]);
+        for (int r = 0; r < RPW; ++r) R[1 + r] = widen_dpp(u[r], v[r]);
+        auto update = [&](int r) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float nu, nv;
+                cell<false, FAST, RowT<2>>(a, R[r], R[r + 1], R[r + 2], 1 + j, true, true, 0u, 0u, nu, nv);
+                u[r][j] = inside[r][j] ? nu : 0.0f;
+                v[r][j] = inside[r][j] ? nv : 0.0f;
+            }
+        };
+        // the rows that need nothing from other waves first: the other waves' rows arrive meanwhile
+#pragma unroll
+        for (int r = 1; r < RPW - 1; ++r) update(r);
         __syncthreads();
         {
             const float *pu = row_of(buf, 0, wa, 1), *pv = row_of(buf, 1, wa, 1);
@@ -1261,15 +1285,8 @@ __device__ __forceinline__ void band_steps(const GsStepArgs &a, float *lds, int 
             R[RPW + 1].u[0] = qu[-1]; R[RPW + 1].u[1] = du.x; R[RPW + 1].u[2] = du.y; R[RPW + 1].u[3] = qu[2];
             R[RPW + 1].v[0] = qv[-1]; R[RPW + 1].v[1] = dv.x; R[RPW + 1].v[2] = dv.y; R[RPW + 1].v[3] = qv[2];
         }
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float nu, nv;
-                cell<false, FAST, RowT<2>>(a, R[r], R[r + 1], R[r + 2], 1 + j, true, true, 0u, 0u, nu, nv);
-                u[r][j] = inside[r][j] ? nu : 0.0f;
-                v[r][j] = inside[r][j] ? nv : 0.0f;
-            }
+        update(0);
+        if (RPW > 1) update(RPW - 1);
     }
 }
 
