@@ -1366,7 +1366,7 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
     if (st == GS_OK && ctx->o.cols_per_lane != 0 && ctx->o.cols_per_lane != 1 && ctx->o.cols_per_lane != 2 &&
         ctx->o.cols_per_lane != 4)
         st = fail(GS_ERR_INVALID, "cols_per_lane must be 0 (auto), 1, 2 or 4, not %d", ctx->o.cols_per_lane);
-    if (st == GS_OK && (ctx->o.tile_shape < 0 || ctx->o.tile_shape > 6))
+    if (st == GS_OK && (ctx->o.tile_shape < 0 || ctx->o.tile_shape > 3))
         st = fail(GS_ERR_INVALID, "tile_shape must be 0 (auto), 1 (32 x 64), 2 (16 x 64) or 3 (64 x 64), not %d", ctx->o.tile_shape);
     if (st == GS_OK && ctx->o.boundary != GS_BOUNDARY_CLIPPED && ctx->o.boundary != GS_BOUNDARY_ZERO_HALO)
         st = fail(GS_ERR_INVALID, "unknown boundary rule %d", ctx->o.boundary);
@@ -1701,8 +1701,8 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
         // window shape (gs_launch_tile): 0 = 32 rows x 64 columns, 1 = 16 x 64, 2 = 64 x 64; steps per launch:
         // 8, or 4 for the 16-row window, whose apron would otherwise outweigh what it produces
         int shape = auto_shape >= 0 ? auto_shape : 0;
-        if (auto_shape < 0 && ctx->o.tile_shape >= 1 && ctx->o.tile_shape <= 6) shape = ctx->o.tile_shape - 1;
-        const int window_rows = shape == 0 ? 32 : (shape == 1 ? 16 : (shape == 2 ? 64 : 16 * shape)); // shapes 3..5: 48, 64, 80 x 128
+        if (auto_shape < 0 && ctx->o.tile_shape >= 1 && ctx->o.tile_shape <= 3) shape = ctx->o.tile_shape - 1;
+        const int window_rows = shape == 0 ? 32 : (shape == 1 ? 16 : 64);
         int kmax = auto_shape >= 0 ? auto_k : (shape == 1 ? 4 : kGsTileMaxSteps);
         if (auto_shape < 0 && ctx->o.fuse_steps > 0)
             kmax = ctx->o.fuse_steps > kGsTileMaxSteps ? kGsTileMaxSteps : ctx->o.fuse_steps;

@@ -1201,139 +1201,6 @@ __global__ __launch_bounds__(kTileWaves * 64) void GS_SUFFIX(gs_run_tile_k)(GsSt
         }
     }
 }
-
-// ------------------------------------------------------------------------------------
-// Wide windows for grids of a few million cells: 16 * RPW rows x 128 columns, two columns per lane.
-//
-// gs_run_tile_k above gives every cell a lane of its own and trades every neighbour through LDS: per step a wave
-// issues 7 LDS operations per cell for 53-63 arithmetic instructions, and the 16 waves of a window alternate
-// between an LDS phase and an arithmetic phase.  Here a wave owns RPW whole rows of 128 columns (10 cells per
-// lane at RPW = 5): the left / right neighbours of its own rows come from the adjacent lanes through the LDS
-// crossbar (ds_bpermute_b32, as in the marching kernel), and only the first and the last row of a wave's band
-// are published in LDS for the waves above and below -- 4 RPW + 16 LDS-pipe operations for 106 RPW arithmetic
-// instructions per step.  One workgroup barrier per step (rows double-buffered by the step's parity).  The ring
-// of cells whose neighbours lie outside the window loses its validity, one ring per step; after K steps the
-// window shrunk by K is exact and is stored, as in gs_run_tile_k.
-// ------------------------------------------------------------------------------------
-constexpr int kBandCols = 128;
-constexpr int kBandPitch = 132; // floats per published row: window column c at index 2 + c, c = -1 ... 128
-__host__ __device__ constexpr int band_rows(int rpw) { return kTileWaves * rpw; }
-// 2 buffers x 2 species x 16 waves x (first row, last row) x pitch
-__host__ __device__ constexpr size_t band_lds_bytes() { return (size_t)2 * 2 * kTileWaves * 2 * kBandPitch * sizeof(float); }
-
-template <int RPW, bool EDGE, int FAST>
-__device__ __forceinline__ void band_steps(const GsStepArgs &a, float *lds, int K, int gr, int gc, int wave, int lane,
-                                           float (&u)[RPW][2], float (&v)[RPW][2])
-{
-    constexpr int P = kBandPitch;
-    // row `which` (0 = first, 1 = last row of a wave's band) of wave w, species sp, buffer buf
-    auto row_of = [&](int buf, int sp, int w, int which) { return lds + ((((buf * 2 + sp) * kTileWaves + w) * 2 + which) * P) + 2 + 2 * lane; };
-    bool inside[RPW][2];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            inside[r][j] = !EDGE || (gr + r >= 0 && gr + r < a.rows && gc + j >= 0 && gc + j < a.cols);
-    // columns -1 and 128 .. 129 of this wave's published rows are never written by a step; they are read
-    // into cells that are discarded, and zeroed once so that nothing depends on earlier contents of the LDS
-    if (lane < 3)
-#pragma unroll
-        for (int b = 0; b < 8; ++b)
-            lds[(((b >> 1) * kTileWaves + wave) * 2 + (b & 1)) * P + (lane == 0 ? 1 : 129 + lane)] = 0.0f;
-    const int wa = wave > 0 ? wave - 1 : 0, wb = wave < kTileWaves - 1 ? wave + 1 : kTileWaves - 1;
-    // the columns next to a lane's two come from the adjacent lanes by DPP wave shifts: VALU work (two issue
-    // slots each) instead of the LDS crossbar, which 16 waves in lock-step would all want at the same moment
-    // (20 ds_bpermute per wave and step: 0.8 us of crossbar per step and CU, exposed; 3.3 us -> ... per step)
-    auto widen_dpp = [](const float (&cu)[2], const float (&cv)[2]) {
-        RowT<2> w;
-        w.u[1] = cu[0]; w.u[2] = cu[1]; w.v[1] = cv[0]; w.v[2] = cv[1];
-        w.u[0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cu[1]), 0x138, 0xf, 0xf, true));
-        w.u[3] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cu[0]), 0x130, 0xf, 0xf, true));
-        w.v[0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cv[1]), 0x138, 0xf, 0xf, true));
-        w.v[3] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cv[0]), 0x130, 0xf, 0xf, true));
-        return w;
-    };
-    for (int s = 1; s <= K; ++s) {
-        const int buf = s & 1;
-        *reinterpret_cast<float2 *>(row_of(buf, 0, wave, 0)) = make_float2(u[0][0], u[0][1]);
-        *reinterpret_cast<float2 *>(row_of(buf, 1, wave, 0)) = make_float2(v[0][0], v[0][1]);
-        *reinterpret_cast<float2 *>(row_of(buf, 0, wave, 1)) = make_float2(u[RPW - 1][0], u[RPW - 1][1]);
-        *reinterpret_cast<float2 *>(row_of(buf, 1, wave, 1)) = make_float2(v[RPW - 1][0], v[RPW - 1][1]);
-        RowT<2> R[RPW + 2]; // R[0]: the row above the band, R[1 + r]: its row r (old values), R[RPW + 1]: the row below
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) R[1 + r] = widen_dpp(u[r], v[r]);
-        auto update = [&](int r) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float nu, nv;
-                cell<false, FAST, RowT<2>>(a, R[r], R[r + 1], R[r + 2], 1 + j, true, true, 0u, 0u, nu, nv);
-                u[r][j] = inside[r][j] ? nu : 0.0f;
-                v[r][j] = inside[r][j] ? nv : 0.0f;
-            }
-        };
-        // the rows that need nothing from other waves first: the other waves' rows arrive meanwhile
-#pragma unroll
-        for (int r = 1; r < RPW - 1; ++r) update(r);
-        __syncthreads();
-        {
-            const float *pu = row_of(buf, 0, wa, 1), *pv = row_of(buf, 1, wa, 1);
-            const float2 cu = *reinterpret_cast<const float2 *>(pu), cv = *reinterpret_cast<const float2 *>(pv);
-            R[0].u[0] = pu[-1]; R[0].u[1] = cu.x; R[0].u[2] = cu.y; R[0].u[3] = pu[2];
-            R[0].v[0] = pv[-1]; R[0].v[1] = cv.x; R[0].v[2] = cv.y; R[0].v[3] = pv[2];
-            const float *qu = row_of(buf, 0, wb, 0), *qv = row_of(buf, 1, wb, 0);
-            const float2 du = *reinterpret_cast<const float2 *>(qu), dv = *reinterpret_cast<const float2 *>(qv);
-            R[RPW + 1].u[0] = qu[-1]; R[RPW + 1].u[1] = du.x; R[RPW + 1].u[2] = du.y; R[RPW + 1].u[3] = qu[2];
-            R[RPW + 1].v[0] = qv[-1]; R[RPW + 1].v[1] = dv.x; R[RPW + 1].v[2] = dv.y; R[RPW + 1].v[3] = qv[2];
-        }
-        update(0);
-        if (RPW > 1) update(RPW - 1);
-    }
-}
-
-// Zero-halo rule only so far (cells outside the grid are zeros and stay zeros: interior code everywhere).
-template <int RPW, int FAST>
-__global__ __launch_bounds__(kTileWaves * 64) void GS_SUFFIX(gs_run_band_k)(GsStepArgs a, int K)
-{
-    if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0); // half_diff: MODE.IEEE = 0
-    extern __shared__ float lds[];
-    constexpr int H = band_rows(RPW);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int HO = H - 2 * K, WO = kBandCols - 2 * K; // output rows / columns per window
-    const int tiles_c = (a.cols + WO - 1) / WO;
-    const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
-    const int gr0 = tr * HO - K, gc0 = tc * WO - K;         // global coordinates of window cell (0, 0)
-    const int gr = gr0 + wave * RPW, gc = gc0 + 2 * lane;   // this lane's first cell
-    float u[RPW][2], v[RPW][2];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool in = gr + r >= 0 && gr + r < a.rows && gc + j >= 0 && gc + j < a.cols;
-            const ptrdiff_t g = (ptrdiff_t)min(max(gr + r, 0), a.rows - 1) * a.pitch + min(max(gc + j, 0), a.cols - 1);
-            u[r][j] = in ? a.in_u[g] : 0.0f;
-            v[r][j] = in ? a.in_v[g] : 0.0f;
-        }
-    const bool edge = gr0 <= 0 || gc0 <= 0 || gr0 + H >= a.rows || gc0 + kBandCols >= a.cols;
-    if (!edge)
-        band_steps<RPW, false, FAST>(a, lds, K, gr, gc, wave, lane, u, v);
-    else
-        band_steps<RPW, true, FAST>(a, lds, K, gr, gc, wave, lane, u, v);
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const int wr = wave * RPW + r;
-        if (wr >= K && wr < H - K && gr + r < a.rows)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int wc = 2 * lane + j;
-                if (wc >= K && wc < kBandCols - K && gc + j < a.cols) {
-                    const ptrdiff_t g = (ptrdiff_t)(gr + r) * a.pitch + gc + j;
-                    a.out_u[g] = u[r][j];
-                    a.out_v[g] = v[r][j];
-                }
-            }
-    }
-}
 #endif // !GS_TB_OP_ONLY
 
 #if !GS_TB_OP_ONLY
@@ -1551,30 +1418,6 @@ hipError_t GS_SUFFIX(gs_launch_tile)(const GsStepArgs &a, int k, int shape, hipS
                                             {"tile16x64/" GS_MATH_NAME, "tile16x64/" GS_MATH_NAME ".op"},
                                             {"tile64x64/" GS_MATH_NAME, "tile64x64/" GS_MATH_NAME ".op"}};
     static const int rpw[3] = {2, 1, 4};
-    if (shape >= 3 && shape <= 5) { // wide windows (gs_run_band_k): 48, 64 or 80 rows x 128 columns; zero-halo rule only
-        static const char *const bnames[3][2] = {{"band48x128/" GS_MATH_NAME, "band48x128/" GS_MATH_NAME ".op"},
-                                                 {"band64x128/" GS_MATH_NAME, "band64x128/" GS_MATH_NAME ".op"},
-                                                 {"band80x128/" GS_MATH_NAME, "band80x128/" GS_MATH_NAME ".op"}};
-        const int brpw = shape;
-        if (a.rows <= 0 || a.cols <= 0 || k < 1 || k > kTileMaxK || a.top_present || a.bottom_present || !a.zero_halo)
-            return hipErrorInvalidValue;
-        int bfast = a.fast & (GS_MATH_FUSED ? 0 : 3);
-        if (bfast != 3) bfast = 0;
-        if (name) *name = bnames[shape - 3][bfast ? 1 : 0];
-        const long bho = band_rows(brpw) - 2 * k, bwo = kBandCols - 2 * k;
-        const long btiles = ((a.rows + bho - 1) / bho) * ((a.cols + bwo - 1) / bwo);
-        if (btiles > 0x7fffffffL) return hipErrorInvalidConfiguration;
-        const void *bfn = nullptr;
-#define GS_BAND_FN(R) (bfast ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_band_k)<R, GS_MATH_FUSED ? 0 : 3>) \
-                             : reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_band_k)<R, 0>))
-        bfn = brpw == 3 ? GS_BAND_FN(3) : (brpw == 4 ? GS_BAND_FN(4) : GS_BAND_FN(5));
-#undef GS_BAND_FN
-        const hipError_t be = ensure_dyn_lds(bfn, band_lds_bytes());
-        if (be != hipSuccess) return be;
-        GsStepArgs bargs = a;
-        void *bkargs[] = {&bargs, &k};
-        return hipLaunchKernel(bfn, dim3((unsigned)btiles), dim3(kTileWaves * 64), bkargs, band_lds_bytes(), s);
-    }
     if (a.rows <= 0 || a.cols <= 0 || k < 1 || k > kTileMaxK || shape < 0 || shape > 2 || a.top_present || a.bottom_present ||
         2 * k >= tile_rows(rpw[shape]))
         return hipErrorInvalidValue;
