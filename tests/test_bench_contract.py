@@ -38,6 +38,16 @@ def test_recorded_bench_line_has_the_contract_keys():
         if r["traffic"]:
             assert abs(r["hbm_physical"] - r["traffic"] / (r["launch_ms"] * 1e-3) / 8e12) < 1e-9 and 0 < r["hbm_physical"] < 1
         assert "value_developed_pattern" in b and 0 < b["value_developed_pattern"] <= 1.05 * b["value"]
+        if "repeats" in b:
+            # round 3 on: `value` is the median of `repeats` timed regions; the developed pattern is the co-headline
+            # with a roofline of its own; the counters name the layout they were profiled with
+            assert b["repeats"] >= 5 and b["value_min"] <= b["value"] <= b["value_max"]
+            d = b["developed_pattern"]
+            assert d["value"] == b["value_developed_pattern"] and d["repeats"] >= 5 and d["value_min"] <= d["value"] <= d["value_max"]
+            assert d["roofline"]["bound"] == r["bound"] and 0 < d["roofline"]["frac"] < r["frac"] + 0.05
+            assert r["frac_source"] and (r["counters_layout"] is None or r["counters_layout"]["rows_per_unit"] > 0)
+            assert r["profile_launch_ms"] is None or 0.8 < r["profile_launch_ms"] / r["launch_ms"] < 1.25
+            assert b["config"]["grid"] == [16384, 16384] and b["config"]["tuned"]["rows_per_unit"] > 0
     else:  # round 1 format
         assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
