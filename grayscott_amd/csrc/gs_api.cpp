@@ -559,6 +559,8 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
     a.rows_per_unit = pick_rows_per_unit(ctx, a.rows, a.cols, fuse);
     a.cpl = pick_cols_per_lane(ctx, a.rows, a.cols, fuse);
     a.allow_fair = ctx->total_slabs() == 1;
+    static const bool edge_kinds = !(std::getenv("GS_HIP_EDGE_KINDS") && std::atoi(std::getenv("GS_HIP_EDGE_KINDS")) == 0);
+    a.edge_kinds = edge_kinds;
     a.zero_halo = ctx->o.boundary == GS_BOUNDARY_ZERO_HALO;
     std::memcpy(a.w, ctx->p.w, sizeof a.w);
     a.du = ctx->p.du;

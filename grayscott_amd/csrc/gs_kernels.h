@@ -53,6 +53,9 @@ struct GsStepArgs {
     // own whole CUs until all their waves end would keep the boundary-band kernel, the ghost-row copies and
     // RCCL's kernels out until the end of the launch (8 slabs on one GPU: 0.79 instead of 0.88 of one slab).
     int32_t allow_fair;
+    // 1 = edge units of the temporal-blocking kernel take the cheap kinds of edge path where one applies
+    // (gs_step_tb_k); 0 = the general path for all of them (GS_HIP_EDGE_KINDS=0, A/B timing).  Same results.
+    int32_t edge_kinds;
     // In-step form: the progress (0 ... 256) from which a wave's priority is steered; before, the waves run as
     // the arbitration leaves them (filled in by the launcher).
     int32_t fair_from;

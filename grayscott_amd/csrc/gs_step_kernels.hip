@@ -233,14 +233,49 @@ __device__ __forceinline__ RowW widen(const RowIn &r)
 // halo.  The temporally blocked kernel branches on the rule ONCE per unit and instantiates both: with
 // a run-time test inside the cell the compiler hoists the other rule's selects above the branch
 // (speculative execution) and every edge cell pays for both rules.
-template <bool EDGE, int FAST = 0, typename Row = RowW, int ZH = -1>
+// EDGE: 0 = interior; 1 = general (any window clipping, per-tap selects); 2 / 3 = a cell of a strip on the grid's
+// LEFT / RIGHT edge whose rows above and below exist, clipped rule, FAST & 1 (side weights 0.5), strict build:
+// the reference's fold over the clipped window, whose weight table is anchored at the window's corner, IS the
+// interior fold over substituted operands, and a substituted centre value contributes w * (u - u) = +0:
+//   right edge (window columns c-1, c): the three right-hand operands := u;
+//   left edge  (window columns c, c+1, weights shifted by one column): (left, centre, right) operands :=
+//     (column c, column c+1, u) in the rows above and below; in the cell's own row (u, column c+1, u), where the
+//     middle one meets the table's centre weight w[1][1] (0 in every stencil of the reference; the tap is
+//     issued, so that a non-finite neighbour spreads as it does there).
+// 6 (right) or 18 (left, first cell of a lane only) selects on top of the interior's 53 instructions, where the
+// general path needs 83: the edge strips -- 8 % of the units of a 4096^2 launch -- cost 1.1-1.2x an interior
+// strip instead of 1.57x.
+template <int EDGE, int FAST = 0, typename Row = RowW, int ZH = -1>
 __device__ __forceinline__ void cell(const GsStepArgs &a, const Row &m, const Row &z,
                                      const Row &p, int k, bool mrow, bool prow, uint32_t la, uint32_t ra,
                                      float &out_u, float &out_v)
 {
     const float u = z.u[k], v = z.v[k];
     float acc_u = 0.0f, acc_v = 0.0f;
-    if (!EDGE && (FAST & 1) && !GS_MATH_FUSED) {
+    if constexpr ((EDGE == 2 || EDGE == 3) && (FAST & 1) && !GS_MATH_FUSED) {
+        const bool L = EDGE == 2 && k == 1 && la != 0u; // only the first cell of a lane can sit on column 0
+        const bool R = EDGE == 3 && ra != 0u;
+        auto pick = [](bool c, float x, float y) { return c ? x : y; };
+        const float tlu = EDGE == 2 && k == 1 ? pick(L, m.u[k], m.u[k - 1]) : m.u[k - 1], tlv = EDGE == 2 && k == 1 ? pick(L, m.v[k], m.v[k - 1]) : m.v[k - 1];
+        const float tu = EDGE == 2 && k == 1 ? pick(L, m.u[k + 1], m.u[k]) : m.u[k], tv = EDGE == 2 && k == 1 ? pick(L, m.v[k + 1], m.v[k]) : m.v[k];
+        const float tru = pick(L || R, u, m.u[k + 1]), trv = pick(L || R, v, m.v[k + 1]);
+        const float lu = pick(L, u, z.u[k - 1]), lv = pick(L, v, z.v[k - 1]);
+        const float ru = pick(L || R, u, z.u[k + 1]), rv = pick(L || R, v, z.v[k + 1]);
+        const float blu = EDGE == 2 && k == 1 ? pick(L, p.u[k], p.u[k - 1]) : p.u[k - 1], blv = EDGE == 2 && k == 1 ? pick(L, p.v[k], p.v[k - 1]) : p.v[k - 1];
+        const float bu = EDGE == 2 && k == 1 ? pick(L, p.u[k + 1], p.u[k]) : p.u[k], bv = EDGE == 2 && k == 1 ? pick(L, p.v[k + 1], p.v[k]) : p.v[k];
+        const float bru = pick(L || R, u, p.u[k + 1]), brv = pick(L || R, v, p.v[k + 1]);
+        GS_TAP(acc_u, a.w[0][0], tlu, u); GS_TAP(acc_v, a.w[0][0], tlv, v);
+        GS_TAP_HALF(acc_u, tu, u);        GS_TAP_HALF(acc_v, tv, v);
+        GS_TAP(acc_u, a.w[0][2], tru, u); GS_TAP(acc_v, a.w[0][2], trv, v);
+        GS_TAP_HALF(acc_u, lu, u);        GS_TAP_HALF(acc_v, lv, v);
+        if (EDGE == 2 && k == 1) { // the table's centre weight on column c + 1 (left-edge lane), on the centre (+0) elsewhere
+            GS_TAP(acc_u, a.w[1][1], pick(L, z.u[k + 1], u), u); GS_TAP(acc_v, a.w[1][1], pick(L, z.v[k + 1], v), v);
+        }
+        GS_TAP_HALF(acc_u, ru, u);        GS_TAP_HALF(acc_v, rv, v);
+        GS_TAP(acc_u, a.w[2][0], blu, u); GS_TAP(acc_v, a.w[2][0], blv, v);
+        GS_TAP_HALF(acc_u, bu, u);        GS_TAP_HALF(acc_v, bv, v);
+        GS_TAP(acc_u, a.w[2][2], bru, u); GS_TAP(acc_v, a.w[2][2], brv, v);
+    } else if (!EDGE && (FAST & 1) && !GS_MATH_FUSED) {
         GS_TAP(acc_u, a.w[0][0], m.u[k - 1], u); GS_TAP(acc_v, a.w[0][0], m.v[k - 1], v);
         GS_TAP_HALF(acc_u, m.u[k], u);           GS_TAP_HALF(acc_v, m.v[k], v);
         GS_TAP(acc_u, a.w[0][2], m.u[k + 1], u); GS_TAP(acc_v, a.w[0][2], m.v[k + 1], v);
@@ -744,7 +779,10 @@ struct FairBoard {
     int wave;
 };
 
-template <int K, bool EDGE, int FAST, int CPL, int ZH = -1, bool FAIR = false>
+// EDGE: 0 = interior unit; 1 = general path; 2 / 3 = strip on the grid's left / right edge that touches neither its
+// top nor its bottom (cell<2> / cell<3>); 4 = interior strip that touches the top or bottom edge: interior code for
+// every row but the grid's first / last, which take the general cell (wave-uniform branch per level-row).
+template <int K, int EDGE, int FAST, int CPL, int ZH = -1, bool FAIR = false>
 __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, int strip, int lane,
                                          const FairBoard &fb
 #if defined(GS_TB_TRACE)
@@ -754,8 +792,10 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
 {
     constexpr int S = tb_sacrificial_lanes(K, CPL), W = tb_cols_per_wave(K, CPL);
     const int c = strip * W + (lane - S) * CPL; // first column of this lane (may be negative)
-    const bool load_ok = !EDGE || (c >= 0 && c < a.pitch);
-    const bool store_ok = (lane >= S) && (lane < 64 - S) && (!EDGE || c < a.pitch);
+    constexpr bool COLS = EDGE == 1 || EDGE == 2 || EDGE == 3; // the strip may leave the grid's columns
+    constexpr bool ROWS = EDGE == 1 || EDGE == 4;              // the unit may touch the grid's first / last row
+    const bool load_ok = !COLS || (c >= 0 && c < a.pitch);
+    const bool store_ok = (lane >= S) && (lane < 64 - S) && (!COLS || c < a.pitch);
     const ptrdiff_t pitch = a.pitch;
 #if !GS_TB_BUFFER_OPS
     const float *bu = a.in_u + c, *bv = a.in_v + c;
@@ -817,8 +857,8 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
         // v_cndmask_b32.  Round 1 kept opaque all-ones / all-zeros words in VGPRs and blended bitwise
         // (v_cndmask is ~10x a plain VALU op on gfx950), which made the edge units 0.5 % of a pass
         // faster -- and cost the 3 registers that kept the whole kernel at 3 waves per SIMD.
-        la[k] = (EDGE && k == 0 && c == 0) ? 0xffffffffu : 0u;
-        ra[k] = (EDGE && (c + k + 1 >= a.cols)) ? 0xffffffffu : 0u;
+        la[k] = ((EDGE == 1 || EDGE == 2) && k == 0 && c == 0) ? 0xffffffffu : 0u;
+        ra[k] = ((EDGE == 1 || EDGE == 3) && (c + k + 1 >= a.cols)) ? 0xffffffffu : 0u;
     }
 
     RowT<CPL> w[K][3]; // w[j][slot]: level-j rows, newest in slot (tick % 3)
@@ -861,21 +901,31 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                     const int row = l0 - j; // level-j row produced in this tick
                     // needed for this unit's outputs, and a row of the global grid?
                     const bool need = (row >= ur0 - (K - j)) && (row < ur1 + (K - j)) &&
-                                      (!EDGE || ((row >= 0 || a.top_present) && (row < a.rows || a.bottom_present)));
+                                      (!ROWS || ((row >= 0 || a.top_present) && (row < a.rows || a.bottom_present)));
                     if (need) {
                         const RowT<CPL> &m = w[j - 1][(s3 + 1) % 3]; // row - 1
                         const RowT<CPL> &z = w[j - 1][(s3 + 2) % 3]; // row
                         const RowT<CPL> &p = w[j - 1][s3];           // row + 1
-                        const bool mrow = !EDGE || (row > 0) || a.top_present;
-                        const bool prow = !EDGE || (row + 1 < a.rows) || a.bottom_present;
+                        const bool mrow = !ROWS || (row > 0) || a.top_present;
+                        const bool prow = !ROWS || (row + 1 < a.rows) || a.bottom_present;
                         float nu[CPL], nv[CPL];
 #if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 2 /* experiment: no arithmetic (memory-only timing) */
 #pragma unroll
                         for (int k = 0; k < CPL; ++k) { nu[k] = z.u[k + 1] + m.u[k]; nv[k] = z.v[k + 1] + p.v[k + 2]; }
 #else
+                        if constexpr (EDGE == 4) {
+                            if (mrow && prow) {
 #pragma unroll
-                        for (int k = 0; k < CPL; ++k)
-                            cell<EDGE, FAST, RowT<CPL>, ZH>(a, m, z, p, k + 1, mrow, prow, la[k], ra[k], nu[k], nv[k]);
+                                for (int k = 0; k < CPL; ++k) cell<0, FAST, RowT<CPL>, ZH>(a, m, z, p, k + 1, true, true, 0u, 0u, nu[k], nv[k]);
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < CPL; ++k) cell<1, FAST, RowT<CPL>, ZH>(a, m, z, p, k + 1, mrow, prow, 0u, 0u, nu[k], nv[k]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < CPL; ++k)
+                                cell<EDGE, FAST, RowT<CPL>, ZH>(a, m, z, p, k + 1, mrow, prow, la[k], ra[k], nu[k], nv[k]);
+                        }
 #endif
 #if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 1
                         if (j < K) {
@@ -1013,20 +1063,33 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         else ur0 = ur0 + hh;
         if (ur0 >= ur1) GS_TB_LEAVE; // a one-row chunk has no second half (wave-uniform)
     }
-    const bool edge = (strip == 0) || ((strip + 1) * W + S * CPL >= a.cols) ||
-                      (ur0 - K < 0 && !a.top_present) || (ur1 + K > a.rows && !a.bottom_present);
+    const bool left = strip == 0, right = (strip + 1) * W + S * CPL >= a.cols;
+    const bool ends = (ur0 - K < 0 && !a.top_present) || (ur1 + K > a.rows && !a.bottom_present);
+    const bool edge = left || right || ends;
 #if defined(GS_TB_TRACE)
     unsigned long long ts[5] = {trace_now(), 0, 0, 0, 0};
 #define GS_TRACE_ARG , ts
 #else
 #define GS_TRACE_ARG
 #endif
+    // One branch per unit (all of it wave-uniform), one instantiation per kind of unit and boundary rule: with a
+    // run-time test inside the cell the compiler hoists the other kinds' selects above the branch.  The cheap edge
+    // kinds (cell<2>, cell<3>, EDGE = 4) exist for the clipped rule with the default side weights in the strict
+    // build; every other combination -- corners, a grid narrower than two strips, the zero-halo rule, general
+    // weights -- takes the general path.  GsStepArgs::edge_kinds = 0 sends every edge unit there (A/B timing).
+    constexpr bool KINDS = (FAST & 1) && !GS_MATH_FUSED;
     if (!edge)
-        tb_march<K, false, FAST, CPL, -1, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
-    else if (a.zero_halo) // one branch per unit, one instantiation per boundary rule (see cell<>)
-        tb_march<K, true, FAST, CPL, 1, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
+        tb_march<K, 0, FAST, CPL, -1, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
+    else if (a.zero_halo)
+        tb_march<K, 1, FAST, CPL, 1, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
+    else if (KINDS && a.edge_kinds && left && !right && !ends)
+        tb_march<K, KINDS ? 2 : 1, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
+    else if (KINDS && a.edge_kinds && right && !left && !ends)
+        tb_march<K, KINDS ? 3 : 1, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
+    else if (KINDS && a.edge_kinds && ends && !left && !right)
+        tb_march<K, KINDS ? 4 : 1, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
     else
-        tb_march<K, true, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
+        tb_march<K, 1, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
 #undef GS_TRACE_ARG
     if constexpr (FAIR) { if (lane == 0) fb.progress[wave] = 0x7fffffff; }
 #undef GS_TB_LEAVE
