@@ -403,15 +403,6 @@ int fit_heights(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse, int cpl
             if (out[i] == (int)h) return;
         if (n < max) out[n++] = (int)h;
     };
-    // On a context that has the GPU to itself a launch of one round runs as 16-wave workgroups whose waves keep
-    // step, with unit heights per kind of strip (gs_launch_tb, tb_fair_plan): the smallest interior height that
-    // fits the round comes first.
-    if (ctx->total_slabs() == 1 && fuse == 4) {
-        const int zh = ctx->o.boundary == GS_BOUNDARY_ZERO_HALO;
-        const int h = ctx->o.math == GS_MATH_FUSED ? gs_tb_fair_height_fused(rows, cols, fuse, fast, cpl, zh)
-                                                   : gs_tb_fair_height_strict(rows, cols, fuse, fast, cpl, zh);
-        if (h >= 2 && (cpl == 2 || h >= 20)) push(h);
-    }
     // A launch of at most one round dispatches its edge units -- up to 3 strips of every chunk, all strips of
     // the top and bottom chunk rows -- as two halves each (gs_launch_tb): count them.  `partial`: also the
     // heights that leave every SIMD w = waves - 1, ..., 1 waves instead of a full round (1080 x 1920, 1 column
@@ -498,15 +489,6 @@ int32_t model_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int f
         // single-round height.
         int fit[8];
         const int nf = fit_heights(ctx, rows, cols, fuse, cpl, fast_of(ctx), fit, 8);
-        // ... but ONE round of in-step workgroups wherever that means units of 16 to 128 rows (grids of about
-        // 4 to 60 M cells on a single slab): 6-11 % ahead of every multi-round height there, level with them at
-        // 8192^2 (146 rows) and behind at 16384^2 (profiles/r03_sweeps.md, section 2).  fit_heights lists it first.
-        if (nf > 0 && ctx->total_slabs() == 1 && fuse == 4 && fit[0] >= 16 && fit[0] <= 128) {
-            const int zh = ctx->o.boundary == GS_BOUNDARY_ZERO_HALO;
-            const int h = ctx->o.math == GS_MATH_FUSED ? gs_tb_fair_height_fused(rows, cols, fuse, fast_of(ctx), cpl, zh)
-                                                       : gs_tb_fair_height_strict(rows, cols, fuse, fast_of(ctx), cpl, zh);
-            if (h == fit[0] && (cpl == 2 || h >= 20)) return h;
-        }
         long best = 0;
         for (int i = 0; i < nf; ++i)
             if (fit[i] >= 4 * fuse && (best == 0 || std::labs(fit[i] - want) < std::labs(best - want))) best = fit[i];

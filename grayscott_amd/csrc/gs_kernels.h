@@ -59,9 +59,6 @@ struct GsStepArgs {
     // In-step form: the progress (0 ... 256) from which a wave's priority is steered; before, the waves run as
     // the arbitration leaves them (filled in by the launcher).
     int32_t fair_from;
-    // In-step form: unit heights of the left / right edge strips (interior strips: rows_per_unit) and units per
-    // left / right / interior strip (filled in by the launcher; gs_step_tb_k).
-    int32_t fair_hl, fair_hr, fair_nl, fair_nr, fair_ni;
     // Boundary rule on global edges: 0 = naive's clipped window (weights anchored at the window's
     // top-left corner), 1 = full window with zeros outside the grid (gs_boundary in gs_hip.h).
     int32_t zero_halo;
@@ -78,8 +75,7 @@ struct GsStepArgs {
     hipError_t gs_launch_tb_##SUFFIX(const GsStepArgs &a, int k, hipStream_t s, const char **name); \
     hipError_t gs_launch_tile_##SUFFIX(const GsStepArgs &a, int k, int shape, hipStream_t s, const char **name); \
     hipError_t gs_launch_lds_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name);  \
-    int gs_tb_wave_slots_##SUFFIX(int k, int fast, int cpl);                                   \
-    int gs_tb_fair_height_##SUFFIX(int rows, int cols, int k, int fast, int cpl, int zero_halo);
+    int gs_tb_wave_slots_##SUFFIX(int k, int fast, int cpl);
 
 GS_DECLARE_LAUNCHERS(strict)
 GS_DECLARE_LAUNCHERS(fused)

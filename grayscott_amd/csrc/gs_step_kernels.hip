@@ -781,8 +781,7 @@ struct FairBoard {
 
 // EDGE: 0 = interior unit; 1 = general path; 2 / 3 = strip on the grid's left / right edge that touches neither its
 // top nor its bottom (cell<2> / cell<3>); 4 = interior strip that touches the top or bottom edge: interior code for
-// every row but the grid's first / last, which take the general cell (wave-uniform branch per level-row); 5 / 6 =
-// the corners: 2 / 3 with the same per-row branch.
+// every row but the grid's first / last, which take the general cell (wave-uniform branch per level-row).
 template <int K, int EDGE, int FAST, int CPL, int ZH = -1, bool FAIR = false>
 __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, int strip, int lane,
                                          const FairBoard &fb
@@ -793,8 +792,8 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
 {
     constexpr int S = tb_sacrificial_lanes(K, CPL), W = tb_cols_per_wave(K, CPL);
     const int c = strip * W + (lane - S) * CPL; // first column of this lane (may be negative)
-    constexpr bool COLS = EDGE == 1 || EDGE == 2 || EDGE == 3 || EDGE == 5 || EDGE == 6; // the strip may leave the grid's columns
-    constexpr bool ROWS = EDGE == 1 || EDGE >= 4;                                      // the unit may touch the grid's first / last row
+    constexpr bool COLS = EDGE == 1 || EDGE == 2 || EDGE == 3; // the strip may leave the grid's columns
+    constexpr bool ROWS = EDGE == 1 || EDGE == 4;              // the unit may touch the grid's first / last row
     const bool load_ok = !COLS || (c >= 0 && c < a.pitch);
     const bool store_ok = (lane >= S) && (lane < 64 - S) && (!COLS || c < a.pitch);
     const ptrdiff_t pitch = a.pitch;
@@ -858,8 +857,8 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
         // v_cndmask_b32.  Round 1 kept opaque all-ones / all-zeros words in VGPRs and blended bitwise
         // (v_cndmask is ~10x a plain VALU op on gfx950), which made the edge units 0.5 % of a pass
         // faster -- and cost the 3 registers that kept the whole kernel at 3 waves per SIMD.
-        la[k] = ((EDGE == 1 || EDGE == 2 || EDGE == 5) && k == 0 && c == 0) ? 0xffffffffu : 0u;
-        ra[k] = ((EDGE == 1 || EDGE == 3 || EDGE == 6) && (c + k + 1 >= a.cols)) ? 0xffffffffu : 0u;
+        la[k] = ((EDGE == 1 || EDGE == 2) && k == 0 && c == 0) ? 0xffffffffu : 0u;
+        ra[k] = ((EDGE == 1 || EDGE == 3) && (c + k + 1 >= a.cols)) ? 0xffffffffu : 0u;
     }
 
     RowT<CPL> w[K][3]; // w[j][slot]: level-j rows, newest in slot (tick % 3)
@@ -914,14 +913,13 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
 #pragma unroll
                         for (int k = 0; k < CPL; ++k) { nu[k] = z.u[k + 1] + m.u[k]; nv[k] = z.v[k + 1] + p.v[k + 2]; }
 #else
-                        if constexpr (EDGE >= 4) {
-                            constexpr int INNER = EDGE == 4 ? 0 : EDGE - 3; // the kind of the rows that have both neighbours
+                        if constexpr (EDGE == 4) {
                             if (mrow && prow) {
 #pragma unroll
-                                for (int k = 0; k < CPL; ++k) cell<INNER, FAST, RowT<CPL>, ZH>(a, m, z, p, k + 1, true, true, la[k], ra[k], nu[k], nv[k]);
+                                for (int k = 0; k < CPL; ++k) cell<0, FAST, RowT<CPL>, ZH>(a, m, z, p, k + 1, true, true, 0u, 0u, nu[k], nv[k]);
                             } else {
 #pragma unroll
-                                for (int k = 0; k < CPL; ++k) cell<1, FAST, RowT<CPL>, ZH>(a, m, z, p, k + 1, mrow, prow, la[k], ra[k], nu[k], nv[k]);
+                                for (int k = 0; k < CPL; ++k) cell<1, FAST, RowT<CPL>, ZH>(a, m, z, p, k + 1, mrow, prow, 0u, 0u, nu[k], nv[k]);
                             }
                         } else {
 #pragma unroll
@@ -988,7 +986,13 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     // a wave without a unit marks itself finished (never "behind") and leaves
 #define GS_TB_LEAVE do { if constexpr (FAIR) { if (lane == 0) fb.progress[wave] = 0x7fffffff; } return; } while (0)
     const int strips = (a.cols + W - 1) / W;
-    const int unit = (int)blockIdx.x * WG + wave;
+    // Units in dispatch order (edge units first).  4-wave workgroups take four consecutive ones; the dispatcher
+    // deals the workgroups over the CUs.  A 16-wave workgroup of the 1-column layout takes every gridDim.x-th unit
+    // instead: with consecutive units the first 31 workgroups would hold nothing but edge units, whose half-height
+    // general-path marches are longer than the interior's when units are short (13 ticks x 1.6 against 18 at
+    // 10-row units: those CUs end 15 % late; 390 k -> 419 k).  With 2 columns per lane the edge halves are the
+    // shorter ones (27 x 1.57 against 46 ticks at 38 rows) and 16 neighbouring strips on one CU read 1 % faster.
+    const int unit = FAIR && CPL == 1 ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * WG + wave;
     const int rpu = a.rows_per_unit;
     const int small = a.small_rpu;
     const int rest_a = a.ra1 - a.ra0 - a.big_chunks * rpu; // rows of range a behind the full-height chunks
@@ -1008,35 +1012,6 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     // outer strips of every chunk and every strip of the first edge_chunks chunks in dispatch order.
     const int es = a.edge_split == 2 ? 2 : 1;
     int chunk, strip, half = -1;
-    int ur0, ur1;
-    if constexpr (FAIR) {
-        // One round of 16-wave workgroups whose waves keep step: every unit should march for the same time.  The
-        // units come strip by strip -- the left edge strip, the right edge strip(s), then the interior strips -- and
-        // every kind of strip is cut into units of its own height (a.fair_hl / fair_hr / rows_per_unit, chosen by
-        // the launcher from the cost of the kinds of edge path: (h + 2K) x cost equal for all).  No halves, no taper.
-        // Order: the interior units chunk by chunk (the waves of a workgroup then work on neighbouring strips of
-        // one chunk row: 16 x 480 contiguous bytes per row, spread over the memory channels -- strip by strip, 16
-        // column slices 36 rows x 16 KB apart, the same launch ran 5-25 % slower with some pitches); the edge
-        // units are dealt over the workgroups, one or two in the last waves of each.
-        const int n_l = a.fair_nl, n_r = a.fair_nr, n_i = a.fair_ni, n_in = strips - 1 - er;
-        const int E = n_l + er * n_r, G = (int)gridDim.x, g = (int)blockIdx.x;
-        const int q = E / G, r = E - q * G, mine_e = q + (g < r ? 1 : 0); // edge units of this workgroup
-        int h;
-        if (wave >= WG - mine_e) {
-            const int e = (WG - 1 - wave) * G + g;
-            if (e < n_l) { strip = 0; chunk = e; h = a.fair_hl; }
-            else { const int v = e - n_l, s2 = v / n_r; strip = strips - er + s2; chunk = v - s2 * n_r; h = a.fair_hr; }
-        } else {
-            const int i = (g < r ? g * (WG - 1 - q) : r * (WG - 1 - q) + (g - r) * (WG - q)) + wave;
-            chunk = i / n_in;
-            strip = 1 + (i - chunk * n_in);
-            h = rpu;
-            if (chunk >= n_i) GS_TB_LEAVE; // wave-uniform
-        }
-        ur0 = a.ra0 + chunk * h;
-        ur1 = min(ur0 + h, a.ra1);
-        if (ur0 >= ur1) GS_TB_LEAVE;
-    } else {
     if (strips <= ne) {
         if (unit >= chunks * strips * es) GS_TB_LEAVE; // wave-uniform
         chunk = unit / (strips * es);
@@ -1063,6 +1038,7 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
             strip = 1 + (v - (v / ni) * ni);
         }
     }
+    int ur0, ur1;
     if (chunk < chunks_a) {
         // the last chunks of the range first, then chunks 0, 1, 2, ... (bottom / top edge chunks)
         const int bf = min(a.bot_first, chunks_a);
@@ -1087,7 +1063,6 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         else ur0 = ur0 + hh;
         if (ur0 >= ur1) GS_TB_LEAVE; // a one-row chunk has no second half (wave-uniform)
     }
-    } // !FAIR
     const bool left = strip == 0, right = (strip + 1) * W + S * CPL >= a.cols;
     const bool ends = (ur0 - K < 0 && !a.top_present) || (ur1 + K > a.rows && !a.bottom_present);
     const bool edge = left || right || ends;
@@ -1113,12 +1088,6 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         tb_march<K, KINDS ? 3 : 1, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
     else if (KINDS && a.edge_kinds && ends && !left && !right)
         tb_march<K, KINDS ? 4 : 1, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
-    // (the corner kinds only with 2 columns per lane: with 1 they take the kernel from 92 to 103 registers,
-    // 4 waves per SIMD instead of 5)
-    else if (KINDS && CPL == 2 && a.edge_kinds && ends && left && !right)
-        tb_march<K, KINDS && CPL == 2 ? 5 : 1, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
-    else if (KINDS && CPL == 2 && a.edge_kinds && ends && right && !left)
-        tb_march<K, KINDS && CPL == 2 ? 6 : 1, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
     else
         tb_march<K, 1, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
 #undef GS_TRACE_ARG
@@ -1623,40 +1592,6 @@ static int tb_reduce_fast(int fast)
 
 // Wave slots of the chip for the kernel entry a launch with these parameters would use (the tuner's
 // "a launch of exactly r rounds" candidates, gs_api.cpp); 0 = no such entry.
-// The in-step form's plan for a launch over `rows` rows (one range, a single slab) with interior units of h_i rows:
-// unit heights of the left / right edge strips such that (h + 2K) x (cost of the strip's kind of edge path) matches
-// the interior's h_i + 2K ticks, and the units per strip.  The costs are the instruction counts of the kinds of
-// cell<> relative to the interior's (gs_step_tb_k): with the cheap kinds 1.21 / 1.11 (left / right, 2 columns per
-// lane; 1.45 / 1.11 with 1), else the general path's 1.57.  Returns the number of units, 0 when the form does not apply.
-struct FairPlan { int hl, hr, nl, nr, ni; };
-static long tb_fair_plan(long rows, long cols, int k, int fast, int cpl, bool zero_halo, long h_i, FairPlan *out)
-{
-    static const bool kinds_env = !(std::getenv("GS_HIP_EDGE_KINDS") && std::atoi(std::getenv("GS_HIP_EDGE_KINDS")) == 0);
-    if (k != 4 || (cpl != 1 && cpl != 2) || rows <= 0 || h_i < 1) return 0;
-    const long W = tb_cols_per_wave(k, cpl), S = tb_sacrificial_lanes(k, cpl);
-    const long strips = (cols + W - 1) / W;
-    const long er = ((strips - 1) * W + S * cpl >= cols && strips >= 2) ? 2 : 1;
-    if (strips < 1 + er + 1) return 0; // a left strip, the right one(s) and at least one interior strip
-    const bool kinds = kinds_env && (tb_reduce_fast(fast) & 1) && !GS_MATH_FUSED && !zero_halo;
-    const double fl = kinds ? (cpl == 2 ? 1.21 : 1.45) : 1.57, fr = kinds ? 1.11 : 1.57;
-    auto height = [&](double f) { const long h = (long)((double)(h_i + 2 * k) / f) - 2 * k; return h < 1 ? 1L : (h > h_i ? h_i : h); };
-    const long hl = height(fl), hr = height(fr);
-    const long nl = (rows + hl - 1) / hl, nr = (rows + hr - 1) / hr, ni = (rows + h_i - 1) / h_i;
-    if (out) *out = FairPlan{(int)hl, (int)hr, (int)nl, (int)nr, (int)ni};
-    return nl + er * nr + (strips - 1 - er) * ni;
-}
-
-// Smallest interior unit height whose in-step launch fits one round of 16-wave workgroups (4096 units); 0 = none.
-int GS_SUFFIX(gs_tb_fair_height)(int rows, int cols, int k, int fast, int cpl, int zero_halo)
-{
-    for (long h = 2; h <= rows; ++h) {
-        const long units = tb_fair_plan(rows, cols, k, fast, cpl, zero_halo != 0, h, nullptr);
-        if (units == 0) return 0;
-        if (units <= 4096) return (int)h;
-    }
-    return 0;
-}
-
 int GS_SUFFIX(gs_tb_wave_slots)(int k, int fast, int cpl)
 {
     if (k < 1 || k > 4 || (cpl != 1 && cpl != 2 && cpl != 4)) return 0;
@@ -1760,27 +1695,23 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
         }
     }
     // A launch that fits the chip in ONE round of 16-wave workgroups (one per CU, 4 waves per SIMD) runs the
-    // in-step form of the kernel (tb_march<FAIR>): every unit starts at once there and, left to the SIMDs'
-    // oldest-first arbitration, the waves of a SIMD finish one after the other, the last one alone.  Its units
-    // come strip by strip with a height per kind of strip (tb_fair_plan), so that they all march equally long.
+    // fair-progress form of the kernel (tb_march<FAIR>): every unit starts at once there and, left to the
+    // SIMDs' oldest-first arbitration, the waves of a SIMD finish one after the other, the last one alone.
     // Not for short marches of the 1-column layout: there most of a unit's ticks are the memory-bound filling
     // of the level pipeline, and waves left out of phase by the oldest-first arbitration hide each other's
-    // waits (free-running / in step, profiles/r03_sweeps.md, section 2: 1 column per lane, 10-row units 430 k /
-    // 390-426 k, 16 rows 524 k / 514 k, 20 rows 565 k / 573 k, 40 rows 677 k / 705 k; 2 columns per lane, 10 rows
-    // 523 k / 537 k, 19 rows 687 k / 738 k, 38 rows 782 k / 865 k).  GS_HIP_FAIR = 0 / 1 forces it off / on.
+    // waits.  Free-running / in step, same box (profiles/r03_sweeps.md, section 2): 1 column per lane, 10-row
+    // units 430 k / 390 k, 12 rows 465 k / 443 k, 16 rows 524 k / 514 k, 20 rows 565 k / 573 k, 40 rows 677 k / 705 k;
+    // 2 columns per lane, 10 rows 523 k / 537 k, 15 rows 615 k / 633 k, 19 rows 687 k / 738 k, 38 rows 782 k / 865 k.
+    // GS_HIP_FAIR = 0 / 1 forces it off / on.
     static const int fair_env = std::getenv("GS_HIP_FAIR") ? std::atoi(std::getenv("GS_HIP_FAIR")) : -1;
-    FairPlan plan{0, 0, 0, 0, 0};
-    const long fair_units = a.allow_fair && a.rb1 <= a.rb0 && a.ra0 == 0 && a.ra1 == a.rows &&
-                                    (fair_env < 0 ? (cpl == 2 || rpu >= 20) : fair_env != 0)
-                                ? tb_fair_plan(a.rows, a.cols, k, a.fast, cpl, a.zero_halo != 0, rpu, &plan) : 0;
-    const void *fair_fn = fair_units > 1024 && fair_units <= 4096 ? tb_entry(k, fast, cpl, 16) : nullptr;
+    const bool fair = a.allow_fair && units <= 4096 && units > 1024 && (fair_env < 0 ? (cpl == 2 || rpu >= 20) : fair_env != 0);
+    const void *fair_fn = fair ? tb_entry(k, fast, cpl, 16) : nullptr;
     static const int fair_from_env = std::getenv("GS_HIP_FAIR_FROM") ? std::atoi(std::getenv("GS_HIP_FAIR_FROM")) : -1;
     args.fair_from = fair_from_env >= 0 ? fair_from_env : 0;
     void *kargs[] = {&args};
     if (fair_fn) {
-        args.fair_hl = plan.hl; args.fair_hr = plan.hr; args.fair_nl = plan.nl; args.fair_nr = plan.nr; args.fair_ni = plan.ni;
         if (name) *name = names16[cpl == 1 ? 0 : 1][fast ? 1 : 0];
-        return hipLaunchKernel(fair_fn, dim3((unsigned)((fair_units + 15) / 16)), dim3(1024), kargs, 0, s);
+        return hipLaunchKernel(fair_fn, dim3((unsigned)((units + 15) / 16)), dim3(1024), kargs, 0, s);
     }
     const long blocks = (units + 3) / 4;
     if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;

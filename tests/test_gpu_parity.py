@@ -245,7 +245,7 @@ def test_temporal_blocking_large_grid_vs_stream():
     dict(rows=1500, cols=1500, cpl=2, rpu=12, boundary=capi.GS_BOUNDARY_ZERO_HALO),
     dict(rows=1300, cols=1700, cpl=2, rpu=16, math=capi.GS_MATH_FUSED),
     dict(rows=1300, cols=1700, cpl=1, rpu=33, general=True),         # non-default parameters: the general kernels
-    dict(rows=1200, cols=300, cpl=2, rpu=2),                         # three strips, 2-row interior units, 1-row edge units
+    dict(rows=2000, cols=130, cpl=2, rpu=2),                         # two strips, both edge strips, 2-row units in halves
 ])
 def test_in_step_workgroups_bit_exact(case):
     """The form of the marching kernel that launches of one round run on a single slab: 16-wave workgroups
