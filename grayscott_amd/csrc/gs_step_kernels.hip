@@ -894,7 +894,7 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                         else __builtin_amdgcn_s_setprio(3);
                         // experiment (GS_HIP_FAIR_THROTTLE): a wave that leads another by more than `throttle` steps aside
                         if (a.fair_throttle > 0 &&
-                            __builtin_amdgcn_ballot_w64(their_simd == fb.simd && theirs + a.fair_throttle < mine))
+                            __builtin_amdgcn_ballot_w64(their_simd == fb.simd && theirs < mine - a.fair_throttle))
                             __builtin_amdgcn_s_sleep(32);
                     }
                 }
