@@ -59,7 +59,6 @@ struct GsStepArgs {
     // In-step form: the progress (0 ... 256) from which a wave's priority is steered; before, the waves run as
     // the arbitration leaves them (filled in by the launcher).
     int32_t fair_from;
-    int32_t fair_throttle; // experiment: lead (in 256ths of a unit's ticks) beyond which a wave sleeps; 0 = never
     // Boundary rule on global edges: 0 = naive's clipped window (weights anchored at the window's
     // top-left corner), 1 = full window with zeros outside the grid (gs_boundary in gs_hip.h).
     int32_t zero_halo;

@@ -892,10 +892,6 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                         const unsigned long long behind = __builtin_amdgcn_ballot_w64(their_simd == fb.simd && theirs < mine);
                         if (behind) __builtin_amdgcn_s_setprio(0);
                         else __builtin_amdgcn_s_setprio(3);
-                        // experiment (GS_HIP_FAIR_THROTTLE): a wave that leads another by more than `throttle` steps aside
-                        if (a.fair_throttle > 0 &&
-                            __builtin_amdgcn_ballot_w64(their_simd == fb.simd && theirs < mine - a.fair_throttle))
-                            __builtin_amdgcn_s_sleep(32);
                     }
                 }
                 w[0][s3] = widen_tb<CPL>(q[s3].u, q[s3].v);
@@ -1712,8 +1708,6 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     const void *fair_fn = fair ? tb_entry(k, fast, cpl, 16) : nullptr;
     static const int fair_from_env = std::getenv("GS_HIP_FAIR_FROM") ? std::atoi(std::getenv("GS_HIP_FAIR_FROM")) : -1;
     args.fair_from = fair_from_env >= 0 ? fair_from_env : 0;
-    static const int fair_throttle_env = std::getenv("GS_HIP_FAIR_THROTTLE") ? std::atoi(std::getenv("GS_HIP_FAIR_THROTTLE")) : 0;
-    args.fair_throttle = fair_throttle_env;
     void *kargs[] = {&args};
     if (fair_fn) {
         if (name) *name = names16[cpl == 1 ? 0 : 1][fast ? 1 : 0];
