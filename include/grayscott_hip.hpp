@@ -99,6 +99,15 @@ class HipContext {
     void sync() const { check(gs_sync(ctx_)); }
     // waits for the asynchronous downloads enqueued so far (not for later steps)
     void download_wait() const { check(gs_download_wait(ctx_)); }
+    // counters of the context (passes, steps, launches, blocking ghost refreshes) and, on slab chains, the
+    // halo-stream / interior times of the passes timed with set_pass_timing (gs_ctx_stats)
+    gs_stats stats() const
+    {
+        gs_stats st;
+        check(gs_ctx_stats(ctx_, &st));
+        return st;
+    }
+    void set_pass_timing(int32_t passes) const { check(gs_ctx_set_pass_timing(ctx_, passes)); }
 
   private:
     gs_ctx *ctx_ = nullptr;
@@ -165,6 +174,8 @@ class HipConcentration {
         check(gs_field_download_async(c->get(), f_, target));
     }
     gs_field *raw() const { return f_; }
+    // a zero-copy producer wrote cells through gs_field_device_ptr: ghost rows of neighbouring slabs are stale
+    void mark_written(Context &c) { check(gs_field_mark_written(c->get(), f_)); }
 
   private:
     HipConcentration(Context &c, Shape s) : ctx_(c), shape_(s)

@@ -37,6 +37,9 @@ int main(int argc, char **argv)
             threw = true;
         }
         if (!threw) return 3;
+        // the library's own counters: every step requested was enqueued, in at least one pass
+        const gs_stats st = species.context()->stats();
+        if (st.steps != steps || (steps > 0 && st.passes == 0) || st.ghost_refreshes != 0) return 5;
         std::FILE *f = std::fopen(argv[4], "wb");
         if (!f) return 4;
         std::fwrite(u.data(), sizeof(float), u.size(), f);
