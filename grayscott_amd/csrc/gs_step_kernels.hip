@@ -667,6 +667,45 @@ __device__ __forceinline__ RowT<CPL> widen_tb(const float (&u)[CPL], const float
     return w;
 }
 
+// The CPL interior cells a lane computes in one row.  With the default side weights in the strict build (FAST & 1)
+// two cells side by side share a difference: IEEE subtraction is antisymmetric, half_diff(a, b) == -half_diff(b, a)
+// bit for bit except that a zero comes out as +0 on both sides, and the accumulator, never -0, does not tell +0
+// from -0 (see half_diff).  So the right-hand tap of a cell is kept and SUBTRACTED as the left-hand tap of the next
+// cell: one instruction less per pair of neighbours, the reference's order of additions unchanged.
+#ifndef GS_TB_HSHARE
+#define GS_TB_HSHARE 1
+#endif
+template <int FAST, int CPL, int ZH>
+__device__ __forceinline__ void cells_interior(const GsStepArgs &a, const RowT<CPL> &m, const RowT<CPL> &z, const RowT<CPL> &p,
+                                               float (&nu)[CPL], float (&nv)[CPL])
+{
+    if constexpr (GS_TB_HSHARE && CPL > 1 && (FAST & 1) && !GS_MATH_FUSED) {
+        float hu = 0.0f, hv = 0.0f; // the previous cell's right-hand tap
+#pragma unroll
+        for (int k = 1; k <= CPL; ++k) {
+            const float u = z.u[k], v = z.v[k];
+            float acc_u = 0.0f, acc_v = 0.0f;
+            GS_TAP(acc_u, a.w[0][0], m.u[k - 1], u); GS_TAP(acc_v, a.w[0][0], m.v[k - 1], v);
+            GS_TAP_HALF(acc_u, m.u[k], u);           GS_TAP_HALF(acc_v, m.v[k], v);
+            GS_TAP(acc_u, a.w[0][2], m.u[k + 1], u); GS_TAP(acc_v, a.w[0][2], m.v[k + 1], v);
+            if (k == 1) {
+                GS_TAP_HALF(acc_u, z.u[k - 1], u);   GS_TAP_HALF(acc_v, z.v[k - 1], v);
+            } else {
+                acc_u = acc_u - hu;                  acc_v = acc_v - hv;
+            }
+            hu = half_diff(z.u[k + 1], u);           hv = half_diff(z.v[k + 1], v);
+            acc_u = acc_u + hu;                      acc_v = acc_v + hv;
+            GS_TAP(acc_u, a.w[2][0], p.u[k - 1], u); GS_TAP(acc_v, a.w[2][0], p.v[k - 1], v);
+            GS_TAP_HALF(acc_u, p.u[k], u);           GS_TAP_HALF(acc_v, p.v[k], v);
+            GS_TAP(acc_u, a.w[2][2], p.u[k + 1], u); GS_TAP(acc_v, a.w[2][2], p.v[k + 1], v);
+            react<(FAST & 2) != 0>(a, u, v, acc_u, acc_v, nu[k - 1], nv[k - 1]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) cell<0, FAST, RowT<CPL>, ZH>(a, m, z, p, k + 1, true, true, 0u, 0u, nu[k], nv[k]);
+    }
+}
+
 template <int CPL> struct VecOf;
 template <> struct VecOf<4> { using type = float4; };
 template <> struct VecOf<2> { using type = float2; };
@@ -915,12 +954,13 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
 #else
                         if constexpr (EDGE == 4) {
                             if (mrow && prow) {
-#pragma unroll
-                                for (int k = 0; k < CPL; ++k) cell<0, FAST, RowT<CPL>, ZH>(a, m, z, p, k + 1, true, true, 0u, 0u, nu[k], nv[k]);
+                                cells_interior<FAST, CPL, ZH>(a, m, z, p, nu, nv);
                             } else {
 #pragma unroll
                                 for (int k = 0; k < CPL; ++k) cell<1, FAST, RowT<CPL>, ZH>(a, m, z, p, k + 1, mrow, prow, 0u, 0u, nu[k], nv[k]);
                             }
+                        } else if constexpr (EDGE == 0) {
+                            cells_interior<FAST, CPL, ZH>(a, m, z, p, nu, nv);
                         } else {
 #pragma unroll
                             for (int k = 0; k < CPL; ++k)
