@@ -202,7 +202,11 @@ struct gs_ctx {
         uint64_t rows = 0, cols = 0;
         int k = 0, rpu = 0, cpl = 0, batch = 0;
         gs_params p{};
-        bool operator==(const GraphKey &other) const { return std::memcmp(this, &other, sizeof *this) == 0; }
+        bool operator==(const GraphKey &o) const
+        {
+            return std::memcmp(planes, o.planes, sizeof planes) == 0 && rows == o.rows && cols == o.cols && k == o.k &&
+                   rpu == o.rpu && cpl == o.cpl && batch == o.batch && std::memcmp(&p, &o.p, sizeof p) == 0;
+        }
     } graph_key;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -1141,7 +1145,6 @@ int32_t replay_graph_batches(Run &r, int kk)
     ctx->bands_active = false;
     const gs_field *f = r.u[0];
     gs_ctx::GraphKey key;
-    std::memset(&key, 0, sizeof key); // padding included: the key is compared with memcmp
     key.planes[0] = r.u[r.in]->s[0].row0; key.planes[1] = r.v[r.in]->s[0].row0;
     key.planes[2] = r.u[1 - r.in]->s[0].row0; key.planes[3] = r.v[1 - r.in]->s[0].row0;
     key.rows = f->rows; key.cols = f->cols;
