@@ -729,6 +729,30 @@ def test_specialised_variants_bit_exact(fuse, cpl, general):
                 assert_bits_equal(got_v, ref_v, f"V {info[0]} {shape} steps {steps} {p}")
 
 
+@pytest.mark.parametrize("fuse,cpl", [(4, 2), (2, 2), (4, 1), (4, 4)])
+def test_shared_difference_with_signed_zeros_and_equal_neighbours(fuse, cpl):
+    """Two cells side by side in a lane share one difference (cells_interior): `x[c+1] - x[c]` is formed once and
+    subtracted in the second cell's fold where the reference adds `x[c] - x[c+1]`.  The two agree up to the sign of an
+    exact or flushed zero, which the accumulator must not see: fields drawn from a handful of values -- both zeros,
+    sub-normals and the smallest normals of both signs, a few ordinary numbers -- so that neighbours are often equal,
+    differ only in the sign of zero, or differ by less than the flush threshold."""
+    values = np.array([0.0, -0.0, 2.0 ** -127, -(2.0 ** -127), 2.0 ** -126, -(2.0 ** -126), 3 * 2.0 ** -126, 2.0 ** -125,
+                       0.25, 0.5, 0.5, 1.0, 1.0, 1.0], np.float32)
+    for shape, seed in [((40, 520), 11), ((64, 300), 12)]:
+        rng = np.random.default_rng(seed)
+        u0 = values[rng.integers(0, len(values), size=shape)]
+        v0 = values[rng.integers(0, len(values), size=shape)]
+        # runs of equal neighbours along the rows, as a smooth field has them
+        u0[:, 1::2] = np.where(rng.random(u0[:, 1::2].shape) < 0.5, u0[:, 0:-1:2][:, : u0[:, 1::2].shape[1]], u0[:, 1::2])
+        v0[:, 1::2] = np.where(rng.random(v0[:, 1::2].shape) < 0.5, v0[:, 0:-1:2][:, : v0[:, 1::2].shape[1]], v0[:, 1::2])
+        for steps in (1, 4, 8):
+            ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True)
+            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(kernel=capi.GS_KERNEL_TB, fuse_steps=fuse, rows_per_block=12,
+                                                                  cols_per_lane=cpl))
+            assert_bits_equal(got_u, ref_u, f"U {info[0]} {shape} steps {steps}")
+            assert_bits_equal(got_v, ref_v, f"V {info[0]} {shape} steps {steps}")
+
+
 def test_specialised_variant_sees_subnormals():
     """The sub-normal test data is real: the keep-denormals answer differs from the FTZ one."""
     u0, v0 = _tiny_fields((64, 300), 6)
