@@ -38,7 +38,31 @@ def parse(argv=None):
     ap.add_argument("-n", "--nbimage", type=int, default=1000)           # main.rs:29-31
     ap.add_argument("-o", "--output", default="output.h5")               # main.rs:33-35, ui/src/lib.rs:72-75
     ap.add_argument("--output-buffer", type=int, default=2)              # main.rs:37-43
+    # The backend's own parameters, flattened into the command line as the reference flattens
+    # `Simulation::CliArgs` (ui/src/lib.rs:43-45, inside the SharedArgs that simulate/src/main.rs:25-27 flattens): the names, meanings and environment
+    # variables of rust/compute_hip/src/lib.rs (HipArgs).  Defaults come from the environment (HipArgs' own).
+    be = ap.add_argument_group("HIP backend")
+    be.add_argument("--hip-devices", default=None, metavar="ID[,ID...]",
+                    help="HIP devices that run the simulation, one row slab each, top to bottom [env GS_HIP_DEVICES, 0]")
+    be.add_argument("--hip-math", type=int, default=None, help="0 = strict (bit-identical to compute_naive), 1 = fused taps [GS_HIP_MATH]")
+    be.add_argument("--hip-rows-per-block", type=int, default=None, help="rows each wavefront marches over, 0 = chosen on line [GS_HIP_ROWS_PER_BLOCK]")
+    be.add_argument("--hip-fuse-steps", type=int, default=None, help="time steps fused per pass over HBM, 1..4, 0 = chosen on line [GS_HIP_FUSE_STEPS]")
+    be.add_argument("--hip-cols-per-lane", type=int, default=None, help="columns per lane: 4, 2 or 1, 0 = chosen on line [GS_HIP_COLS_PER_LANE]")
+    be.add_argument("--hip-no-tune", type=int, default=None, help="1 = never time candidate configurations inside perform_steps [GS_HIP_NO_TUNE]")
     return ap.parse_args(argv)
+
+
+def backend_args(args) -> HipArgs:
+    """``HipArgs`` from the command line; what it leaves unset keeps its environment default."""
+    h = HipArgs()
+    if getattr(args, "hip_devices", None):
+        h.devices = [int(x) for x in str(args.hip_devices).split(",") if x != ""]
+    for flag, name in (("hip_math", "math"), ("hip_rows_per_block", "rows_per_block"), ("hip_fuse_steps", "fuse_steps"),
+                       ("hip_cols_per_lane", "cols_per_lane"), ("hip_no_tune", "no_tune")):
+        value = getattr(args, flag, None)
+        if value is not None:
+            setattr(h, name, value)
+    return h
 
 
 def simulation_parameters(args) -> Parameters:
@@ -58,7 +82,7 @@ def run(args, hip_args: HipArgs | None = None, out=None) -> dict:
     shape = (args.nbrow, args.nbcol)
     if args.output_buffer < 1:
         raise ValueError("--output-buffer must be at least 1")
-    sim = Simulation.new(simulation_parameters(args), hip_args)
+    sim = Simulation.new(simulation_parameters(args), hip_args if hip_args is not None else backend_args(args))
     species = sim.make_species(shape)
     ctx = sim.context
     if out is None and args.output.lower().endswith((".h5", ".hdf5")):

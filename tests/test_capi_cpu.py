@@ -128,3 +128,20 @@ def test_named_stencils_match_the_reference_constants():
     assert [five.w[0][0], five.w[0][1], five.w[1][0], five.w[1][1]] == [0.0, 1.0, 1.0, 0.0]
     assert Parameters.with_stencil("oono-puri").weights == Parameters().weights
     assert set(STENCILS) == {"oono-puri", "5points", "patrakarttunen", "pretty"}
+
+
+def test_simulate_driver_flattens_the_backend_flags(monkeypatch):
+    """ui/src/lib.rs:43-45 flattens the backend's CliArgs into the command line; the Python driver mirrors the Rust
+    shim's names (rust/compute_hip/src/lib.rs) and keeps the environment defaults for what is not given."""
+    from grayscott_amd import simulate as driver
+
+    monkeypatch.setenv("GS_HIP_FUSE_STEPS", "3")
+    monkeypatch.setenv("GS_HIP_DEVICES", "1,2")
+    h = driver.backend_args(driver.parse([]))
+    assert list(h.devices) == [1, 2] and h.fuse_steps == 3 and h.math == 0
+    h = driver.backend_args(driver.parse(["--hip-devices", "0,0", "--hip-fuse-steps", "2", "--hip-math", "1", "--hip-no-tune", "1"]))
+    assert list(h.devices) == [0, 0] and (h.fuse_steps, h.math, h.no_tune) == (2, 1, 1)
+    shim = open(os.path.join(ROOT, "rust", "compute_hip", "src", "lib.rs")).read()
+    for flag in ("hip_devices", "hip_math", "hip_rows_per_block", "hip_fuse_steps", "hip_cols_per_lane", "hip_no_tune"):
+        assert f"pub {flag}:" in shim, flag
+        assert hasattr(driver.parse([]), flag), flag

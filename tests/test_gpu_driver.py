@@ -78,3 +78,19 @@ def test_driver_defaults_match_reference_cli():
     assert a.output == "output.h5"                                                  # ui/src/lib.rs:72-75
     assert (a.nbrow, a.nbcol, a.nbimage, a.output_buffer) == (1080, 1920, 1000, 2)  # ui/src/lib.rs:32-38, main.rs:29-43
     assert a.nbextrastep is None and driver.simulation_parameters(a) == Parameters()
+
+
+def test_driver_backend_flags_reach_the_library(built, tmp_path):
+    """The backend's parameters flattened into the command line (ui/src/lib.rs:43-45: `#[command(flatten)] backend:
+    Simulation::CliArgs`), same names as the Rust shim's HipArgs: a 3-slab chain, pinned layout, bit-exact."""
+    out = tmp_path / "out.npy"
+    args = driver.parse(["-n", "3", "-e", "7", "-r", "150", "-c", "260", "-o", str(out), "--hip-devices", "0,0,0",
+                         "--hip-fuse-steps", "2", "--hip-rows-per-block", "8", "--hip-cols-per-lane", "1", "--hip-no-tune", "1"])
+    h = driver.backend_args(args)
+    assert list(h.devices) == [0, 0, 0] and (h.fuse_steps, h.rows_per_block, h.cols_per_lane, h.no_tune) == (2, 8, 1, 1)
+    driver.run(args)
+    data = np.load(out)
+    u, v = oracle.init_species(150, 260)
+    for i in range(3):
+        u, v = oracle.run(u, v, 7)
+        assert_bits_equal(data[i], v, f"image {i}")
