@@ -59,6 +59,11 @@ struct GsStepArgs {
     // In-step form: the progress (0 ... 256) from which a wave's priority is steered; before, the waves run as
     // the arbitration leaves them (filled in by the launcher).
     int32_t fair_from;
+    // XCD-aware unit order (filled in by the launcher; 0 = off).  The dispatcher deals workgroups over the 8 XCDs
+    // round-robin, so workgroup b runs on XCD b % 8.  From workgroup xcd_first on, every group of 8 * xcd_m
+    // workgroups is renumbered so that the xcd_m workgroups an XCD gets are consecutive ones -- neighbours in the
+    // grid, whose overlapping rows and columns then meet in that XCD's L2.
+    int32_t xcd_m, xcd_first;
     // Boundary rule on global edges: 0 = naive's clipped window (weights anchored at the window's
     // top-left corner), 1 = full window with zeros outside the grid (gs_boundary in gs_hip.h).
     int32_t zero_halo;

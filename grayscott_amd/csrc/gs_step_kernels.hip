@@ -552,7 +552,12 @@ __global__ __launch_bounds__(256) void GS_SUFFIX(gs_step_stream_k)(GsStepArgs a)
     // from it (unit, row range, edge flags) then lives in SGPRs and branches are scalar.
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int strips = (a.cols + 255) >> 8;
-    const int unit = blockIdx.x * 4 + wave;
+    int block = (int)blockIdx.x;
+    if (a.xcd_m > 0) { // XCD-aware order (GsStepArgs::xcd_m)
+        const int per = 8 * a.xcd_m, g = block / per, o = block - g * per;
+        if ((g + 1) * per <= (int)gridDim.x) block = g * per + (o & 7) * a.xcd_m + (o >> 3);
+    }
+    const int unit = block * 4 + wave;
     const int chunk = unit / strips;
     const int strip = unit - chunk * strips;
     const int rpu = a.rows_per_unit;
@@ -1032,7 +1037,12 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     // general-path marches are longer than the interior's when units are short (13 ticks x 1.6 against 18 at
     // 10-row units: those CUs end 15 % late; 390 k -> 419 k).  With 2 columns per lane the edge halves are the
     // shorter ones (27 x 1.57 against 46 ticks at 38 rows) and 16 neighbouring strips on one CU read 1 % faster.
-    const int unit = FAIR && CPL == 1 ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * WG + wave;
+    int block = (int)blockIdx.x;
+    if (a.xcd_m > 0 && block >= a.xcd_first) {
+        const int per = 8 * a.xcd_m, r = block - a.xcd_first, g = r / per, o = r - g * per;
+        if ((g + 1) * per <= (int)gridDim.x - a.xcd_first) block = a.xcd_first + g * per + (o & 7) * a.xcd_m + (o >> 3);
+    }
+    const int unit = FAIR && CPL == 1 ? wave * (int)gridDim.x + (int)blockIdx.x : block * WG + wave;
     const int rpu = a.rows_per_unit;
     const int small = a.small_rpu;
     const int rest_a = a.ra1 - a.ra0 - a.big_chunks * rpu; // rows of range a behind the full-height chunks
@@ -1559,6 +1569,12 @@ hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const
     const long blocks = (chunks * strips + 3) / 4;
     if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
     GsStepArgs args = a;
+    // XCD-aware order, as in gs_launch_tb: this kernel IS bound by HBM, so the re-reads the XCDs' L2s absorb are
+    // time -- 16384^2 365 k -> 376 k (6.0 TB/s algorithmic), 4096^2 323 k -> 347 k, 1080 x 1920 171 k -> 186 k; 8192^2
+    // unchanged on average (265-333 k from one context to the next either way: the four planes' placement decides).
+    // Groups of 8 x 64 workgroups lose 6 % (profiles/r03_sweeps.md, section 12).  GS_HIP_XCD_M_STREAM = 0 / n: off / 8 n.
+    static const int xcd_env = std::getenv("GS_HIP_XCD_M_STREAM") ? std::atoi(std::getenv("GS_HIP_XCD_M_STREAM")) : -1;
+    args.xcd_m = xcd_env >= 0 ? xcd_env : 16;
     void *kargs[] = {&args};
     return hipLaunchKernel(reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_stream_k)<2>),
                            dim3((unsigned)blocks), dim3(256), kargs, 0, s);
@@ -1755,6 +1771,18 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     }
     const long blocks = (units + 3) / 4;
     if (blocks > 0x7fffffffL) return hipErrorInvalidConfiguration;
+    // XCD-aware unit order (GsStepArgs::xcd_m): the dispatcher deals workgroups over the 8 XCDs round-robin, so
+    // four-strip neighbours in the grid land on eight different L2s and each fetches the columns and rows their
+    // windows share for itself.  With every XCD taking 16 consecutive workgroups of each group of 128, the HBM
+    // reads of a 16384^2 launch fall from 2.376 to 2.239 GiB (minimum 2.0; FETCH_SIZE, tools/fetch_ab.sh) and the
+    // launch gains 0.3-0.5 % (8192^2 +0.8 %, 4 / 8 slabs on one GPU +1.4 / +0.6 %).  Larger groups read no less
+    // (68: 2.226 GiB) and run slower (-2 %, 136: -6 %: an XCD's share of the last groups is all tall or all short
+    // units).  Launches of about one round keep the plain order: 1080 x 1920 loses 1.2 % with the renumbering
+    // (profiles/r03_sweeps.md, section 12).  GS_HIP_XCD_M = 0 / n forces it off / to groups of 8 n.
+    static const int xcd_env = std::getenv("GS_HIP_XCD_M") ? std::atoi(std::getenv("GS_HIP_XCD_M")) : -1;
+    args.xcd_m = xcd_env >= 0 ? xcd_env : (units >= 2 * slots ? 16 : 0);
+    // the edge units at the head of the dispatch order stay dealt over all XCDs (they are the slow ones)
+    args.xcd_first = (int32_t)(((chunks * ne * (args.edge_split == 2 ? 2 : 1) + 3) / 4 + 7) / 8 * 8);
     return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), kargs, 0, s);
 }
 

@@ -1086,3 +1086,33 @@ def test_huge_grid_32768_index_width():
     u = in_u.make_scalar_view(sim.context)
     assert_bits_equal(u[R0:R1, C0:C1][inner], cu[inner], "crop U at 32768^2")
     assert (u[-1] == 1.0).all() and (u[:, -1] == 1.0).all() and (u[0] == 1.0).all()
+
+
+def test_xcd_aware_unit_order_bit_exact():
+    """Large launches renumber their workgroups so that the ones an XCD is dealt are neighbours in the grid
+    (GsStepArgs::xcd_m; groups of 8 x 16 workgroups).  The group size is read from the environment once per process,
+    so a child process runs the marching kernel and the single-step kernel with groups of 8 x 2 and 8 x 3 -- small
+    enough to permute the units of a 300 x 2000 grid -- against the oracle, every kind of unit included."""
+    import subprocess
+    import sys
+
+    code = r"""
+import numpy as np, oracle
+from grayscott_amd import HipArgs, capi
+from tests.helpers import assert_bits_equal, gpu_run, stress_fields
+u0, v0 = stress_fields((300, 2000), 21)
+for kernel, kw in ((capi.GS_KERNEL_TB, dict(fuse_steps=4, rows_per_block=8, cols_per_lane=2)),
+                   (capi.GS_KERNEL_TB, dict(fuse_steps=3, rows_per_block=12, cols_per_lane=1)),
+                   (capi.GS_KERNEL_STREAM, dict(rows_per_block=16))):
+    for steps in (1, 4, 9):
+        ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True)
+        got_u, got_v, info = gpu_run(u0, v0, steps, args=HipArgs(devices=[0], kernel=kernel, no_tune=1, **kw))
+        assert_bits_equal(got_u, ref_u, f"U {info[0]} steps {steps}")
+        assert_bits_equal(got_v, ref_v, f"V {info[0]} steps {steps}")
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for m in ("2", "3"):
+        env = dict(os.environ, GS_HIP_XCD_M=m, GS_HIP_XCD_M_STREAM=m, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (m, r.stdout[-2000:], r.stderr[-4000:])
