@@ -360,13 +360,25 @@ def main() -> int:
         return sorted(runs, key=lambda r: r[0])[len(runs) // 2]
 
     def warm(sp):
-        """At least 50 ms of untimed steps right before a warm-up, no host gap: the timed launches meet the
-        clocks and caches of a running simulation, which is what the number claims to describe."""
-        rate = 4.0e11 if cells_per_gpu >= (1 << 24) else 1.0e11        # cell-steps per second, a low guess
-        sim.perform_steps(sp, max(16, int(0.05 * rate / cells_per_gpu)))
+        """At least 120 ms of untimed steps right before a warm-up, no host gap: the timed launches meet the
+        clocks and caches of a running simulation, which is what the number claims to describe.  (A chip that
+        comes out of an idle stretch -- the tuning's waits, a clock sample -- needs ~50 ms of load before its rate
+        settles: with 18 ms here the first five 5-ms regions read 1-4 % low, profiles/r03_sweeps.md section 6.)"""
+        rate = 1.2e12 if cells_per_gpu >= (1 << 24) else 5.0e11        # cell-steps per second, a high guess
+        n = (max(24, int(0.12 * rate / cells_per_gpu)) + 11) // 12 * 12
+        sim.perform_steps(sp, n)                        # whole passes only, whatever the tuner fuses (2, 3 or 4 steps)
+        return n
 
-    warm(species)
+    # A rehearsal of the timed region first: the first torch.cuda.synchronize() / barrier / HIP-event calls of a
+    # process may initialise things lazily, and a chip that idles for 2 ms runs its next ~10 ms at lower clocks
+    # (tools/region_startup.py: a 5-pass region after 2 ms of idle reads 5 % low).
+    # The W warm-up steps come first and the long untimed phase after them, directly before the timed regions: a W
+    # that is not a whole number of passes (the driver's 5) ends in a single-step launch of another kernel, and the
+    # chip, which sits on its power limit, answers that 0.7 ms change of load with a 20 ms dip -- the first four
+    # 5-ms regions read 1-5 % low with W = 5 and not with W = 0, 4 or 8 (profiles/r03_sweeps.md, section 6).
+    timed_run(species, args.steps)
     sim.perform_steps(species, args.warmup)
+    extra_warm_steps = warm(species)
     runs = repeated(species, args.steps, args.repeats)
     wall, event_ms, passes = median_run(runs)
     walls = [r[0] for r in runs]
@@ -457,8 +469,8 @@ def main() -> int:
     if with_extra:
         # co-headline: the same kernel, same context, same launches on a developed spot pattern (the chip
         # sustains a lower clock on non-trivial operands; BASELINE.md asks for "random/real data not zeros")
-        warm(sp_dev)
         sim.perform_steps(sp_dev, args.warmup)
+        warm(sp_dev)
         runs_dev = repeated(sp_dev, args.steps, args.repeats)
         w_dev, ms_dev, p_dev = median_run(runs_dev)
         developed = {"value": cells * args.steps / w_dev / 1e6,
@@ -501,6 +513,9 @@ def main() -> int:
         "repeats": len(runs),
         "value_min": cells * args.steps / max(walls) / 1e6,
         "value_max": cells * args.steps / min(walls) / 1e6,
+        "values": [round(cells * args.steps / w / 1e6) for w in walls],     # every timed region, in order
+        # untimed steps between the W warm-up steps and the first timed region (whole passes, >= 120 ms)
+        "untimed_steps_after_warmup": extra_warm_steps,
         "config": {
             "workload": f"{rows}x{cols} f32 (rows x cols), Species::new init, default feed/kill, "
                         f"double-buffered U/V in HBM",
