@@ -48,6 +48,12 @@ def test_recorded_bench_line_has_the_contract_keys():
             assert r["frac_source"] and (r["counters_layout"] is None or r["counters_layout"]["rows_per_unit"] > 0)
             assert r["profile_launch_ms"] is None or 0.8 < r["profile_launch_ms"] / r["launch_ms"] < 1.25
             assert b["config"]["grid"] == [16384, 16384] and b["config"]["tuned"]["rows_per_unit"] > 0
+            if "values" in b:
+                # end of round 3: every timed region in order; whole untimed passes between the W warm-up steps and
+                # the first region (an odd W ends in a single-step launch that costs the next 20 ms 1-5 %)
+                assert len(b["values"]) == b["repeats"] and abs(sorted(b["values"])[len(b["values"]) // 2] - b["value"]) <= 1
+                assert b["untimed_steps_after_warmup"] % 12 == 0 and b["untimed_steps_after_warmup"] >= 24
+                assert min(b["values"]) > 0.97 * b["value"]       # no region of the recorded run stands out
     else:  # round 1 format
         assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
