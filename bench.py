@@ -10,8 +10,10 @@ perform_steps only, :77-83).  Inputs are resident in HBM before the timed region
 N = 1 : BASELINE.json's headline workload, 16384 x 16384 f32 (config 3), Species::new init,
         default feed/kill.  Rank 0 also times the same kernel on a developed spot pattern, the
         fused-tap flavour, and the CPU ports on the host cores on a bounded sample.
-N > 1 : launched by torchrun, one process per GPU, row slabs with ghost-row exchange through RCCL
-        send/recv inside libgs_hip.so.
+N > 1 : one process per GPU (torchrun; `python bench.py --gpus N` without WORLD_SIZE starts that torchrun
+        itself, as a CHILD process, before anything touches a GPU), row slabs with ghost-row exchange
+        through RCCL send/recv inside libgs_hip.so.  Every rank runs a watchdog: a stage that exceeds its
+        bound prints one JSON line {"error", "rank", "stage"} and the process exits non-zero.
         --scaling weak (default): 2^28 cells per GPU -- rows = 16384 * N over 16384 columns
             (N = 2: 32768 x 16384, BASELINE config 4; N = 8: 65536 x 32768, config 5);
         --scaling strong: one grid for every N -- 32768 x 16384 (config 4 "across 2 then 4") for
@@ -147,7 +149,9 @@ def scaled_valu_insts(pmc, tuned):
     if not insts:
         return None, None
     h0, h = pmc.get("rows_per_unit"), tuned[0]
-    if not h0 or not h or h0 == h:
+    if not h:
+        return insts, f"profile of {h0}-row units; this run's layout is not known (nothing tuned or pinned)"
+    if not h0 or h0 == h:
         return insts, "measured (profile of this layout)"
     if pmc.get("cols_per_lane") != tuned[2] or pmc.get("steps_per_pass") != tuned[1]:
         return None, f"profile is for {pmc.get('cols_per_lane')} col/lane, {pmc.get('steps_per_pass')} steps/pass"
@@ -156,13 +160,11 @@ def scaled_valu_insts(pmc, tuned):
         f"scaled from the profile's {h0}-row units to this run's {h}-row units"
 
 
-def developed_species(sim, rows, cols, develop_steps=4000):
-    """A pattern-forming state instead of the reference's benchmark input: U = 1, V = 0 with one
-    12 x 12 seed (U = 0.5, V = 0.25) per 40 000 cells and 1 % noise, advanced `develop_steps` steps
-    (tools/pattern_rate.py, profiles/r01_soak.md: spots replicate until they fill the grid)."""
+def developed_start(rows, cols):
+    """Start of a pattern-forming run instead of the reference's benchmark input: U = 1, V = 0 with one
+    12 x 12 seed (U = 0.5, V = 0.25) per 40 000 cells and 1 % noise (tools/pattern_rate.py, profiles/r01_soak.md:
+    4000 steps later spots fill the grid).  Returns dense host arrays (u0, v0)."""
     import numpy as np
-
-    from grayscott_amd import Evolving, HipConcentration, Species
 
     rng = np.random.default_rng(2024)
     u0 = np.ones((rows, cols), np.float32)
@@ -173,23 +175,32 @@ def developed_species(sim, rows, cols, develop_steps=4000):
         v0[r:r + 12, c:c + 12] = 0.25
     u0 += rng.random(u0.shape, dtype=np.float32) * np.float32(0.01)
     v0 += rng.random(v0.shape, dtype=np.float32) * np.float32(0.01)
+    return u0, v0
+
+
+def upload_species(sim, u0, v0):
+    """A Species of `sim`'s context whose input planes hold (u0, v0); `steps_done` counts what it has run."""
+    from grayscott_amd import Evolving, HipConcentration, Species
+
     ctx = sim.context
     u = Evolving([HipConcentration(ctx, u0.shape), HipConcentration(ctx, u0.shape)])
     v = Evolving([HipConcentration(ctx, u0.shape), HipConcentration(ctx, u0.shape)])
     u.in_out()[0].upload(ctx, u0)
     v.in_out()[0].upload(ctx, v0)
-    del u0, v0
     species = Species(ctx, u, v)
-    sim.perform_steps(species, develop_steps)
+    species.steps_done = 0
     return species
 
 
 NOMINAL_SCLK_MHZ = 2400.0  # the clock VALU_PEAK_TLANEOPS is priced at
 
 
-def sample_clock_and_power(work, device: int):
-    """Medians of rocm-smi's shader clock (MHz) and socket power (W) sampled while `work()` runs; None when
-    rocm-smi is missing or says nothing useful (informational fields, never part of `value`)."""
+def sample_clock_and_power(work, device: int, cell_steps: float = 0.0):
+    """Medians of rocm-smi's shader clock (MHz) and socket power (W) sampled while `work()` runs, the board's
+    power cap, and -- from the card's accumulated-energy counter, first and last sample taken while the kernel
+    ran -- the average power over that window and the energy per cell-step (`work` returns (wall seconds, ...)
+    for `cell_steps` cell-steps, so pJ per cell-step = watts x seconds / cell-steps).  None when rocm-smi is
+    missing or says nothing useful (informational fields, never part of `value`)."""
     import re
     import shutil
     import statistics
@@ -199,34 +210,280 @@ def sample_clock_and_power(work, device: int):
     smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     if not os.path.exists(smi):
         return None
-    sclk, power, stop = [], [], threading.Event()
+    sclk, power, energy, stop = [], [], [], threading.Event()
+    cap = [None]
 
     def sampler():
+        try:
+            out = subprocess.run([smi, "-d", str(device), "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
+            m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", out)
+            if m:
+                cap[0] = float(m.group(1))
+        except Exception:
+            pass
         while not stop.is_set():
+            t0 = time.monotonic()
             try:
-                out = subprocess.run([smi, "-d", str(device), "--showclocks", "--showpower"], capture_output=True,
-                                     text=True, timeout=10).stdout
+                out = subprocess.run([smi, "-d", str(device), "--showclocks", "--showpower", "--showenergycounter"],
+                                     capture_output=True, text=True, timeout=10).stdout
             except Exception:
                 return
+            t1 = time.monotonic()
+            busy = False
             m = re.search(r"sclk clock level:[^(]*\((\d+)Mhz\)", out)
             if m:
+                busy = float(m.group(1)) > 1000.0
                 sclk.append(float(m.group(1)))
             m = re.search(r"Power \(W\):\s*([0-9.]+)", out)
             if m:
                 power.append(float(m.group(1)))
+            m = re.search(r"Accumulated Energy \(uJ\):\s*([0-9.]+)", out)
+            if m and busy:
+                energy.append((0.5 * (t0 + t1), float(m.group(1))))
             stop.wait(0.2)
 
     thread = threading.Thread(target=sampler, daemon=True)
     thread.start()
     try:
-        work()
+        ret = work()
     finally:
         stop.set()
         thread.join(timeout=15)
     busy = [c for c in sclk if c > 1000.0]          # samples taken while the kernel ran
     if not busy:
         return None
-    return {"sclk_MHz": statistics.median(busy), "power_W": statistics.median(power) if power else None, "samples": len(busy)}
+    out = {"sclk_MHz": statistics.median(busy), "power_W": statistics.median(power) if power else None,
+           "samples": len(busy), "power_cap_W": cap[0]}
+    # the last sample may have been taken after the kernel ended: leave it out when there are enough
+    win = energy[:-1] if len(energy) >= 4 else energy
+    if len(win) >= 2 and win[-1][0] - win[0][0] > 0.5 and cell_steps > 0 and ret:
+        watts = (win[-1][1] - win[0][1]) * 1e-6 / (win[-1][0] - win[0][0])
+        out["energy_W"] = watts
+        out["energy_window_s"] = win[-1][0] - win[0][0]
+        out["energy_pJ_per_cell_step"] = watts * ret[0] / cell_steps * 1e12
+    return out
+
+
+def planes_equal(a, b) -> bool:
+    """Bit-for-bit equality of two HipConcentrations of one shape, compared on the device (the planes are
+    1 GiB each at 16384^2): int32 views, so that NaNs and signed zeros count as what they are."""
+    import torch
+
+    ok = True
+    for (_, _, x), (_, _, y) in zip(a.torch_views(), b.torch_views()):
+        ok = ok and bool(torch.equal(x.view(torch.int32), y.view(torch.int32)))
+    return ok
+
+
+def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_kernel):
+    """In-run proof that the timed launches did the work, and the HBM-bound single-step leg north_star asks the
+    rocprof evidence for.  A second context pinned to the single-step stream kernel (one launch = one step =
+    one read and one write of U and V: 16 B per cell-step of HBM traffic) starts from the same Species::new,
+    is timed over 5 regions of steps (`single_step`), then runs on to exactly the number of steps the timed
+    Species has taken -- tuning passes, warm-ups and every timed region included -- and both planes must be
+    equal bit for bit; the same for the developed pattern (same upload, same step count)."""
+    import statistics
+
+    ctx_s = sim_s.context
+    cells = rows * cols
+    n_region = max(40, min(400, int(0.08 * 3.5e11 / cells)))        # ~80 ms per region
+    n_region = min(n_region, max(1, (species.steps_done - 40) // 6))
+    sim_s.perform_steps(sp_s, n_region)                              # untimed: clocks, first touches
+    sp_s.steps_done += n_region
+    rates, launch_ms = [], []
+    for _ in range(5):
+        ctx_s.sync()
+        t0 = time.perf_counter()
+        ctx_s.timer_start()
+        sim_s.prepare_steps(sp_s, n_region)
+        ms = ctx_s.timer_stop()
+        ctx_s.sync()
+        wall = time.perf_counter() - t0
+        sp_s.steps_done += n_region
+        rates.append(cells * n_region / wall / 1e6)
+        launch_ms.append(ms / n_region)
+    rate = statistics.median(rates)
+    step_ms = statistics.median(launch_ms)
+    gbs = BYTES_PER_CELL_STEP * cells / (step_ms * 1e-3) / 1e9
+    label = ctx_s.info()[0]
+    pmc = measured_counters(label, rows, cols, (0, 0, 0))
+    single_step = {
+        "kernel": label,
+        "value": rate, "unit": "Mcells×steps/s", "values": [round(r) for r in rates], "steps_per_region": n_region,
+        "launch_ms": step_ms,                                    # HIP events on the library's stream, per launch
+        "hbm_GBps": gbs,                                         # algorithmic: 16 B per cell-step, one step per launch
+        "frac_of_8TBps": gbs / HBM_PEAK_GBS,
+        "frac_of_copy_ceiling": gbs / HBM_COPY_CEILING_GBS,
+        "traffic": pmc.get("traffic"),                           # HBM bytes per launch, PMC of the committed profile
+        "hbm_physical_GBps": pmc["traffic"] / (step_ms * 1e-3) / 1e9 if pmc.get("traffic") else None,
+        "profile_launch_ms": pmc.get("launch_ms"), "counters_source": pmc.get("source"),
+    }
+    left = species.steps_done - sp_s.steps_done
+    if left < 0:
+        raise RuntimeError(f"the replay is ahead of the timed Species ({sp_s.steps_done} > {species.steps_done} steps)")
+    sim_s.perform_steps(sp_s, left)
+    sp_s.steps_done += left
+    species.context().sync()
+    a, b = species.in_out(), sp_s.in_out()
+    verified = {"against": f"single-step kernel {label} in a second context, same start", "timed_kernel": timed_kernel,
+                "steps": species.steps_done,
+                "equal": planes_equal(a[0], b[0]) and planes_equal(a[1], b[1])}
+    if sp_dev is not None and sp_dev_s is not None:
+        sim_s.perform_steps(sp_dev_s, sp_dev.steps_done)
+        a, b = sp_dev.in_out(), sp_dev_s.in_out()
+        verified["developed_pattern"] = {"steps": sp_dev.steps_done,
+                                         "equal": planes_equal(a[0], b[0]) and planes_equal(a[1], b[1])}
+    return single_step, verified
+
+
+def range_checksums(view, block: int = 2048):
+    """Two wrapping int64 sums (plain, position-weighted) of the bit patterns of every `block` rows of a plane
+    view: a checksum of checksums for planes that live on different GPUs."""
+    import torch
+
+    out = []
+    for k0 in range(0, view.shape[0], block):
+        x = view[k0:k0 + block].view(torch.int32).to(torch.int64)
+        w = (torch.arange(x.numel(), device=x.device, dtype=torch.int64) % 65521 + 1).reshape(x.shape)
+        out.append((int(x.sum()), int((x * w).sum())))
+    return out
+
+
+def verify_slab_chain(species, rows, cols, rank, world, local_rank, rehearsal):
+    """N > 1: every rank checksums the rows it holds; rank 0 replays the WHOLE grid alone (a single slab on its
+    own GPU: 288 GB hold BASELINE config 5 several times over) for as many steps as the chain has taken and
+    checksums the same row ranges.  Equal sums = the exchanged ghost rows carried the right data on every seam."""
+    import torch.distributed as dist
+
+    from grayscott_amd import HipArgs, Parameters, Simulation
+
+    species.context().sync()
+    mine = []
+    for conc in species.in_out()[:2]:
+        for row0, nrows, view in conc.torch_views():
+            mine.append((row0, nrows, range_checksums(view)))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    result = None
+    if rank == 0:
+        solo = Simulation.new(Parameters(), HipArgs(devices=[local_rank]))
+        whole = solo.make_species([rows, cols])
+        solo.perform_steps(whole, species.steps_done)
+        views = [conc.torch_views()[0][2] for conc in whole.in_out()[:2]]
+        bad, blocks = [], 0
+        for r, parts in enumerate(gathered):
+            per_plane = len(parts) // 2
+            for i, (row0, nrows, sums) in enumerate(parts):
+                ref = range_checksums(views[i // per_plane][row0:row0 + nrows])
+                blocks += len(ref)
+                if ref != sums and r not in bad:
+                    bad.append(r)
+        solo.context.close()
+        result = {"against": "single-GPU run of the whole grid on rank 0 (row-block checksums of U and V)",
+                  "steps": species.steps_done, "equal": not bad, "blocks": blocks, "mismatching_ranks": bad}
+    return result
+
+
+class Watchdog:
+    """Per-rank stage timer.  `with wd.stage(name, seconds):` arms a bound; a daemon thread that finds it
+    exceeded prints ONE JSON line {"error", "rank", "stage", "bound_s"} and ends the process with exit code 3
+    (os._exit: the main thread may sit in ncclCommInitRank or a stream wait that never returns).  No restart,
+    no re-exec: torchrun sees the non-zero exit and takes the other ranks down.
+    GS_BENCH_WATCHDOG_S caps every bound (tests use a few seconds)."""
+
+    EXIT_CODE = 3
+
+    def __init__(self, rank: int = 0, out=None):
+        import threading
+
+        self.rank = rank
+        self.out = out or sys.stdout
+        self._lock = threading.Lock()
+        self._stage = None          # (name, deadline, bound)
+        cap = os.environ.get("GS_BENCH_WATCHDOG_S", "")
+        self._cap = float(cap) if cap else None
+        self._thread = threading.Thread(target=self._watch, daemon=True)
+        self._thread.start()
+
+    def _watch(self):
+        while True:
+            time.sleep(0.25)
+            with self._lock:
+                st = self._stage
+            if st and time.monotonic() > st[1]:
+                line = json.dumps({"error": f"stage '{st[0]}' exceeded its bound of {st[2]:.0f} s",
+                                   "rank": self.rank, "stage": st[0], "bound_s": st[2]})
+                try:
+                    self.out.write(line + "\n")
+                    self.out.flush()
+                finally:
+                    os._exit(self.EXIT_CODE)
+
+    def stage(self, name: str, seconds: float):
+        wd = self
+        bound = min(seconds, self._cap) if self._cap else seconds
+
+        class _Stage:
+            def __enter__(self_inner):
+                with wd._lock:
+                    wd._stage = (name, time.monotonic() + bound, bound)
+                fault = os.environ.get("GS_BENCH_FAULT", "")       # "stall:RANK:STAGE" (tests)
+                if fault.startswith("stall:"):
+                    _, r, st = fault.split(":")
+                    if int(r) == wd.rank and st == name:
+                        time.sleep(1e6)
+
+            def __exit__(self_inner, *exc):
+                with wd._lock:
+                    wd._stage = None
+                return False
+
+        return _Stage()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) without a torchrun environment: start `torch.distributed.run` as a
+    CHILD process -- before this process has touched a GPU or loaded libgs_hip.so -- relay its output (the one
+    JSON line) and return its exit code.  Never an exec of this process."""
+    import socket
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.rehearsal and not env.get("GS_RCCL_LIBRARY"):
+        # all ranks share GPU 0: RCCL refuses that, the library binds the shared-memory transport double
+        import shutil
+
+        out_dir = os.path.join(ROOT, "gpurun_out", "rehearsal")
+        os.makedirs(out_dir, exist_ok=True)
+        lib = os.path.join(out_dir, "libshm_transport.so")
+        cc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        r = subprocess.run([cc, "-O2", "-fPIC", "-shared", "-std=c++17", "-x", "hip", "--offload-arch=gfx950",
+                            os.path.join(ROOT, "tests", "cpp", "shm_transport.cpp"), "-o", lib, "-lrt", "-lpthread"],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            print("bench.py: building the rehearsal transport failed:\n" + r.stdout + r.stderr, file=sys.stderr)
+            return 2
+        env["GS_RCCL_LIBRARY"] = lib
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    limit = float(os.environ.get("GS_BENCH_CHILD_TIMEOUT_S", "1500"))
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)       # inherits stdout / stderr
+    try:
+        return child.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+
+        print(json.dumps({"error": f"the torchrun child exceeded {limit:.0f} s", "rank": -1, "stage": "child"}))
+        try:
+            os.killpg(child.pid, signal.SIGKILL)     # the session this process started, nothing else
+        except OSError:
+            pass
+        child.wait()
+        return 3
 
 
 def main() -> int:
@@ -242,95 +499,128 @@ def main() -> int:
                     help="timed regions of --steps steps each, back to back; `value` is their median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
-                    help="skip the informational legs (fused flavour, developed pattern)")
+                    help="skip the informational legs (fused flavour, developed pattern, clock / energy samples)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the replay that compares the timed planes with an independent run (and, on one GPU, "
+                         "the single-step HBM leg that is part of it)")
     ap.add_argument("--rehearsal", action="store_true",
-                    help="N > 1 on a 1-GPU box: all ranks share GPU 0 and torch.distributed uses gloo; needs "
-                         "GS_RCCL_LIBRARY to name a transport that accepts several ranks per device "
-                         "(tests/cpp/shm_transport.cpp).  Checks the code path, the numbers mean nothing")
+                    help="N > 1 on a 1-GPU box: all ranks share GPU 0 and torch.distributed uses gloo; the library "
+                         "binds a transport that accepts several ranks per device (tests/cpp/shm_transport.cpp, "
+                         "built on the fly unless GS_RCCL_LIBRARY names one).  Checks the code path, the numbers "
+                         "mean nothing")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
-    from grayscott_amd import HipArgs, Parameters, Simulation, capi
-    from grayscott_amd import dist as gsd
+    # N > 1 without a torchrun environment: this process is only the launcher of the torchrun CHILD -- decided
+    # before torch.cuda, the process group or libgs_hip.so exist in this process.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    wd = Watchdog(rank)
+
+    with wd.stage("import", 600):
+        import torch
+        import torch.distributed as dist
+
+        from grayscott_amd import HipArgs, Parameters, Simulation, capi
+        from grayscott_amd import dist as gsd
+
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus N > 1 must be launched with torch.distributed.run "
-                  "(one process per GPU)", file=sys.stderr)
-            return 2
         args.gpus = world
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         return 2
     if args.rehearsal:
         if world > 1 and not os.environ.get("GS_RCCL_LIBRARY"):
-            print("bench.py: --rehearsal needs GS_RCCL_LIBRARY", file=sys.stderr)
+            print("bench.py: --rehearsal under torchrun needs GS_RCCL_LIBRARY", file=sys.stderr)
             return 2
         local_rank = 0
     torch.cuda.set_device(local_rank)
     red_dev = "cpu" if args.rehearsal else "cuda"   # where the bootstrap / reduction tensors live
-
-    unique_id = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearsal:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        buf = torch.zeros(capi.GS_UNIQUE_ID_BYTES, dtype=torch.uint8, device=red_dev)
-        if rank == 0:
-            buf.copy_(torch.frombuffer(bytearray(capi.get_unique_id()), dtype=torch.uint8))
-        dist.broadcast(buf, src=0)
-        unique_id = bytes(buf.cpu().numpy().tobytes())
 
     rows, cols = grid_for(args.gpus, args.scaling)
     if args.grid:
         rows, cols = (int(x) for x in args.grid.lower().split("x"))
     if args.rows and args.cols:
         rows, cols = args.rows, args.cols
-    # The library's defaults, nothing pinned: one kernel launch per pass, so "launch" in the roofline
-    # object is unambiguous and comparable with rocprofv3's per-kernel average.
-    hip_args = HipArgs(devices=[local_rank], rank=rank, world=world, unique_id=unique_id)
-    sim = Simulation.new(Parameters(), hip_args)
+
+    # communicator creation: the process group, rank 0's RCCL unique id, ncclCommInitRank inside gs_ctx_create
+    with wd.stage("init", 300):
+        unique_id = None
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.rehearsal:
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+            buf = torch.zeros(capi.GS_UNIQUE_ID_BYTES, dtype=torch.uint8, device=red_dev)
+            if rank == 0:
+                buf.copy_(torch.frombuffer(bytearray(capi.get_unique_id()), dtype=torch.uint8))
+            dist.broadcast(buf, src=0)
+            unique_id = bytes(buf.cpu().numpy().tobytes())
+        # The library's defaults, nothing pinned: one kernel launch per pass, so "launch" in the roofline
+        # object is unambiguous and comparable with rocprofv3's per-kernel average.
+        hip_args = HipArgs(devices=[local_rank], rank=rank, world=world, unique_id=unique_id)
+        sim = Simulation.new(Parameters(), hip_args)
     ctx = sim.context
     cells = rows * cols
     cells_per_gpu = cells / args.gpus
     single = args.gpus == 1
     with_extra = single and not args.no_extra
+    verify = not args.no_verify
+
+    def run(sp, steps):
+        """perform_steps, counted: the replay at the end repeats exactly the steps a Species has taken."""
+        sim.perform_steps(sp, steps)
+        sp.steps_done += steps
 
     # Everything the timed regions touch exists BEFORE the first of them: the timed Species (Species::new on
     # the device, HBM-resident) and, for the co-headline, the developed pattern.  Nothing is allocated, freed
     # or filled between tuning and timing -- round 2's line read 8 % low because 4 GiB of planes were created
-    # in that gap and the first launches after it ran on an idle chip's clocks.
-    species = sim.make_species([rows, cols])
-    sp_dev = developed_species(sim, rows, cols) if with_extra else None     # 4000 steps: also tunes the context
-    tuned = (0, 0, 0)
-    if world == 1:
-        # gs_run chooses unit height / fused steps / columns per lane on line, from timed passes of the
-        # simulation itself (per context and shape).  It finishes here, on passes of the timed Species, so
-        # that neither the W warm-up steps nor the K timed ones contain tuning passes whatever W and K are.
-        for _ in range(8):
-            tuned = ctx.get_tuned(rows, cols)
-            if tuned[0] > 0:
-                break
-            sim.perform_steps(species, 400)
-    else:
-        # A slab chain does not tune on line: rank 0 tunes on a throw-away single slab of the slab's
-        # shape and every rank is handed the same configuration (grayscott_amd/dist.py).
-        tuned = gsd.share_tuning(sim, rows // world, cols, rank, world, device=red_dev, local_device=local_rank)
+    # in that gap and the first launches after it ran on an idle chip's clocks.  The same holds for the planes
+    # of the replay (single GPU: a second context pinned to the single-step stream kernel).
+    with wd.stage("setup", 900):
+        species = sim.make_species([rows, cols])
+        species.steps_done = 0
+        sp_dev, sim_s, sp_s, sp_dev_s = None, None, None, None
+        if single and verify:
+            sim_s = Simulation.new(Parameters(), HipArgs(devices=[local_rank], kernel=capi.GS_KERNEL_STREAM))
+            sp_s = sim_s.make_species([rows, cols])
+            sp_s.steps_done = 0
+        if with_extra:
+            u0, v0 = developed_start(rows, cols)
+            sp_dev = upload_species(sim, u0, v0)
+            if sim_s is not None:
+                sp_dev_s = upload_species(sim_s, u0, v0)
+            del u0, v0
+            run(sp_dev, 4000)                            # develops the pattern; also tunes the context
+        tuned = (0, 0, 0)
+        if world == 1:
+            # gs_run chooses unit height / fused steps / columns per lane on line, from timed passes of the
+            # simulation itself (per context and shape).  It finishes here, on passes of the timed Species, so
+            # that neither the W warm-up steps nor the K timed ones contain tuning passes whatever W and K are.
+            for _ in range(8):
+                tuned = ctx.get_tuned(rows, cols)
+                if tuned[0] > 0:
+                    break
+                run(species, 400)
+        else:
+            # A slab chain does not tune on line: rank 0 tunes on a throw-away single slab of the slab's
+            # shape and every rank is handed the same configuration (grayscott_amd/dist.py).
+            tuned = gsd.share_tuning(sim, rows // world, cols, rank, world, device=red_dev, local_device=local_rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
     def timed_run(sp, steps):
-        """(wall seconds, HIP-event ms, passes) of `steps` steps bracketed as the contract says."""
+        """(wall seconds, HIP-event ms, passes) of `steps` steps, bracketed as the contract says: barrier +
+        synchronize, clock, the steps, synchronize, clock, barrier.  The closing barrier is NOT inside the wall
+        time (it is an all-reduce of its own: 50-100 us per 5 ms region): the job's time is the maximum over
+        ranks of these walls, taken by repeated()."""
         ctx.sync()
         barrier()
         torch.cuda.synchronize()
@@ -341,8 +631,10 @@ def main() -> int:
         ms = ctx.timer_stop()
         ctx.sync()
         torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
         barrier()
-        return time.perf_counter() - t0, ms, ctx.stats()["passes"] - p0
+        sp.steps_done += steps
+        return wall, ms, ctx.stats()["passes"] - p0
 
     def repeated(sp, steps, repeats):
         """`repeats` timed regions of `steps` steps each, back to back; per region the maximum over ranks."""
@@ -366,7 +658,7 @@ def main() -> int:
         settles: with 18 ms here the first five 5-ms regions read 1-4 % low, profiles/r03_sweeps.md section 6.)"""
         rate = 1.2e12 if cells_per_gpu >= (1 << 24) else 5.0e11        # cell-steps per second, a high guess
         n = (max(24, int(0.12 * rate / cells_per_gpu)) + 11) // 12 * 12
-        sim.perform_steps(sp, n)                        # whole passes only, whatever the tuner fuses (2, 3 or 4 steps)
+        run(sp, n)                                      # whole passes only, whatever the tuner fuses (2, 3 or 4 steps)
         return n
 
     # A rehearsal of the timed region first: the first torch.cuda.synchronize() / barrier / HIP-event calls of a
@@ -376,10 +668,12 @@ def main() -> int:
     # that is not a whole number of passes (the driver's 5) ends in a single-step launch of another kernel, and the
     # chip, which sits on its power limit, answers that 0.7 ms change of load with a 20 ms dip -- the first four
     # 5-ms regions read 1-5 % low with W = 5 and not with W = 0, 4 or 8 (profiles/r03_sweeps.md, section 6).
-    timed_run(species, args.steps)
-    sim.perform_steps(species, args.warmup)
-    extra_warm_steps = warm(species)
-    runs = repeated(species, args.steps, args.repeats)
+    with wd.stage("timed", 600):
+        timed_run(species, args.steps)
+        run(species, args.warmup)
+        extra_warm_steps = warm(species)
+        untimed_before_first = species.steps_done       # tuning + rehearsal + W + warm: everything before region 0
+        runs = repeated(species, args.steps, args.repeats)
     wall, event_ms, passes = median_run(runs)
     walls = [r[0] for r in runs]
 
@@ -388,19 +682,20 @@ def main() -> int:
         # Per rank: its own launch time, and -- in an untimed repeat with HIP events on the halo and compute
         # streams (gs_ctx_set_pass_timing) -- whether the boundary band + ghost-row exchange hid behind the
         # interior kernel.  Then what RCCL itself says about the communicator, and where every rank runs.
-        _, my_ms, my_passes = median_run([timed_run(species, args.steps) for _ in range(3)])
-        n_timed = min(64, max(1, my_passes))
-        ctx.set_pass_timing(n_timed)
-        timed_run(species, args.steps)
-        st = ctx.stats()
-        ctx.set_pass_timing(0)
-        tp = max(1, st["timed_passes"])
-        mine = torch.tensor([my_ms / max(1, my_passes), st["halo_ms"] / tp, st["interior_ms"] / tp,
-                             st["halo_exposed_ms"] / tp, float(st["timed_passes"])] +
-                            [float(x) for x in ctx.comm_info()] + [float(local_rank)],
-                            dtype=torch.float64, device=red_dev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
+        with wd.stage("per-rank", 600):
+            _, my_ms, my_passes = median_run([timed_run(species, args.steps) for _ in range(3)])
+            n_timed = min(64, max(1, my_passes))
+            ctx.set_pass_timing(n_timed)
+            timed_run(species, args.steps)
+            st = ctx.stats()
+            ctx.set_pass_timing(0)
+            tp = max(1, st["timed_passes"])
+            mine = torch.tensor([my_ms / max(1, my_passes), st["halo_ms"] / tp, st["interior_ms"] / tp,
+                                 st["halo_exposed_ms"] / tp, float(st["timed_passes"])] +
+                                [float(x) for x in ctx.comm_info()] + [float(local_rank)],
+                                dtype=torch.float64, device=red_dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
         for r in allr:
             x = [float(v) for v in r.cpu()]
             per_rank.append({"launch_ms": x[0], "halo_stream_ms_per_pass": x[1], "interior_ms_per_pass": x[2],
@@ -465,36 +760,50 @@ def main() -> int:
         }
 
     roofline = roofline_of(event_ms, passes)
-    extra, developed, clocks = None, None, None
+    extra, developed, clocks, clocks_dev = None, None, None, None
     if with_extra:
-        # co-headline: the same kernel, same context, same launches on a developed spot pattern (the chip
-        # sustains a lower clock on non-trivial operands; BASELINE.md asks for "random/real data not zeros")
-        sim.perform_steps(sp_dev, args.warmup)
-        warm(sp_dev)
-        runs_dev = repeated(sp_dev, args.steps, args.repeats)
-        w_dev, ms_dev, p_dev = median_run(runs_dev)
-        developed = {"value": cells * args.steps / w_dev / 1e6,
-                     "value_min": cells * args.steps / max(r[0] for r in runs_dev) / 1e6,
-                     "value_max": cells * args.steps / min(r[0] for r in runs_dev) / 1e6,
-                     "repeats": len(runs_dev),
-                     "roofline": {k: v for k, v in roofline_of(ms_dev, p_dev).items()
-                                  if k in ("bound", "achieved", "peak", "unit", "frac", "frac_source", "valu", "useful_valu",
-                                           "hbm_physical", "algorithmic_GBps", "launch_ms")}}
-        # informational: shader clock and socket power while the same kernel runs (rocm-smi samples next to
-        # an untimed repeat of the timed run; the VALU roof is priced at the nominal 2.4 GHz, the chip
-        # sustains less on its power limit)
-        clocks = sample_clock_and_power(lambda: timed_run(species, max(args.steps, 8000)), local_rank)
-        # informational: the fused-tap flavour (GS_MATH_FUSED: bit-identical wherever no sub-normal
-        # intermediate occurs, |diff| <= 1e-37 elsewhere -- inside north_star's 1e-5 tolerance)
-        sim_c = Simulation.new(Parameters(), HipArgs(devices=[local_rank], math=capi.GS_MATH_FUSED))
-        species_c = sim_c.make_species([rows, cols])
-        sim_c.perform_steps(species_c, max(args.warmup, 400))
-        tc = time.perf_counter()
-        sim_c.perform_steps(species_c, args.steps)
-        tc = time.perf_counter() - tc
-        extra = {"kernel": sim_c.context.info()[0], "value": rows * cols * args.steps / tc / 1e6}
-        sim_c.context.close()
-        del species_c, sim_c
+        with wd.stage("extras", 900):
+            # co-headline: the same kernel, same context, same launches on a developed spot pattern (the chip
+            # sustains a lower clock on non-trivial operands; BASELINE.md asks for "random/real data not zeros")
+            run(sp_dev, args.warmup)
+            warm(sp_dev)
+            runs_dev = repeated(sp_dev, args.steps, args.repeats)
+            w_dev, ms_dev, p_dev = median_run(runs_dev)
+            developed = {"value": cells * args.steps / w_dev / 1e6,
+                         "value_min": cells * args.steps / max(r[0] for r in runs_dev) / 1e6,
+                         "value_max": cells * args.steps / min(r[0] for r in runs_dev) / 1e6,
+                         "repeats": len(runs_dev),
+                         "roofline": {k: v for k, v in roofline_of(ms_dev, p_dev).items()
+                                      if k in ("bound", "achieved", "peak", "unit", "frac", "frac_source", "valu", "useful_valu",
+                                               "hbm_physical", "algorithmic_GBps", "launch_ms")}}
+            # informational: shader clock, socket power and energy per cell-step while the same kernel runs
+            # (rocm-smi samples next to an untimed repeat of >= 3 s; the VALU roof is priced at the nominal
+            # 2.4 GHz, the chip sustains less on its power limit), on both inputs
+            long_steps = max(args.steps, int(3.2 * value * 1e6 / cells) // 12 * 12)
+            clocks = sample_clock_and_power(lambda: timed_run(species, long_steps), local_rank, cells * long_steps)
+            clocks_dev = sample_clock_and_power(lambda: timed_run(sp_dev, long_steps), local_rank, cells * long_steps)
+            # informational: the fused-tap flavour (GS_MATH_FUSED: bit-identical wherever no sub-normal
+            # intermediate occurs, |diff| <= 1e-37 elsewhere -- inside north_star's 1e-5 tolerance)
+            sim_c = Simulation.new(Parameters(), HipArgs(devices=[local_rank], math=capi.GS_MATH_FUSED))
+            species_c = sim_c.make_species([rows, cols])
+            sim_c.perform_steps(species_c, max(args.warmup, 400))
+            tc = time.perf_counter()
+            sim_c.perform_steps(species_c, args.steps)
+            tc = time.perf_counter() - tc
+            extra = {"kernel": sim_c.context.info()[0], "value": rows * cols * args.steps / tc / 1e6}
+            sim_c.context.close()
+            del species_c, sim_c
+
+    verified, single_step = None, None
+    if verify:
+        with wd.stage("verify", 900):
+            try:
+                if single:
+                    single_step, verified = verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, kernel_name)
+                else:
+                    verified = verify_slab_chain(species, rows, cols, rank, world, local_rank, args.rehearsal)
+            except Exception as e:                      # the line is still worth printing
+                verified = {"error": f"{type(e).__name__}: {e}"}
     result = {
         # BASELINE.json's metric, verbatim; `value` is its first quantity, the `roofline` object
         # carries the second
@@ -514,8 +823,13 @@ def main() -> int:
         "value_min": cells * args.steps / max(walls) / 1e6,
         "value_max": cells * args.steps / min(walls) / 1e6,
         "values": [round(cells * args.steps / w / 1e6) for w in walls],     # every timed region, in order
-        # untimed steps between the W warm-up steps and the first timed region (whole passes, >= 120 ms)
+        "value_first_region": cells * args.steps / walls[0] / 1e6,          # the plain "warm up, then time K" reading
+        # untimed steps between the W warm-up steps and the first timed region (whole passes, >= 120 ms) ...
         "untimed_steps_after_warmup": extra_warm_steps,
+        # ... and ALL steps this Species took before region 0: on-line tuning, the rehearsal region, W, the above
+        "untimed_steps_before_first_region": untimed_before_first,
+        "timing": "wall clock per region between barrier + synchronize brackets, closing barrier outside; "
+                  "maximum over ranks; median over regions",
         "config": {
             "workload": f"{rows}x{cols} f32 (rows x cols), Species::new init, default feed/kill, "
                         f"double-buffered U/V in HBM",
@@ -535,20 +849,40 @@ def main() -> int:
     if clocks:
         roofline["sclk_MHz_under_load"] = clocks["sclk_MHz"]
         roofline["socket_power_W_under_load"] = clocks["power_W"]
+        roofline["power_cap_W"] = clocks.get("power_cap_W")
         if roofline["valu"] and roofline["bound"] == "valu-issue":
             roofline["valu_at_sustained_clock"] = roofline["valu"] / (clocks["sclk_MHz"] / NOMINAL_SCLK_MHZ)
+        if clocks.get("energy_pJ_per_cell_step"):
+            result["energy_pJ_per_cell_step"] = clocks["energy_pJ_per_cell_step"]
+            roofline["energy_W_from_counter"] = clocks.get("energy_W")
+        cap, pw = clocks.get("power_cap_W"), clocks.get("energy_W") or clocks["power_W"]
+        if cap and pw and pw >= 0.96 * cap and roofline["bound"] == "valu-issue":
+            # the package sits on its power limit: what a faster instruction stream gains, the clock gives back
+            roofline["bound"] = "power-capped valu"
     if developed is not None:
         result["value_developed_pattern"] = developed["value"]
         result["developed_pattern"] = developed
+        if clocks_dev:
+            developed["sclk_MHz_under_load"] = clocks_dev["sclk_MHz"]
+            developed["socket_power_W_under_load"] = clocks_dev["power_W"]
+            developed["energy_pJ_per_cell_step"] = clocks_dev.get("energy_pJ_per_cell_step")
     if extra is not None:
         result["fused_flavour"] = extra
+    if single_step is not None:
+        result["single_step"] = single_step
+    if verified is not None:
+        result["verified"] = verified
     if rank == 0 and single and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline()
+        with wd.stage("cpu_baseline", 600):
+            result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(result, ensure_ascii=False))
-    ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+        print(json.dumps(result, ensure_ascii=False), flush=True)
+    with wd.stage("teardown", 120):
+        if sim_s is not None:
+            sim_s.context.close()
+        ctx.close()
+        if world > 1:
+            dist.destroy_process_group()
     return 0
 
 

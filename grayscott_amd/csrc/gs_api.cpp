@@ -24,6 +24,7 @@
 // timings of a phase of candidate configurations, a few times per context and shape).
 #include "../../include/gs_hip.h"
 #include "gs_kernels.h"
+#include "gs_experiments.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -361,6 +362,8 @@ int32_t refresh_ghosts(gs_ctx *ctx, gs_field *f)
             GS_TRY(push_halo(ctx, planes, 1, i, ctx->slabs[i].halo, depth));
         }
         GS_TRY(sync_all(ctx));
+        f->ghost_depth = depth; // what was exchanged: min(4, smallest slab)
+        return GS_OK;
     }
     f->ghost_depth = kGhostRows;
     return GS_OK;
@@ -536,7 +539,7 @@ int32_t launch_rows(gs_ctx *ctx, const GsStepArgs &a, hipStream_t stream, int fu
     if (e != hipSuccess) return fail(GS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     ctx->last_kernel = name;
     ctx->launches++;
-    static const bool trace = std::getenv("GS_HIP_TRACE_LAUNCH") != nullptr;
+    static const bool trace = gs_env_int("GS_HIP_TRACE_LAUNCH", 0, 0, 1) != 0;
     static int traced = 0;
     if (trace && traced < 64 && ++traced)
         std::fprintf(stderr, "gs_hip launch %s: slab of %d rows x %d cols, rows [%d, %d) + [%d, %d), unit %d rows, %d col/lane, %d step(s)\n",
@@ -563,7 +566,7 @@ GsStepArgs make_args(const gs_ctx *ctx, const gs_field *in_u, const gs_field *in
     a.rows_per_unit = pick_rows_per_unit(ctx, a.rows, a.cols, fuse);
     a.cpl = pick_cols_per_lane(ctx, a.rows, a.cols, fuse);
     a.allow_fair = ctx->total_slabs() == 1;
-    static const bool edge_kinds = !(std::getenv("GS_HIP_EDGE_KINDS") && std::atoi(std::getenv("GS_HIP_EDGE_KINDS")) == 0);
+    static const bool edge_kinds = gs_env_int("GS_HIP_EDGE_KINDS", 1, 0, 1) != 0;
     a.edge_kinds = edge_kinds;
     a.zero_halo = ctx->o.boundary == GS_BOUNDARY_ZERO_HALO;
     std::memcpy(a.w, ctx->p.w, sizeof a.w);
@@ -795,9 +798,10 @@ int32_t step_impl(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, 
     ctx->step_no++;
     ctx->passes++;
     ctx->steps_done += (uint64_t)fuse;
-    // (a chain exchanged min(4, smallest slab) rows; fuse never exceeds that)
-    out_u->ghost_depth = S > 1 ? kGhostRows : fuse;
-    out_v->ghost_depth = S > 1 ? kGhostRows : fuse;
+    // the depth actually exchanged: a chain pushed min(4, smallest slab) rows (fuse never exceeds that)
+    const int left = S > 1 ? (min_slab_rows(ctx, in_u) < kGhostRows ? min_slab_rows(ctx, in_u) : kGhostRows) : fuse;
+    out_u->ghost_depth = left;
+    out_v->ghost_depth = left;
     return GS_OK;
 }
 
@@ -1000,7 +1004,7 @@ int32_t tune_online(Run &r, int fuse)
                 hipEventElapsedTime(&w1, tu->events[3 * b + 1], tu->events[3 * b + 2]) != hipSuccess)
                 return fail(GS_ERR_HIP, "timing a tuning pass failed");
             const float ms = (w0 < w1 ? w0 : w1) / (float)(t.reps * t.k); // per time step
-            static const bool trace = std::getenv("GS_HIP_TRACE_TUNER") != nullptr;
+            static const bool trace = gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1) != 0;
             if (trace)
                 std::fprintf(stderr, "gs_hip tuner %llux%llu: unit %3d rows, %d band(s), %d steps/pass, %d col/lane: "
                                      "%.4f ms/step (windows %.3f %.3f ms)\n",
@@ -1119,7 +1123,7 @@ int32_t tune_online(Run &r, int fuse)
         const gs_ctx::Tuned done{f->rows, f->cols, fuse, tu->best_rpu, tu->best_split, tu->best_k, tu->best_cpl};
         remember_tuned(ctx, done);
         recall_tuned(ctx, f, fuse);
-        if (std::getenv("GS_HIP_TRACE_TUNER"))
+        if (gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1))
             std::fprintf(stderr, "gs_hip tuner %llux%llu: chose unit %d rows, %d steps/pass, %d col/lane\n",
                          (unsigned long long)f->rows, (unsigned long long)f->cols, done.rpu, done.k, done.cpl);
         for (auto e : tu->events)
@@ -1350,11 +1354,19 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
     // One slab per process is the deployment (one process per GPU).  A process of a chain may also hold
     // several consecutive slabs as long as they live on ONE device -- the communicator is bound to it -- which
     // is how an 8-slab chain is rehearsed on boxes that admit fewer processes than slabs.
-    if (world > 1)
+    if (world > 1) {
         for (int i = 1; i < n_local; ++i)
             if (device_ids[i] != device_ids[0])
                 return fail(GS_ERR_UNSUPPORTED, "a process of a multi-process chain drives slabs of one device "
                                                 "(one process per GPU); got devices %d and %d", device_ids[0], device_ids[i]);
+        // ... and only over a transport named with GS_RCCL_LIBRARY (the tests' double): with several local slabs the
+        // first and the last slab each issue their own send / recv group, from two streams, on the one communicator
+        // -- whether the real RCCL orders two streams on one communicator is version-dependent and was never run.
+        const char *user = std::getenv("GS_RCCL_LIBRARY");
+        if (n_local > 1 && !(user && *user))
+            return fail(GS_ERR_UNSUPPORTED, "several slabs per process of a multi-process chain are a rehearsal mode: "
+                                            "set GS_RCCL_LIBRARY to the transport to use, or run one slab per process");
+    }
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);

@@ -34,9 +34,10 @@
 //       lanes instead of halo loads.  ~16 B of HBM traffic per cell for K steps;
 //       VALU-issue bound for K >= 3.  Bit-identical to K single steps.
 //
-// GS_TB_ABLATE (1: no memory traffic, 2: no arithmetic) are timing experiments only
-// (profiles/r01_sweeps.md, "ablation"); the shipped build never defines it.
+// Build-time switches of A/B and diagnostic builds (none is set in the shipped build) and the run-time
+// GS_HIP_* switches of the launchers live in gs_experiments.h.
 #include "gs_kernels.h"
+#include "gs_experiments.h"
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -314,9 +315,6 @@ __device__ __forceinline__ void cell(const GsStepArgs &a, const Row &m, const Ro
         GS_ROW_TAPS_Z(p, 2, prow, true)
 #undef GS_ROW_TAPS_Z
     } else {
-        // Weight row of the centre row: 1 normally, 0 when the row above is clipped away.
-        // Weight column of the centre column: 1 normally, 0 when the left column is clipped.
-        // An absent left/right neighbour is replaced by the centre value (adds +0).
         // Weight row of the centre row: 1 normally, 0 when the row above is clipped away.
         // Weight column of the centre column: 1 normally, 0 when the left column is clipped.
         // An absent left/right neighbour is replaced by the centre value (adds +0).
@@ -630,9 +628,6 @@ struct RowT { // [0] = column c-1, [1..CPL] = own columns, [CPL+1] = column c+CP
 // issue slots; ds_bpermute_b32 goes through the LDS crossbar (no LDS memory, ~6 cycles per CU and
 // wave-instruction) and takes no VALU slot at all.  At 4 exchanges per row and level the crossbar is
 // ~40 % busy, so the exchange is free: +7 % at 16384^2 over the DPP form (GS_TB_XLANE=0, kept for A/B).
-#ifndef GS_TB_XLANE
-#define GS_TB_XLANE 1
-#endif
 #if GS_TB_XLANE
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 // lane i receives lane i-1's `own` (lane 0: lane 63's)
@@ -677,9 +672,6 @@ __device__ __forceinline__ RowT<CPL> widen_tb(const float (&u)[CPL], const float
 // bit for bit except that a zero comes out as +0 on both sides, and the accumulator, never -0, does not tell +0
 // from -0 (see half_diff).  So the right-hand tap of a cell is kept and SUBTRACTED as the left-hand tap of the next
 // cell: one instruction less per pair of neighbours, the reference's order of additions unchanged.
-#ifndef GS_TB_HSHARE
-#define GS_TB_HSHARE 1
-#endif
 template <int FAST, int CPL, int ZH>
 __device__ __forceinline__ void cells_interior(const GsStepArgs &a, const RowT<CPL> &m, const RowT<CPL> &z, const RowT<CPL> &p,
                                                float (&nu)[CPL], float (&nv)[CPL])
@@ -711,54 +703,17 @@ __device__ __forceinline__ void cells_interior(const GsStepArgs &a, const RowT<C
     }
 }
 
-template <int CPL> struct VecOf;
-template <> struct VecOf<4> { using type = float4; };
-template <> struct VecOf<2> { using type = float2; };
-template <> struct VecOf<1> { using type = float; };
-
-template <int CPL>
-__device__ __forceinline__ void load_cols(const float *p, float (&out)[CPL])
-{
-    const typename VecOf<CPL>::type x = *reinterpret_cast<const typename VecOf<CPL>::type *>(p);
-    __builtin_memcpy(out, &x, sizeof x);
-}
-template <int CPL>
-__device__ __forceinline__ void store_cols(float *p, const float (&in)[CPL])
-{
-    typename VecOf<CPL>::type x;
-    __builtin_memcpy(&x, in, sizeof x);
-    *reinterpret_cast<typename VecOf<CPL>::type *>(p) = x;
-}
-
-// Buffer-instruction forms of the same accesses: address = 128-bit resource in SGPRs (base pointer of
+// Buffer-instruction forms of the plane accesses: address = 128-bit resource in SGPRs (base pointer of
 // the unit's first row) + per-lane byte offset (one VGPR for the whole march) + scalar byte offset of
-// the row.  Interior units use them (GS_TB_BUFFER_OPS): no 64-bit per-lane addresses to keep or to
-// recompute per row.  The resource is raw (stride 0) with the widest record count: these units never
-// step outside their planes, so nothing relies on the range check.
-#ifndef GS_TB_BUFFER_OPS
-#define GS_TB_BUFFER_OPS 1
-#endif
-// GS_TB_LATE_FETCH: 1 = the K = 4 / 2-columns-per-lane march requests its next level-0 row at the END of a
-// tick (2 rows in flight while the levels are computed, not 3).  With that, the buffer addressing above
-// and the edge path's column masks kept as lane masks in SGPRs, the whole kernel entry -- general path
-// included -- fits 126 registers: 4 waves per SIMD instead of 3, +9 % at 16384^2 (profiles/r02_sweeps.md,
-// section 8).  Other layouts keep the early request: it is worth 2-6 % where the occupancy does not change.
-#ifndef GS_TB_LATE_FETCH
-#define GS_TB_LATE_FETCH 1
-#endif
+// the row: no 64-bit per-lane addresses to keep or to recompute per row.  The resource is raw (stride 0)
+// with the widest record count: the units never step outside their planes, so nothing relies on the
+// range check.  With them, the late fetch (GS_TB_LATE_FETCH, gs_experiments.h) and the edge path's column
+// masks kept as lane masks in SGPRs, the whole kernel entry -- general path included -- fits 126
+// registers: 4 waves per SIMD instead of 3, +9 % at 16384^2 (profiles/r02_sweeps.md, section 8).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
 }
-// GS_TB_AUX_LOAD / GS_TB_AUX_STORE: cache-policy bits of every plane access of the marching kernel (gfx950:
-// 1 = sc0, 2 = nt, 16 = sc1).  0 in the shipped build; 16 / 16 is the timing experiment "what would accesses that
-// other CUs can observe inside a launch cost" (profiles/r03_sweeps.md, section 3).
-#ifndef GS_TB_AUX_LOAD
-#define GS_TB_AUX_LOAD 0
-#endif
-#ifndef GS_TB_AUX_STORE
-#define GS_TB_AUX_STORE 0
-#endif
 template <int CPL>
 __device__ __forceinline__ void load_cols_buf(__amdgpu_buffer_rsrc_t r, int voff, int soff, float (&out)[CPL])
 {
@@ -790,24 +745,6 @@ __device__ __forceinline__ void store_cols_buf(__amdgpu_buffer_rsrc_t r, int vof
         __builtin_amdgcn_raw_buffer_store_b32(x, r, voff, soff, GS_TB_AUX_STORE);
     }
 }
-
-// GS_TB_TRACE (diagnostic builds only, tools/wave_timeline.py): every wave of gs_step_tb_k leaves five
-// timestamps of the 100 MHz real-time counter -- entry, first level-0 rows used (tick 3), level pipeline full
-// (tick 2K), last level-0 row taken (tick nticks - 2K), exit -- its hardware id and its unit in a device
-// buffer that gs_debug_trace_read() copies out.  The shipped build never defines it.
-#if defined(GS_TB_TRACE)
-constexpr int kTraceWords = 8, kTraceUnits = 1 << 17;
-__device__ unsigned long long gs_trace_buf[kTraceWords * kTraceUnits];
-__device__ __forceinline__ unsigned long long trace_now()
-{
-    unsigned long long t;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-}
-#define GS_TRACE_AT(COND, SLOT) do { if (COND) ts[SLOT] = trace_now(); } while (0)
-#else
-#define GS_TRACE_AT(COND, SLOT) do { } while (0)
-#endif
 
 // Fair progress in launches of about one round of wave slots (FAIR, 16-wave workgroups).  The SIMD's issue
 // arbitration is priority, then AGE: of four waves with equal work the two oldest take nearly every slot, and
@@ -841,15 +778,11 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
     const bool load_ok = !COLS || (c >= 0 && c < a.pitch);
     const bool store_ok = (lane >= S) && (lane < 64 - S) && (!COLS || c < a.pitch);
     const ptrdiff_t pitch = a.pitch;
-#if !GS_TB_BUFFER_OPS
-    const float *bu = a.in_u + c, *bv = a.in_v + c;
-#endif
 
     // Level-0 rows needed: [ur0 - K, ur1 + K) clipped to the rows that exist: the slab's own
     // rows plus, on a slab seam, `ghost` rows of the neighbouring slab.
     const int row_lo = max(ur0 - K, a.top_present ? -a.ghost : 0);
     const int row_hi = min(ur1 + K - 1, a.bottom_present ? a.rows + a.ghost - 1 : a.rows - 1);
-    constexpr bool BUF = GS_TB_BUFFER_OPS != 0;
     constexpr bool LATE = GS_TB_LATE_FETCH && K == 4 && CPL == 2;
     // resources based at the unit's first input row (row_lo) / first output row (ur0): scalar row offsets
     // stay small and positive whatever the size of the plane
@@ -859,36 +792,13 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
     auto fetch = [&](int row) {
         RowQ<CPL> r;
         const int rr = min(max(row, row_lo), row_hi);
-#if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 1 /* experiment: no loads (VALU-only timing) */
-        const float fr = (float)rr * a.du + (float)lane;
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) { r.u[i] = fr + a.dv * (float)i; r.v[i] = fr * a.dv - a.feed * (float)i; }
-        return r;
-#endif
-        if constexpr (BUF) {
-            if (load_ok) {
-#if defined(GS_TB_ABLATE) && GS_TB_ABLATE >= 3 /* experiment: every load hits the cache (8 rows per unit) */
-                load_cols_buf<CPL>(ru, voff, ((rr - row_lo) & 7) * pitch_bytes, r.u);
-                load_cols_buf<CPL>(rv, voff, ((rr - row_lo) & 7) * pitch_bytes, r.v);
-#else
-                load_cols_buf<CPL>(ru, voff, (rr - row_lo) * pitch_bytes, r.u);
-                load_cols_buf<CPL>(rv, voff, (rr - row_lo) * pitch_bytes, r.v);
-#endif
-            } else {
-#pragma unroll
-                for (int i = 0; i < CPL; ++i) { r.u[i] = 0.f; r.v[i] = 0.f; }
-            }
-            return r;
-        }
-#if !GS_TB_BUFFER_OPS
         if (load_ok) {
-            load_cols<CPL>(bu + (ptrdiff_t)rr * pitch, r.u);
-            load_cols<CPL>(bv + (ptrdiff_t)rr * pitch, r.v);
+            load_cols_buf<CPL>(ru, voff, (rr - row_lo) * pitch_bytes, r.u);
+            load_cols_buf<CPL>(rv, voff, (rr - row_lo) * pitch_bytes, r.v);
         } else {
 #pragma unroll
             for (int i = 0; i < CPL; ++i) { r.u[i] = 0.f; r.v[i] = 0.f; }
         }
-#endif
         return r;
     };
 
@@ -953,10 +863,6 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                         const bool mrow = !ROWS || (row > 0) || a.top_present;
                         const bool prow = !ROWS || (row + 1 < a.rows) || a.bottom_present;
                         float nu[CPL], nv[CPL];
-#if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 2 /* experiment: no arithmetic (memory-only timing) */
-#pragma unroll
-                        for (int k = 0; k < CPL; ++k) { nu[k] = z.u[k + 1] + m.u[k]; nv[k] = z.v[k + 1] + p.v[k + 2]; }
-#else
                         if constexpr (EDGE == 4) {
                             if (mrow && prow) {
                                 cells_interior<FAST, CPL, ZH>(a, m, z, p, nu, nv);
@@ -971,28 +877,11 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                             for (int k = 0; k < CPL; ++k)
                                 cell<EDGE, FAST, RowT<CPL>, ZH>(a, m, z, p, k + 1, mrow, prow, la[k], ra[k], nu[k], nv[k]);
                         }
-#endif
-#if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 1
                         if (j < K) {
-                            w[j < K ? j : 0][s3] = widen_tb<CPL>(nu, nv);
-                        } else if (store_ok && nu[0] == 12345.678f) {
-#else
-                        if (j < K) {
-                            w[j < K ? j : 0][s3] = widen_tb<CPL>(nu, nv);
+                            w[j][s3] = widen_tb<CPL>(nu, nv);
                         } else if (store_ok) {
-#endif
-                            if constexpr (BUF) {
-#if defined(GS_TB_ABLATE) && GS_TB_ABLATE == 4 /* experiment: ... and every store goes to the same 8 rows */
-                                store_cols_buf<CPL>(wu, voff, ((row - ur0) & 7) * pitch_bytes, nu);
-                                store_cols_buf<CPL>(wv, voff, ((row - ur0) & 7) * pitch_bytes, nv);
-#else
-                                store_cols_buf<CPL>(wu, voff, (row - ur0) * pitch_bytes, nu);
-                                store_cols_buf<CPL>(wv, voff, (row - ur0) * pitch_bytes, nv);
-#endif
-                            } else {
-                                store_cols<CPL>(a.out_u + (ptrdiff_t)row * pitch + c, nu);
-                                store_cols<CPL>(a.out_v + (ptrdiff_t)row * pitch + c, nv);
-                            }
+                            store_cols_buf<CPL>(wu, voff, (row - ur0) * pitch_bytes, nu);
+                            store_cols_buf<CPL>(wv, voff, (row - ur0) * pitch_bytes, nv);
                         }
                     }
                 }
@@ -1010,11 +899,7 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     // the quieting of signalling NaNs otherwise, which parity does not cover.
     if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0);
     constexpr int W = tb_cols_per_wave(K, CPL), S = tb_sacrificial_lanes(K, CPL);
-#if defined(GS_TB_WG16_PLAIN) /* timing experiment: 16-wave workgroups without the board */
-    constexpr bool FAIR = false;
-#else
     constexpr bool FAIR = WG == 16;
-#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, see above
     FairBoard fb{nullptr, 0, wave};
@@ -1118,6 +1003,7 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     const bool edge = left || right || ends;
 #if defined(GS_TB_TRACE)
     unsigned long long ts[5] = {trace_now(), 0, 0, 0, 0};
+    const unsigned long long cycles0 = __builtin_readcyclecounter(); // s_memtime: the shader clock's counter
 #define GS_TRACE_ARG , ts
 #else
 #define GS_TRACE_ARG
@@ -1145,6 +1031,7 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
 #undef GS_TB_LEAVE
 #if defined(GS_TB_TRACE)
     ts[4] = trace_now();
+    const unsigned long long cycles = __builtin_readcyclecounter() - cycles0;
     if (lane == 0 && unit < kTraceUnits) {
         unsigned long long *rec = gs_trace_buf + (size_t)unit * kTraceWords;
         for (int i = 0; i < 5; ++i) rec[i] = ts[i];
@@ -1152,7 +1039,8 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
         rec[5] = ((unsigned long long)xcc << 32) | hw;
         rec[6] = ((unsigned long long)(unsigned)ur0 << 32) | (unsigned)((ur1 - ur0) | (edge ? 0x40000000 : 0));
-        rec[7] = (unsigned)strip;
+        // shader cycles between entry and exit (in-kernel clock = cycles / (ts[4] - ts[0]) x 100 MHz) | strip
+        rec[7] = (cycles << 32) | (unsigned)strip;
     }
 #endif
 }
@@ -1235,17 +1123,10 @@ __device__ __forceinline__ void tile_steps(const GsStepArgs &a, float *lds, int 
 #pragma unroll
         for (int i = 0; i < RPW + 2; ++i) {
             const int d = (i - 1) * P;
-#if defined(GS_TILE_ABLATE) && (GS_TILE_ABLATE & 2) /* timing experiment: no LDS reads */
-            const float fu = u[(i + RPW - 1) % RPW], fv = v[(i + RPW - 1) % RPW];
-            R[i].u[0] = fu * a.dv; R[i].u[2] = fu + a.du; R[i].v[0] = fv * a.du; R[i].v[2] = fv + a.dv;
-            R[i].u[1] = fu; R[i].v[1] = fv;
-            (void)su; (void)sv; (void)d;
-#else
             R[i].u[0] = su[d - 1]; R[i].u[2] = su[d + 1];
             R[i].v[0] = sv[d - 1]; R[i].v[2] = sv[d + 1];
             if (i == 0 || i == RPW + 1) { R[i].u[1] = su[d]; R[i].v[1] = sv[d]; }
             else { R[i].u[1] = u[i - 1]; R[i].v[1] = v[i - 1]; }
-#endif
         }
         float nu[RPW], nv[RPW];
 #pragma unroll
@@ -1261,9 +1142,7 @@ __device__ __forceinline__ void tile_steps(const GsStepArgs &a, float *lds, int 
             float *du = lds + (cur ^ 1) * 2 * plane + o;
 #pragma unroll
             for (int i = 0; i < RPW; ++i) { du[i * P] = u[i]; du[plane + i * P] = v[i]; }
-#if !(defined(GS_TILE_ABLATE) && (GS_TILE_ABLATE & 1)) /* timing experiment: no barrier */
             __syncthreads();
-#endif
             cur ^= 1;
         }
     }
@@ -1547,7 +1426,7 @@ hipError_t GS_SUFFIX(gs_launch_tile)(const GsStepArgs &a, int k, int shape, hipS
     switch (shape) { GS_TILE_FN(0, 2) GS_TILE_FN(1, 1) GS_TILE_FN(2, 4) }
 #undef GS_TILE_FN
     size_t lds = tile_lds_bytes(rpw[shape]);
-    static const int lds_floor = std::getenv("GS_HIP_TILE_LDS_FLOOR") ? std::atoi(std::getenv("GS_HIP_TILE_LDS_FLOOR")) : 0;
+    static const int lds_floor = gs_env_int("GS_HIP_TILE_LDS_FLOOR", 0, 0, 160 * 1024);
     if (lds < (size_t)lds_floor) lds = (size_t)lds_floor; // experiment: limit the workgroups per CU
     { // more than 64 KB of dynamic LDS needs the opt-in, per device and device function
         const hipError_t e = ensure_dyn_lds(fn, lds);
@@ -1573,7 +1452,7 @@ hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const
     // time -- 16384^2 365 k -> 376 k (6.0 TB/s algorithmic), 4096^2 323 k -> 347 k, 1080 x 1920 171 k -> 186 k; 8192^2
     // unchanged on average (265-333 k from one context to the next either way: the four planes' placement decides).
     // Groups of 8 x 64 workgroups lose 6 % (profiles/r03_sweeps.md, section 12).  GS_HIP_XCD_M_STREAM = 0 / n: off / 8 n.
-    static const int xcd_env = std::getenv("GS_HIP_XCD_M_STREAM") ? std::atoi(std::getenv("GS_HIP_XCD_M_STREAM")) : -1;
+    static const int xcd_env = gs_env_int("GS_HIP_XCD_M_STREAM", -1, 0, kGsXcdGroupMax);
     args.xcd_m = xcd_env >= 0 ? xcd_env : 16;
     void *kargs[] = {&args};
     return hipLaunchKernel(reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_stream_k)<2>),
@@ -1631,7 +1510,7 @@ static int tb_waves_of(const void *f)
     } else {
         (void)hipGetLastError();
     }
-    if (std::getenv("GS_HIP_TRACE_TUNER"))
+    if (gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1))
         std::fprintf(stderr, "gs_hip: kernel entry %p: %d registers -> %d waves per SIMD\n", f, attr.numRegs, w);
     if (occ_n < 64) { occ_fn[occ_n] = f; occ_waves[occ_n++] = w; }
     return w;
@@ -1733,7 +1612,7 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // up the edge-first order does the job and halves only add recomputed rows: 8192^2 -1 %;
     // profiles/r02_sweeps.md, section 11).  The kernel's dispatch order: the outer strips of every chunk, then all strips of the
     // bottom `bot` and the top chunk row of range a, then the rest.
-    static const int split_env = std::getenv("GS_HIP_EDGE_SPLIT") ? std::atoi(std::getenv("GS_HIP_EDGE_SPLIT")) : -1;
+    static const int split_env = gs_env_int("GS_HIP_EDGE_SPLIT", -1, 0, 1);
     const long er = ((strips - 1) * W + tb_sacrificial_lanes(k, cpl) * cpl >= a.cols && strips >= 2) ? 2 : 1, ne = 1 + er;
     bool split = 4 * chunks * strips <= 5 * slots && rpu >= 2;
     if (split_env >= 0) split = split_env != 0;
@@ -1759,10 +1638,10 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // units 430 k / 390 k, 12 rows 465 k / 443 k, 16 rows 524 k / 514 k, 20 rows 565 k / 573 k, 40 rows 677 k / 705 k;
     // 2 columns per lane, 10 rows 523 k / 537 k, 15 rows 615 k / 633 k, 19 rows 687 k / 738 k, 38 rows 782 k / 865 k.
     // GS_HIP_FAIR = 0 / 1 forces it off / on.
-    static const int fair_env = std::getenv("GS_HIP_FAIR") ? std::atoi(std::getenv("GS_HIP_FAIR")) : -1;
+    static const int fair_env = gs_env_int("GS_HIP_FAIR", -1, 0, 1);
     const bool fair = a.allow_fair && units <= 4096 && units > 1024 && (fair_env < 0 ? (cpl == 2 || rpu >= 20) : fair_env != 0);
     const void *fair_fn = fair ? tb_entry(k, fast, cpl, 16) : nullptr;
-    static const int fair_from_env = std::getenv("GS_HIP_FAIR_FROM") ? std::atoi(std::getenv("GS_HIP_FAIR_FROM")) : -1;
+    static const int fair_from_env = gs_env_int("GS_HIP_FAIR_FROM", -1, 0, 256);
     args.fair_from = fair_from_env >= 0 ? fair_from_env : 0;
     void *kargs[] = {&args};
     if (fair_fn) {
@@ -1779,7 +1658,7 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // (68: 2.226 GiB) and run slower (-2 %, 136: -6 %: an XCD's share of the last groups is all tall or all short
     // units).  Launches of about one round keep the plain order: 1080 x 1920 loses 1.2 % with the renumbering
     // (profiles/r03_sweeps.md, section 12).  GS_HIP_XCD_M = 0 / n forces it off / to groups of 8 n.
-    static const int xcd_env = std::getenv("GS_HIP_XCD_M") ? std::atoi(std::getenv("GS_HIP_XCD_M")) : -1;
+    static const int xcd_env = gs_env_int("GS_HIP_XCD_M", -1, 0, kGsXcdGroupMax);
     args.xcd_m = xcd_env >= 0 ? xcd_env : (units >= 2 * slots ? 16 : 0);
     // the edge units at the head of the dispatch order stay dealt over all XCDs (they are the slow ones)
     args.xcd_first = (int32_t)(((chunks * ne * (args.edge_split == 2 ? 2 : 1) + 3) / 4 + 7) / 8 * 8);

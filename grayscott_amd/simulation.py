@@ -294,6 +294,21 @@ class HipConcentration:
             i += 1
         return out
 
+    def torch_views(self):
+        """Zero-copy torch views of the local slabs: ``[(global row0, rows, tensor [rows, cols])]`` with the row
+        pitch as stride (``__cuda_array_interface__``); for on-device comparisons and producers (a producer calls
+        ``mark_written``).  The library's streams are not torch's: ``context.sync()`` before reading."""
+        import torch
+
+        class _DeviceArray:
+            def __init__(self, address, rows, cols, pitch):
+                self.__cuda_array_interface__ = {"shape": (rows, cols), "typestr": "<f4", "data": (address, False),
+                                                 "version": 3, "strides": (pitch * 4, 4)}
+
+        cols = self._shape[1]
+        return [(row0, rows, torch.as_tensor(_DeviceArray(address, rows, cols, pitch), device=f"cuda:{device}"))
+                for address, pitch, row0, rows, device in self.device_slabs() if rows > 0 and cols > 0]
+
     def mark_written(self, context: HipContext) -> None:
         """``gs_field_mark_written``: cells were written through ``device_slabs`` addresses."""
         capi.check(context._lib.gs_field_mark_written(context.handle, self.handle))

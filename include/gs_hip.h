@@ -40,6 +40,22 @@
  *   inside a process, by RCCL ncclSend/ncclRecv between processes -- on a side stream,
  *   overlapped with the interior update.  The reference has no multi-device code; its
  *   in-process precedent is SimulateCpu::split_grid (compute/shared/src/cpu.rs:111-154).
+ *
+ * Environment
+ *   The library itself reads these variables (the host mirrors add one per gs_options field, GS_HIP_<FIELD>, as the
+ *   reference's CliArgs do with clap's `env`).  None of them changes results: every combination is bit-identical.
+ *     GS_RCCL_LIBRARY       library to bind instead of librccl (a custom RCCL build; the tests' shared-memory
+ *                           transport double).  An explicit choice never falls back to the system's librccl.
+ *     GS_HIP_TRACE_LAUNCH   1 = print the first 64 kernel launches (label, row ranges, layout) on stderr
+ *     GS_HIP_TRACE_TUNER    1 = print every timing window of gs_run's on-line tuner and what it chose
+ *   Launch-policy switches for A/B timing (defaults are the measured best; grayscott_amd/csrc/gs_experiments.h):
+ *     GS_HIP_EDGE_KINDS     0 = edge units of the marching kernel all take the general path
+ *     GS_HIP_EDGE_SPLIT     0 / 1 = never / always dispatch edge units as two half-height units
+ *     GS_HIP_FAIR           0 / 1 = never / always run one-round launches as in-step 16-wave workgroups
+ *     GS_HIP_FAIR_FROM      progress (0 ... 256) from which the in-step form steers wave priorities
+ *     GS_HIP_XCD_M          0 = plain workgroup order, n = XCD-aware renumbering in groups of 8 n workgroups
+ *     GS_HIP_XCD_M_STREAM   the same for the single-step kernel
+ *     GS_HIP_TILE_LDS_FLOOR least dynamic LDS (bytes) of the LDS-window kernel: limits its workgroups per CU
  */
 #ifndef GS_HIP_H
 #define GS_HIP_H
@@ -294,6 +310,11 @@ int32_t gs_ctx_set_pass_timing(gs_ctx *ctx, int32_t passes);
  * ("tb-k4/strict@32x2" = 4 fused steps, strict math, tuned: 32-row units, 2 row bands) and the number of
  * kernel launches so far. */
 int32_t gs_ctx_info(const gs_ctx *ctx, char *kernel_name, size_t cap, uint64_t *launches);
+
+/* Test hook, not for bindings: the key of the table that remembers on which (device, kernel entry) more than 64 KB
+ * of dynamic LDS were opted into -- 1 when (device, slot, bytes) is new (and is recorded), 0 when a launch on that
+ * device would skip the opt-in, -1 for a bad slot (tests/test_capi_cpu.py). */
+int32_t gs_debug_dyn_lds_key(int32_t device, int32_t slot, int32_t bytes);
 
 #ifdef __cplusplus
 }

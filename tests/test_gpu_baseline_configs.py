@@ -229,6 +229,68 @@ def test_inprocess_chain_full_size_vs_single_slab_and_oracle(built, rows, cols, 
     _release(single, ref)
 
 
+def fill_seeded(species, ctx):
+    """A pattern-forming start written on the device, a function of the row block alone (so every context gets the
+    same data): U = 1, V = 0, 12 x 12 seeds (U = 0.5, V = 0.25) on a 12-cell lattice with one seed per 40 000 cells
+    on average, 1 % noise everywhere -- the start of tools/soak.py and bench.py's developed pattern."""
+    import torch
+
+    in_u, in_v, _, _ = species.in_out()
+    cols = in_u.shape()[1]
+    for si, conc in enumerate((in_u, in_v)):
+        for row0, rows, view in plane_views(conc):
+            for k in range(row0 // CHUNK, (row0 + rows + CHUNK - 1) // CHUNK):
+                g = torch.Generator(device="cuda")
+                g.manual_seed(7_000_003 * (k + 1))
+                coarse = torch.rand((CHUNK // 12 + 1, cols // 12 + 1), generator=g, device="cuda") < 144.0 / 40000.0
+                mask = coarse.repeat_interleave(12, 0).repeat_interleave(12, 1)[:CHUNK, :cols]
+                g.manual_seed(9_000_011 * (k + 1) + si)
+                noise = torch.rand((CHUNK, cols), generator=g, device="cuda", dtype=torch.float32) * 0.01
+                base = torch.where(mask, 0.5, 1.0) if si == 0 else torch.where(mask, 0.25, 0.0)
+                lo, hi = max(k * CHUNK, row0), min((k + 1) * CHUNK, row0 + rows)
+                view[lo - row0:hi - row0].copy_((base.to(torch.float32) + noise)[lo - k * CHUNK:hi - k * CHUNK])
+        torch.cuda.synchronize()
+        conc.mark_written(ctx)
+
+
+def test_two_slab_chain_2000_steps_of_a_developing_pattern(built):
+    """BASELINE config 4's grid (32768 x 16384) over 2 slabs, a pattern-forming start, 2000 steps in uneven calls:
+    the seam under chaotic dynamics -- one stale or misplaced ghost row anywhere in ~500 exchanges changes bits
+    that the dynamics then spread -- against the single-slab run of the same grid, every word of U and V.
+    Spec: compute/naive/src/lib.rs:42-83; overlapping sub-grids: compute/shared/src/cpu.rs:111-154."""
+    import torch
+
+    from grayscott_amd import HipArgs, Parameters, Simulation
+
+    rows, cols, n_slabs = 32768, 16384, 2
+    calls = (997, 1003)
+    single = Simulation.new(Parameters(), HipArgs(devices=[0]))
+    ref = single.make_species([rows, cols])
+    fill_seeded(ref, single.context)
+    for n in calls:
+        single.perform_steps(ref, n)
+    chain, tuned = _make_chain(rows, cols, [0] * n_slabs)
+    sp = chain.make_species([rows, cols])
+    fill_seeded(sp, chain.context)
+    before = chain.context.stats()
+    for n in calls:
+        chain.perform_steps(sp, n)
+    st = chain.context.stats()
+    assert st["steps"] - before["steps"] == sum(calls)
+    assert st["ghost_refreshes"] - before["ghost_refreshes"] == 2, (before, st)     # the two written planes, once
+    torch.cuda.synchronize()
+    for name, a, b in (("U", ref.in_out()[0], sp.in_out()[0]), ("V", ref.in_out()[1], sp.in_out()[1])):
+        (_, _, whole), = plane_views(a)
+        for row0, nrows, view in plane_views(b):
+            assert torch.equal(view.view(torch.int32), whole[row0:row0 + nrows].view(torch.int32)), \
+                f"{name}: slab at row {row0} differs from the single-slab run after {sum(calls)} steps"
+        assert bool(torch.isfinite(whole[::61]).all())
+    (_, _, v), = plane_views(ref.in_out()[1])
+    assert float(v[16300:16460].max()) > 0.3           # the pattern is alive on the seam
+    _release(chain, sp)
+    _release(single, ref)
+
+
 # ---- N processes over the transport double -------------------------------------------------------------
 
 def _free_port():

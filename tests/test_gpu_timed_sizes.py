@@ -134,3 +134,34 @@ def test_default_schedule_4096_403_steps_vs_stream_and_oracle():
     inner = (slice(m, R1 - R0 - m), slice(m, C1 - C0 - m))
     assert_bits_equal(gu[R0:R1, C0:C1][inner], cu[inner], "crop U, 403 steps, default schedule")
     assert_bits_equal(gv[R0:R1, C0:C1][inner], cv[inner], "crop V, 403 steps, default schedule")
+
+
+def test_config3_as_written_10000_steps_vs_stream_kernel():
+    """BASELINE config 3 as written: 16384 x 16384 f32, Species::new, default feed/kill, double-buffered U/V in
+    HBM, 10 000 steps -- the library's default schedule in uneven calls (tuning passes, remainders, re-entry)
+    against the single-step stream kernel, every word of U and V, compared on the device.
+    Spec: compute/naive/src/lib.rs:42-83, compute/shared/src/cpu.rs:30-42."""
+    import torch
+
+    rows = cols = 16384
+    calls = (4001, 2999, 1777, 1223)
+    assert sum(calls) == 10000
+    prod = Simulation.new(Parameters(), HipArgs(devices=[0]))
+    sp = prod.make_species([rows, cols])
+    for n in calls:
+        prod.perform_steps(sp, n)
+    _assert_production(prod.context.info()[0])
+    ref = Simulation.new(Parameters(), HipArgs(devices=[0], kernel=capi.GS_KERNEL_STREAM))
+    sr = ref.make_species([rows, cols])
+    ref.perform_steps(sr, sum(calls))
+    assert ref.context.info()[0].startswith("stream")
+    torch.cuda.synchronize()
+    for name, a, b in (("U", sp.in_out()[0], sr.in_out()[0]), ("V", sp.in_out()[1], sr.in_out()[1])):
+        (_, _, x), = a.torch_views()
+        (_, _, y), = b.torch_views()
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), f"{name} differs after 10000 steps at 16384^2"
+        assert bool(torch.isfinite(x[::53]).all())
+    (_, _, v), = sp.in_out()[1].torch_views()
+    assert float(v.max()) > 0.3 and float((v > 0.1).sum()) > 1e4          # the seed has grown into a pattern
+    _destroy(prod, sp)
+    _destroy(ref, sr)
