@@ -503,6 +503,8 @@ def main() -> int:
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the replay that compares the timed planes with an independent run (and, on one GPU, "
                          "the single-step HBM leg that is part of it)")
+    ap.add_argument("--kernel", choices=("auto", "stream"), default="auto",
+                    help="diagnostics / profiles: `stream` pins the single-step HBM-bound kernel for the whole protocol")
     ap.add_argument("--rehearsal", action="store_true",
                     help="N > 1 on a 1-GPU box: all ranks share GPU 0 and torch.distributed uses gloo; the library "
                          "binds a transport that accepts several ranks per device (tests/cpp/shm_transport.cpp, "
@@ -563,7 +565,8 @@ def main() -> int:
             unique_id = bytes(buf.cpu().numpy().tobytes())
         # The library's defaults, nothing pinned: one kernel launch per pass, so "launch" in the roofline
         # object is unambiguous and comparable with rocprofv3's per-kernel average.
-        hip_args = HipArgs(devices=[local_rank], rank=rank, world=world, unique_id=unique_id)
+        hip_args = HipArgs(devices=[local_rank], rank=rank, world=world, unique_id=unique_id,
+                           kernel=capi.GS_KERNEL_STREAM if args.kernel == "stream" else capi.GS_KERNEL_AUTO)
         sim = Simulation.new(Parameters(), hip_args)
     ctx = sim.context
     cells = rows * cols

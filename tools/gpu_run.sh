@@ -4,6 +4,7 @@
 # Logs and JSON lines land under gpurun_out/TAG/ (scratch; what is to be judged is copied to profiles/).
 # A failing stage ends the call (no GPU step is started after a failed or timed-out one).
 # Stages:
+#   probe           what the GPU box has: Rust toolchain?, CPU share, rocm-smi's energy counter and power cap
 #   newtests        this round's new GPU tests first (fast failure)
 #   tests           the whole GPU suite
 #   bench           bench.py as the driver runs it (--steps 20 --warmup 5) and with its defaults
@@ -27,9 +28,16 @@ for stage in "$@"; do
   rest=${stage#*:}; [ "$rest" = "$stage" ] && rest=""
   echo "=== stage $stage ($(date +%T))"
   case $name in
+    probe)
+      # SURVEY 8(d) / BASELINE.md row C: is there a Rust toolchain (with an offline registry) on the GPU box?
+      { date -u; echo "--- command -v cargo rustc rustup"; command -v cargo rustc rustup || echo "none on PATH";
+        echo "--- ls ~/.cargo ~/.rustup /usr/local/cargo /opt/rust*"; ls -d ~/.cargo ~/.cargo/registry ~/.rustup /usr/local/cargo /usr/local/rustup /opt/rust* 2>&1;
+        echo "--- find / -name cargo -o -name rustc (maxdepth 4)"; find / -maxdepth 4 \( -name cargo -o -name rustc \) -not -path '/proc/*' 2>/dev/null | head; echo "(end)";
+        echo "--- nproc / cpu quota / memory"; nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; grep MemTotal /proc/meminfo;
+        echo "--- rocm-smi energy / power cap"; rocm-smi --showenergycounter --showmaxpower --showpower --showclocks 2>&1 | head -40; } > "$OUT/probe.txt" 2>&1; rc=0; cat "$OUT/probe.txt" ;;
     newtests)
-      timeout -k 10 1100 python -m pytest tests/test_gpu_baseline_configs.py tests/test_gpu_multiprocess.py tests/test_gpu_parity.py -m gpu -x -q \
-        -k "baseline_configs or full_size or several_local or never_refreshes or pass_timing or two_contexts or row_slabs or shm" \
+      timeout -k 10 1100 python -m pytest tests/test_gpu_bench_rehearsal.py tests/test_gpu_timed_sizes.py tests/test_gpu_baseline_configs.py -m gpu -x -q \
+        -k "rehearsal or stalled or config3 or developing" \
         > "$OUT/newtests.log" 2>&1; rc=$?; tail -15 "$OUT/newtests.log" ;;
     tests)
       timeout -k 10 1100 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; rc=$?; tail -8 "$OUT/pytest_gpu.log" ;;

@@ -24,11 +24,21 @@ from grayscott_amd import HipArgs, Parameters, Simulation, capi  # noqa: E402
 def main():
     rows, cols = int(sys.argv[1]), int(sys.argv[2])
     kw = {"devices": [0]}
+    developed = False
     for kv in sys.argv[3:]:
         k, v = kv.split("=")
+        if k == "developed":            # developed=1: bench.py's developed spot pattern instead of Species::new
+            developed = int(v) != 0
+            continue
         kw[k] = int(v)
     sim = Simulation.new(Parameters(), HipArgs(**kw))
-    sp = sim.make_species([rows, cols])
+    if developed:
+        import bench
+
+        sp = bench.upload_species(sim, *bench.developed_start(rows, cols))
+        sim.perform_steps(sp, 4000)
+    else:
+        sp = sim.make_species([rows, cols])
     for _ in range(8):
         sim.perform_steps(sp, 400)
         if "rows_per_block" in kw or sim.context.get_tuned(rows, cols)[0] > 0:
@@ -78,6 +88,14 @@ def main():
           f" at {800 // passes} steps per pass")
     print(f"waves recorded: {n} ({int(edge.sum())} edge units); launch span first entry -> last exit: {span:.2f} us; "
           f"gap to the period: {period - span:.2f} us")
+    # in-kernel clock: shader cycles (s_memtime) over real time (s_memrealtime, 100 MHz) between a wave's entry
+    # and exit (MI355X_MICROARCH.md, "DVFS give-back" item 6); waves shorter than 20 us are left out
+    cycles = (rec[:, 7] >> np.uint64(32)).astype(np.float64)
+    dur_us = (rec[:, 4].astype(np.int64) - rec[:, 0].astype(np.int64)) * 0.01
+    ok = (dur_us > 20.0) & (cycles > 0)
+    if ok.any():
+        print(f"in-kernel clock (cycles / real time per wave), MHz, percentiles 0/10/50/90/100: {pct(cycles[ok] / dur_us[ok])}"
+              f"  ({int(ok.sum())} waves)")
     print(f"distinct CUs {len(np.unique(cu_key))}, SIMDs {len(np.unique(simd_key))}; waves per SIMD min/median/max: "
           f"{pct(np.bincount(np.unique(simd_key, return_inverse=True)[1]), (0, 50, 100))}")
     print("percentiles 0/10/50/90/100 [us]:")
