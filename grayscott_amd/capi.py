@@ -78,8 +78,7 @@ class GsOptions(ctypes.Structure):
         ("boundary", ctypes.c_int32),
         ("no_tune", ctypes.c_int32),
         ("tile_shape", ctypes.c_int32),
-        ("halo_cus", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 3),
+        ("reserved", ctypes.c_int32 * 4),
     ]
 
 

@@ -1385,8 +1385,6 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
         st = fail(GS_ERR_INVALID, "cols_per_lane must be 0 (auto), 1, 2 or 4, not %d", ctx->o.cols_per_lane);
     if (st == GS_OK && (ctx->o.tile_shape < 0 || ctx->o.tile_shape > 3))
         st = fail(GS_ERR_INVALID, "tile_shape must be 0 (auto), 1 (32 x 64), 2 (16 x 64) or 3 (64 x 64), not %d", ctx->o.tile_shape);
-    if (st == GS_OK && (ctx->o.halo_cus < 0 || ctx->o.halo_cus > 8))
-        st = fail(GS_ERR_INVALID, "halo_cus must be 0 (off) to 8 compute units per XCD, not %d", ctx->o.halo_cus);
     if (st == GS_OK && ctx->o.boundary != GS_BOUNDARY_CLIPPED && ctx->o.boundary != GS_BOUNDARY_ZERO_HALO)
         st = fail(GS_ERR_INVALID, "unknown boundary rule %d", ctx->o.boundary);
     if (st != GS_OK) { delete ctx; return st; }
@@ -1415,20 +1413,10 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
         GS_HIP_B(hipSetDevice(sl.device));
         int least = 0, greatest = 0;
         GS_HIP_B(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        if (ctx->o.halo_cus > 0 && world * n_local > 1) {
-            // gs_options.halo_cus: the interior kernel's stream may not use the last `halo_cus` compute units of every
-            // XCD.  A queue's CU mask is dealt over the XCDs bit by bit (bit i: XCD i % 8, its CU i / 8), so the top
-            // 8 x halo_cus bits of the mask are those units.
-            const int cus = prop.multiProcessorCount;
-            const int xcds = 8, words = (cus + 31) / 32;
-            std::vector<uint32_t> mask((size_t)words, 0u);
-            const int keep = cus - xcds * ctx->o.halo_cus;
-            if (keep < xcds) return bail(fail(GS_ERR_INVALID, "halo_cus = %d leaves no compute unit on a device of %d", ctx->o.halo_cus, cus));
-            for (int b = 0; b < keep; ++b) mask[(size_t)(b / 32)] |= 1u << (b % 32);
-            GS_HIP_B(hipExtStreamCreateWithCUMask(&sl.compute, (uint32_t)words, mask.data()));
-        } else {
-            GS_HIP_B(hipStreamCreateWithPriority(&sl.compute, hipStreamNonBlocking, least));
-        }
+        // (A compute stream whose CU mask leaves 1 or 2 CUs per XCD to the halo stream was measured in round 4: 4 / 8
+        // slabs on one GPU ran at 0.59 / 0.40 of the unmasked chain with 1 CU per XCD left out, 0.65 / 0.74 with 2
+        // -- profiles/r04_sweeps.md, section 1 -- and is not offered.)
+        GS_HIP_B(hipStreamCreateWithPriority(&sl.compute, hipStreamNonBlocking, least));
         GS_HIP_B(hipStreamCreateWithPriority(&sl.halo, hipStreamNonBlocking, greatest));
         GS_HIP_B(hipStreamCreateWithFlags(&sl.copy, hipStreamNonBlocking));
         GS_HIP_B(hipEventCreateWithFlags(&sl.staged, hipEventDisableTiming));

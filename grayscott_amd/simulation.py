@@ -94,7 +94,6 @@ class HipArgs:
     boundary: int = field(default_factory=lambda: _env_int("GS_HIP_BOUNDARY", capi.GS_BOUNDARY_CLIPPED))
     no_tune: int = field(default_factory=lambda: _env_int("GS_HIP_NO_TUNE", 0))
     tile_shape: int = field(default_factory=lambda: _env_int("GS_HIP_TILE_SHAPE", 0))
-    halo_cus: int = field(default_factory=lambda: _env_int("GS_HIP_HALO_CUS", 0))
     rank: int = 0
     world: int = 1
     unique_id: Optional[bytes] = None
@@ -110,7 +109,6 @@ class HipArgs:
         o.boundary = self.boundary
         o.no_tune = self.no_tune
         o.tile_shape = self.tile_shape
-        o.halo_cus = self.halo_cus
         return o
 
 

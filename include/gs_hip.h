@@ -153,11 +153,7 @@ typedef struct gs_options {
     int32_t tile_shape;      /* GS_KERNEL_TILE: window of a workgroup, 1 = 32 rows x 64 columns, 2 = 16 x 64,       *
                               * 3 = 64 x 64; 0 = 32 x 64.  With kernel = TILE, fuse_steps (1..8, and less than  *
                               * half the window's rows) sets the steps per launch                          */
-    int32_t halo_cus;        /* slab chains: compute units per XCD that the interior kernel's stream leaves alone    *
-                              * (hipExtStreamCreateWithCUMask), so that the boundary-band kernel, the ghost-row copies *
-                              * and RCCL's kernels on the high-priority halo stream find a CU at once instead of      *
-                              * queueing behind ~100 us interior waves; 0 = off (default), at most 8                    */
-    int32_t reserved[3];
+    int32_t reserved[4];
 } gs_options;
 
 typedef struct gs_ctx gs_ctx;     /* devices, streams, row partition, RCCL communicator    */

@@ -33,8 +33,7 @@ pub struct gs_options {
     pub boundary: i32,
     pub no_tune: i32,
     pub tile_shape: i32,
-    pub halo_cus: i32,
-    pub reserved: [i32; 3],
+    pub reserved: [i32; 4],
 }
 
 #[repr(C)]

@@ -12,6 +12,7 @@
 #   sweep:RxC:STEPS:VARIANT;VARIANT...   tools/sweep.py (VARIANT = key=value,key=value)
 #   libsweep:NAME:RxC:STEPS:VARIANT;...  the same against grayscott_amd/variants/libgs_hip_NAME.so
 #   profile:TAG[:bench extra args]       tools/profile_gpu.sh
+#   energyprof      rocprofv3 PMC passes of tools/energy_table.py --profile (tools/summarize_energy.py reads them)
 #   configs         tools/baseline_configs.py
 #   criterion       tools/criterion_grid.py
 #   rehearsal       tools/rehearsal.sh
@@ -62,6 +63,16 @@ for stage in "$@"; do
     profile)
       IFS=: read -r ptag extra <<< "$rest"
       GS_BENCH_EXTRA="$extra" timeout -k 10 1100 bash tools/profile_gpu.sh "$ptag" 400 > "$OUT/profile_$ptag.log" 2>&1; rc=$?; tail -5 "$OUT/profile_$ptag.log" ;;
+    energyprof)
+      # per-flavour PMC counters of tools/energy_table.py (--profile: 40 steps per flavour), one pass per input
+      rc=0
+      for data in new developed; do
+        ( cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU \
+            --output-format csv -d "$OUT/energy_$data" -o energy -- python3 "$ROOT/tools/energy_table.py" --profile --data $data \
+            > "$OUT/energyprof_$data.log" 2>&1 ) || rc=$?
+        tail -3 "$OUT/energyprof_$data.log"
+        [ $rc -eq 0 ] || break
+      done ;;
     configs)
       timeout -k 10 1100 python tools/baseline_configs.py > "$OUT/baseline_configs.log" 2>&1; rc=$?; tail -30 "$OUT/baseline_configs.log" ;;
     criterion)
