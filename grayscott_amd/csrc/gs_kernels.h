@@ -71,6 +71,23 @@ struct GsStepArgs {
     float du, dv, feed, feed_plus_kill, dt;
 };
 
+// gs_launch_window_*: one persistent launch for a whole gs_run on grids of ONE round of register-resident windows.
+// Workgroup (tr, tc) owns rows [tr * HO, (tr + 1) * HO) x columns [tc * WO, (tc + 1) * WO) of the grid, HO = 16 * rpw
+// - 2 k, WO = 128 - 2 k, and keeps them plus a k-cell apron in registers; every k steps it stores the k-cell ring of its
+// owned cells into the exchange planes, raises its flag, waits for the flags of its (up to 8) neighbours and loads its
+// apron from their rings.  Exchange e uses the planes of parity e & 1.  The input planes are never written: a launch
+// that gives up (abort set) has destroyed nothing.
+struct GsWindowArgs {
+    float *xu[2], *xv[2]; // exchange planes: local row 0, column 0; the field planes' pitch, at least the grid's rows
+    int32_t *flags;       // one per workgroup; a workgroup that has finished exchange e holds epoch + e + 1
+    int32_t *abort;       // sticky: a poll ran out of patience (workgroups not co-resident); every workgroup then leaves
+    int32_t steps;        // time steps of this launch (>= 1)
+    int32_t k;            // steps per exchange: even, 2 ... 8, less than half the window's rows
+    int32_t epoch;        // flags left by earlier launches are <= epoch
+    int32_t tiles_r, tiles_c;
+    int32_t patience;     // polls before a workgroup gives up
+};
+
 // Launchers, one set per arithmetic flavour (see gs_math in include/gs_hip.h).  Each
 // returns the hipError_t of the launch.  `name` receives a static kernel-variant label.
 #define GS_DECLARE_LAUNCHERS(SUFFIX)                                                           \
@@ -80,6 +97,7 @@ struct GsStepArgs {
     hipError_t gs_launch_tb_##SUFFIX(const GsStepArgs &a, int k, hipStream_t s, const char **name); \
     hipError_t gs_launch_tile_##SUFFIX(const GsStepArgs &a, int k, int shape, hipStream_t s, const char **name); \
     hipError_t gs_launch_lds_##SUFFIX(const GsStepArgs &a, hipStream_t s, const char **name);  \
+    hipError_t gs_launch_window_##SUFFIX(const GsStepArgs &a, const GsWindowArgs &x, int rpw, hipStream_t s, const char **name); \
     int gs_tb_wave_slots_##SUFFIX(int k, int fast, int cpl);
 
 GS_DECLARE_LAUNCHERS(strict)

@@ -1193,6 +1193,254 @@ __global__ __launch_bounds__(kTileWaves * 64) void GS_SUFFIX(gs_run_tile_k)(GsSt
         }
     }
 }
+
+// ------------------------------------------------------------------------------------
+// Grids of ONE round of register-resident windows (1.5-4 M cells: the reference's default 1080 x 1920): the whole
+// gs_run in one persistent launch, aprons traded between workgroups inside it.
+//
+// At these sizes a pass of the marching kernel is 19 us for 4 steps of which ~9 are fixed (launch gap, dispatch,
+// first-rows burst, level-pipeline fill on memory latency) and its 10-row units recompute 30 % of their rows
+// (profiles/r03_sweeps.md, sections 1-4).  Here a workgroup of 16 waves owns a window of 16 * RPW rows x 128
+// columns for the whole run: a wave keeps RPW whole rows in registers, two columns per lane (10 cells per lane at
+// RPW = 5).  Per step the columns next to a lane's two come from the adjacent lanes (DPP wave shifts), only the
+// first and the last row of a wave's band go through LDS for the waves above and below (double-buffered by the
+// step's parity: one workgroup barrier per step, reached after the RPW - 2 rows that need nothing from other waves),
+// and every cell is updated by the same cell<> code as in every other kernel: bit-identical.  The window's outer K
+// cells are an apron: they lose their validity one ring per step.  After K steps the workgroup stores the K-cell
+// ring of the cells it OWNS (the window shrunk by K) into an exchange plane with sc1 stores, drains, raises its
+// flag, polls the flags of its up to 8 neighbours and reloads its apron from their rings with sc1 loads -- the
+// hand-off form MI355X_MICROARCH.md lists as valid for one workgroup per CU (one lane signals for all stores of the
+// workgroup behind a barrier; the polling wave joins a barrier before anybody loads; all stores and loads sc1),
+// measured for exactly this shape in tools/ubench/handoff_probe.hip: 4.3 us per exchange, no stale word.  Exchanges
+// alternate between two sets of exchange planes, so a workgroup that is one exchange ahead never overwrites what a
+// neighbour still has to read.  The input planes are only read and the output planes only written at the very end.
+// Every poll is bounded: a workgroup that runs out of patience (its neighbours are not resident: the GPU is shared
+// with another long-running kernel) sets a sticky abort word and every workgroup leaves; gs_sync reports it.
+// Edge windows use the cheap kinds of edge path of the marching kernel (cell<2>, cell<3>, general rows only for the
+// grid's first and last row) under the clipped rule and interior code over zeros under the zero-halo rule.
+// ------------------------------------------------------------------------------------
+constexpr int kWinCols = 128;              // window columns: 64 lanes x 2
+constexpr int kWinPitch = 132;             // floats per published row: window column c at index 2 + c, c = -1 ... 129
+constexpr int kWinWaves = 16;
+__host__ __device__ constexpr int win_rows(int rpw) { return kWinWaves * rpw; }
+// 2 buffers x 2 species x 16 waves x (first row, last row) x pitch
+__host__ __device__ constexpr size_t win_lds_bytes() { return (size_t)2 * 2 * kWinWaves * 2 * kWinPitch * sizeof(float); }
+
+// `n` time steps of a window.  EDGE / ZH as in tb_march: 0 = window inside the grid; 1 = general path; 2 / 3 = window
+// on the grid's left / right edge (touching neither top nor bottom); 4 = window on the top or bottom edge only.
+// `step` counts the steps of the launch (parity of the LDS buffer).
+template <int RPW, int EDGE, int FAST, int ZH>
+__device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, int n, int &step, int gr, int gc, int wave, int lane,
+                                             float (&u)[RPW][2], float (&v)[RPW][2])
+{
+    constexpr int P = kWinPitch;
+    constexpr bool COLS = EDGE == 1 || EDGE == 2 || EDGE == 3, ROWS = EDGE == 1 || EDGE == 4;
+    // row `which` (0 = first, 1 = last row of a wave's band) of wave w, species sp, buffer buf
+    auto row_of = [&](int buf, int sp, int w, int which) { return lds + ((((buf * 2 + sp) * kWinWaves + w) * 2 + which) * P) + 2 + 2 * lane; };
+    bool inside[RPW][2];
+    uint32_t la[2], ra[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        la[j] = ((EDGE == 1 || EDGE == 2) && j == 0 && gc == 0) ? 0xffffffffu : 0u; // gc is even: only a lane's first cell
+        ra[j] = ((EDGE == 1 || EDGE == 3) && (gc + j + 1 >= a.cols)) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+            inside[r][j] = EDGE == 0 || (gr + r >= 0 && gr + r < a.rows && gc + j >= 0 && gc + j < a.cols);
+    }
+    const int wa = wave > 0 ? wave - 1 : 0, wb = wave < kWinWaves - 1 ? wave + 1 : kWinWaves - 1;
+    auto widen = [](const float (&cu)[2], const float (&cv)[2]) {
+        RowT<2> w;
+        w.u[1] = cu[0]; w.u[2] = cu[1]; w.v[1] = cv[0]; w.v[2] = cv[1];
+        w.u[0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cu[1]), 0x138, 0xf, 0xf, true));
+        w.u[3] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cu[0]), 0x130, 0xf, 0xf, true));
+        w.v[0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cv[1]), 0x138, 0xf, 0xf, true));
+        w.v[3] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cv[0]), 0x130, 0xf, 0xf, true));
+        return w;
+    };
+    for (int s = 0; s < n; ++s, ++step) {
+        const int buf = step & 1;
+        *reinterpret_cast<float2 *>(row_of(buf, 0, wave, 0)) = make_float2(u[0][0], u[0][1]);
+        *reinterpret_cast<float2 *>(row_of(buf, 1, wave, 0)) = make_float2(v[0][0], v[0][1]);
+        *reinterpret_cast<float2 *>(row_of(buf, 0, wave, 1)) = make_float2(u[RPW - 1][0], u[RPW - 1][1]);
+        *reinterpret_cast<float2 *>(row_of(buf, 1, wave, 1)) = make_float2(v[RPW - 1][0], v[RPW - 1][1]);
+        RowT<2> R[RPW + 2]; // R[0]: the row above the band, R[1 + r]: its row r (old values), R[RPW + 1]: the row below
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) R[1 + r] = widen(u[r], v[r]);
+        auto update = [&](int r) {
+            const int row = gr + r; // wave-uniform
+            const bool mrow = !ROWS || row > 0, prow = !ROWS || row + 1 < a.rows;
+            float nu[2], nv[2];
+            if constexpr (EDGE == 0) {
+                cells_interior<FAST, 2, ZH>(a, R[r], R[r + 1], R[r + 2], nu, nv);
+            } else if constexpr (EDGE == 4) {
+                if (mrow && prow) {
+                    cells_interior<FAST, 2, ZH>(a, R[r], R[r + 1], R[r + 2], nu, nv);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) cell<1, FAST, RowT<2>, ZH>(a, R[r], R[r + 1], R[r + 2], 1 + j, mrow, prow, 0u, 0u, nu[j], nv[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) cell<EDGE, FAST, RowT<2>, ZH>(a, R[r], R[r + 1], R[r + 2], 1 + j, mrow, prow, la[j], ra[j], nu[j], nv[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u[r][j] = inside[r][j] ? nu[j] : 0.0f;
+                v[r][j] = inside[r][j] ? nv[j] : 0.0f;
+            }
+        };
+        // the rows that need nothing from other waves first: the other waves' rows arrive meanwhile
+#pragma unroll
+        for (int r = 1; r < RPW - 1; ++r) update(r);
+        __syncthreads();
+        {
+            const float *pu = row_of(buf, 0, wa, 1), *pv = row_of(buf, 1, wa, 1);
+            const float2 cu = *reinterpret_cast<const float2 *>(pu), cv = *reinterpret_cast<const float2 *>(pv);
+            R[0].u[0] = pu[-1]; R[0].u[1] = cu.x; R[0].u[2] = cu.y; R[0].u[3] = pu[2];
+            R[0].v[0] = pv[-1]; R[0].v[1] = cv.x; R[0].v[2] = cv.y; R[0].v[3] = pv[2];
+            const float *qu = row_of(buf, 0, wb, 0), *qv = row_of(buf, 1, wb, 0);
+            const float2 du = *reinterpret_cast<const float2 *>(qu), dv = *reinterpret_cast<const float2 *>(qv);
+            R[RPW + 1].u[0] = qu[-1]; R[RPW + 1].u[1] = du.x; R[RPW + 1].u[2] = du.y; R[RPW + 1].u[3] = qu[2];
+            R[RPW + 1].v[0] = qv[-1]; R[RPW + 1].v[1] = dv.x; R[RPW + 1].v[2] = dv.y; R[RPW + 1].v[3] = qv[2];
+        }
+        update(0);
+        if (RPW > 1) update(RPW - 1);
+    }
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t win_rsrc(const void *p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+template <int RPW, int FAST>
+__global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsStepArgs a, GsWindowArgs x)
+{
+    if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0); // half_diff: MODE.IEEE = 0
+    extern __shared__ float lds[];
+    __shared__ int go;
+    constexpr int H = win_rows(RPW), SC1 = 16;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = x.k;
+    const int HO = H - 2 * K, WO = kWinCols - 2 * K; // rows / columns a workgroup owns
+    const int wg = (int)blockIdx.x, tr = wg / x.tiles_c, tc = wg - tr * x.tiles_c;
+    const int gr0 = tr * HO - K, gc0 = tc * WO - K;         // global coordinates of window cell (0, 0)
+    const int gr = gr0 + wave * RPW, gc = gc0 + 2 * lane;   // this lane's first cell
+    const int wc = 2 * lane;                                // its window column
+    // a launch enqueued behind one that gave up leaves at once (nothing of it is valid anyway)
+    if (__builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(win_rsrc(x.abort), 0, 0, SC1)) != 0) return;
+    // columns -1 and 128 .. 129 of this wave's published rows are never written by a step; they are read into cells
+    // that are discarded, and zeroed once so that nothing depends on earlier contents of the LDS
+    if (lane < 3)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            lds[(((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + (lane == 0 ? 1 : 129 + lane)] = 0.0f;
+    float u[RPW][2], v[RPW][2];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const bool in = gr + r >= 0 && gr + r < a.rows && gc >= 0 && gc < a.cols;
+        v2f fu = {0.0f, 0.0f}, fv = {0.0f, 0.0f};
+        if (in) { // 8-byte loads: gc is even and the row pitch a multiple of 64 floats
+            const int off = ((gr + r) * a.pitch + gc) * (int)sizeof(float);
+            fu = __builtin_amdgcn_raw_buffer_load_b64(win_rsrc(a.in_u), off, 0, 0);
+            fv = __builtin_amdgcn_raw_buffer_load_b64(win_rsrc(a.in_v), off, 0, 0);
+        }
+        const bool in1 = in && gc + 1 < a.cols;
+        u[r][0] = fu[0]; u[r][1] = in1 ? fu[1] : 0.0f;
+        v[r][0] = fv[0]; v[r][1] = in1 ? fv[1] : 0.0f;
+    }
+    const bool left = gc0 <= 0, right = gc0 + kWinCols >= a.cols, ends = gr0 <= 0 || gr0 + H >= a.rows;
+    const bool edge = left || right || ends;
+    constexpr bool KINDS = (FAST & 1) && !GS_MATH_FUSED;
+    int step = 0;
+    const int supers = (x.steps + K - 1) / K;
+    for (int s = 0; s < supers; ++s) {
+        // the short super-step first
+        const int n = (s == 0 && x.steps % K) ? x.steps % K : K;
+        if (!edge)
+            window_steps<RPW, 0, FAST, -1>(a, lds, n, step, gr, gc, wave, lane, u, v);
+        else if (a.zero_halo)
+            window_steps<RPW, 1, FAST, 1>(a, lds, n, step, gr, gc, wave, lane, u, v);
+        else if (KINDS && a.edge_kinds && left && !right && !ends)
+            window_steps<RPW, KINDS ? 2 : 1, FAST, 0>(a, lds, n, step, gr, gc, wave, lane, u, v);
+        else if (KINDS && a.edge_kinds && right && !left && !ends)
+            window_steps<RPW, KINDS ? 3 : 1, FAST, 0>(a, lds, n, step, gr, gc, wave, lane, u, v);
+        else if (KINDS && a.edge_kinds && ends && !left && !right)
+            window_steps<RPW, KINDS ? 4 : 1, FAST, 0>(a, lds, n, step, gr, gc, wave, lane, u, v);
+        else
+            window_steps<RPW, 1, FAST, 0>(a, lds, n, step, gr, gc, wave, lane, u, v);
+        if (s == supers - 1) break;
+        // ---- exchange s: ring out, flag, poll, apron in -------------------------------------------------------
+        const __amdgpu_buffer_rsrc_t xu = win_rsrc(x.xu[s & 1]), xv = win_rsrc(x.xv[s & 1]);
+        const bool lane_owned = wc >= K && wc < kWinCols - K && gc < a.cols;
+        const bool lane_ring = wc < 2 * K || wc >= kWinCols - 2 * K;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int wr = wave * RPW + r; // wave-uniform
+            const bool row_owned = wr >= K && wr < H - K && gr + r < a.rows;
+            const bool row_ring = wr < 2 * K || wr >= H - 2 * K;
+            if (row_owned && lane_owned && (row_ring || lane_ring)) {
+                const int off = ((gr + r) * a.pitch + gc) * (int)sizeof(float);
+                const v2f su = {u[r][0], u[r][1]}, sv = {v[r][0], v[r][1]};
+                __builtin_amdgcn_raw_buffer_store_b64(su, xu, off, 0, SC1);
+                __builtin_amdgcn_raw_buffer_store_b64(sv, xv, off, 0, SC1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wave == 0) {
+            const int target = x.epoch + s + 1;
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(target, win_rsrc(x.flags), wg * 4, 0, SC1);
+            const int dy = lane / 3 - 1, dx = lane % 3 - 1, ny = tr + dy, nx = tc + dx;
+            const bool watch = lane < 9 && lane != 4 && ny >= 0 && ny < x.tiles_r && nx >= 0 && nx < x.tiles_c;
+            int ok = 1, spins = 0;
+            for (;;) {
+                const int seen = watch ? __builtin_amdgcn_raw_buffer_load_b32(win_rsrc(x.flags), (ny * x.tiles_c + nx) * 4, 0, SC1) : target;
+                if (!__builtin_amdgcn_ballot_w64(seen - target < 0)) break;
+                if (++spins > x.patience || __builtin_amdgcn_raw_buffer_load_b32(win_rsrc(x.abort), 0, 0, SC1) != 0) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (lane == 0) {
+                if (!ok) __builtin_amdgcn_raw_buffer_store_b32(1, win_rsrc(x.abort), 0, 0, SC1);
+                go = ok;
+            }
+        }
+        __syncthreads();
+        if (!go) return; // (workgroup-uniform)
+        const bool lane_apron = (wc < K || wc >= kWinCols - K) && gc >= 0 && gc < a.cols;
+        const bool lane_in = gc >= 0 && gc < a.cols;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int wr = wave * RPW + r;
+            const bool row_in = gr + r >= 0 && gr + r < a.rows;
+            const bool row_apron = wr < K || wr >= H - K;
+            if (row_in && ((row_apron && lane_in) || lane_apron)) {
+                const int off = ((gr + r) * a.pitch + gc) * (int)sizeof(float);
+                const v2f fu = __builtin_amdgcn_raw_buffer_load_b64(xu, off, 0, SC1);
+                const v2f fv = __builtin_amdgcn_raw_buffer_load_b64(xv, off, 0, SC1);
+                const bool in1 = gc + 1 < a.cols;
+                u[r][0] = fu[0]; u[r][1] = in1 ? fu[1] : 0.0f;
+                v[r][0] = fv[0]; v[r][1] = in1 ? fv[1] : 0.0f;
+            }
+        }
+    }
+    // the cells this workgroup owns, where they lie in the grid (8-byte stores; a second column beyond `cols` lands in
+    // the planes' padding columns, which nothing reads)
+    if (wc >= K && wc < kWinCols - K && gc < a.cols) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int wr = wave * RPW + r;
+            if (wr >= K && wr < H - K && gr + r < a.rows) {
+                const int off = ((gr + r) * a.pitch + gc) * (int)sizeof(float);
+                const v2f su = {u[r][0], u[r][1]}, sv = {v[r][0], v[r][1]};
+                __builtin_amdgcn_raw_buffer_store_b64(su, win_rsrc(a.out_u), off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(sv, win_rsrc(a.out_v), off, 0, 0);
+            }
+        }
+    }
+}
 #endif // !GS_TB_OP_ONLY
 
 #if !GS_TB_OP_ONLY
@@ -1435,6 +1683,38 @@ hipError_t GS_SUFFIX(gs_launch_tile)(const GsStepArgs &a, int k, int shape, hipS
     GsStepArgs args = a;
     void *kargs[] = {&args, &k};
     return hipLaunchKernel(fn, dim3((unsigned)tiles), dim3(kTileWaves * 64), kargs, lds, s);
+}
+
+// One persistent launch of gs_run_window_k: `x.steps` time steps of a single slab, in-planes -> out-planes.
+// rpw: rows per wave (window = 16 rpw rows x 128 columns); the caller sized x.tiles_r / x.tiles_c for it.
+hipError_t GS_SUFFIX(gs_launch_window)(const GsStepArgs &a, const GsWindowArgs &x, int rpw, hipStream_t s, const char **name)
+{
+    static const char *const names[2][2] = {{"window80x128/" GS_MATH_NAME, "window80x128/" GS_MATH_NAME ".op"},
+                                            {"window96x128/" GS_MATH_NAME, "window96x128/" GS_MATH_NAME ".op"}};
+    if (a.rows <= 0 || a.cols <= 0 || a.top_present || a.bottom_present || (rpw != 5 && rpw != 6) || x.steps < 1 || x.k < 2 ||
+        x.k > 8 || (x.k & 1) || 2 * x.k >= win_rows(rpw) || !x.flags || !x.abort || !x.xu[0] || !x.xu[1] || !x.xv[0] || !x.xv[1])
+        return hipErrorInvalidValue;
+    const long ho = win_rows(rpw) - 2 * x.k, wo = kWinCols - 2 * x.k;
+    if (x.tiles_r != (a.rows + ho - 1) / ho || x.tiles_c != (a.cols + wo - 1) / wo) return hipErrorInvalidValue;
+    // byte offsets inside a plane are 32-bit in the kernel
+    if ((long)(a.rows + 8) * a.pitch * 4 > 0x7fffffffL) return hipErrorInvalidValue;
+    int fast = a.fast & (GS_MATH_FUSED ? 0 : 3);
+    if (fast != 3) fast = 0; // only the variant for the default parameters is built besides the general one
+    if (name) *name = names[rpw == 5 ? 0 : 1][fast ? 1 : 0];
+    const void *fn = nullptr;
+#define GS_WIN_FN(R) (fast ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_window_k)<R, GS_MATH_FUSED ? 0 : 3>) \
+                           : reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_window_k)<R, 0>))
+    fn = rpw == 5 ? GS_WIN_FN(5) : GS_WIN_FN(6);
+#undef GS_WIN_FN
+    const size_t lds = win_lds_bytes();
+    { // more than 64 KB of dynamic LDS needs the opt-in, per device and device function
+        const hipError_t e = ensure_dyn_lds(fn, lds);
+        if (e != hipSuccess) return e;
+    }
+    GsStepArgs args = a;
+    GsWindowArgs xa = x;
+    void *kargs[] = {&args, &xa};
+    return hipLaunchKernel(fn, dim3((unsigned)(x.tiles_r * x.tiles_c)), dim3(kWinWaves * 64), kargs, lds, s);
 }
 
 hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const char **name)
