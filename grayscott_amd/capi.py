@@ -23,7 +23,7 @@ GS_ERR_UNSUPPORTED = -5
 GS_ERR_NOMEM = -6
 
 GS_MATH_STRICT, GS_MATH_FUSED = 0, 1
-GS_KERNEL_AUTO, GS_KERNEL_SIMPLE, GS_KERNEL_STREAM, GS_KERNEL_TB, GS_KERNEL_LDS, GS_KERNEL_TILE = 0, 1, 2, 3, 4, 5
+GS_KERNEL_AUTO, GS_KERNEL_SIMPLE, GS_KERNEL_STREAM, GS_KERNEL_TB, GS_KERNEL_LDS, GS_KERNEL_TILE, GS_KERNEL_WINDOW = 0, 1, 2, 3, 4, 5, 6
 GS_BOUNDARY_CLIPPED, GS_BOUNDARY_ZERO_HALO = 0, 1
 GS_UNIQUE_ID_BYTES = 128
 

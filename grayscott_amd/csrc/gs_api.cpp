@@ -211,6 +211,17 @@ struct gs_ctx {
     } graph_key;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    // gs_run_window_k (one persistent launch per gs_run on grids of one round of windows): exchange planes, flags and
+    // the abort word, sized for one plane shape at a time (single-slab contexts only)
+    struct WindowRt {
+        float *planes[4] = {nullptr, nullptr, nullptr, nullptr}; // xu[0], xu[1], xv[0], xv[1]
+        int32_t *words = nullptr;                                // kWindowMaxTiles flags, then the abort word
+        uint64_t rows = 0, pitch = 0;
+        int32_t epoch = 0;
+        bool pending = false;  // a launch has been enqueued since the abort word was last read
+        bool disabled = false; // a launch gave up once: this context stays with the marching kernel
+    } win;
+    int cu_count = 0; // compute units of the first slab's device
     int total_slabs() const { return world * (int)slabs.size(); }
     int global_index(int i) const { return rank * (int)slabs.size() + i; }
 };
@@ -232,6 +243,7 @@ struct gs_field {
 
 namespace {
 
+constexpr int kWindowMaxTiles = 1024; // flags of gs_run_window_k (one per workgroup; a launch has at most one per CU)
 constexpr int kGuardFloats = 64; // 256 B in front of / behind every plane
 constexpr int kGhostRows = 4;    // ghost rows kept above and below every slab (= max fused steps)
 
@@ -279,6 +291,22 @@ int32_t sync_all(gs_ctx *ctx)
         GS_HIP(hipSetDevice(b.device));
         GS_HIP(hipStreamSynchronize(b.halo));
         GS_HIP(hipStreamSynchronize(b.compute));
+    }
+    if (ctx->win.pending) {
+        // Did a persistent window launch give up?  (Its workgroups poll each other's flags with bounded patience;
+        // they only run out of it when they are not all resident, i.e. when another long-running kernel holds CUs.)
+        ctx->win.pending = false;
+        int32_t gave_up = 0;
+        GS_HIP(hipSetDevice(ctx->slabs[0].device));
+        GS_HIP(hipMemcpy(&gave_up, ctx->win.words + kWindowMaxTiles, sizeof gave_up, hipMemcpyDeviceToHost));
+        if (gave_up) {
+            GS_HIP(hipMemset(ctx->win.words, 0, (kWindowMaxTiles + 1) * sizeof(int32_t)));
+            ctx->win.epoch = 0;
+            ctx->win.disabled = true;
+            return fail(GS_ERR_HIP, "a persistent window launch gave up waiting for a neighbouring workgroup (is another "
+                                    "long-running kernel resident on this GPU?): the steps of the last gs_run were not "
+                                    "taken, its input planes are intact; this context now uses the marching kernel");
+        }
     }
     return GS_OK;
 }
@@ -514,7 +542,7 @@ int32_t model_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int f
 int32_t launch_rows(gs_ctx *ctx, const GsStepArgs &a, hipStream_t stream, int fuse)
 {
     int32_t kernel = ctx->o.kernel;
-    if (kernel == GS_KERNEL_AUTO || kernel == GS_KERNEL_TILE) kernel = fuse > 1 ? GS_KERNEL_TB : GS_KERNEL_STREAM;
+    if (kernel == GS_KERNEL_AUTO || kernel == GS_KERNEL_TILE || kernel == GS_KERNEL_WINDOW) kernel = fuse > 1 ? GS_KERNEL_TB : GS_KERNEL_STREAM;
     if (fuse > 1 && kernel != GS_KERNEL_TB)
         return fail(GS_ERR_UNSUPPORTED, "only the temporally blocked kernel fuses steps");
     const bool fused = ctx->o.math == GS_MATH_FUSED;
@@ -603,6 +631,54 @@ void pick_tile_config(long rows, long cols, int *shape, int *k)
             const double us_per_step = (launch_us[sh] + kk * step_us[sh] * rounds) / kk;
             if (best == 0.0 || us_per_step < best) { best = us_per_step; *shape = sh; *k = kk; }
         }
+}
+
+// ---- gs_run_window_k: grids of one round of register-resident windows ----------------------------------------
+// Window (rows per wave) and steps per exchange for a grid, or false when the grid is not one round of workgroups:
+// a workgroup owns (16 rpw - 2 k) x (128 - 2 k) cells and there is one workgroup per CU at most, all of them resident
+// for the whole launch.  Work per step is proportional to rpw (every CU updates its whole 16 rpw x 128 window), so the
+// smallest window that covers the grid wins; k = 4 is the measured balance between apron work (window cells outside
+// the owned ones: 16 % at 80 x 128) and exchanges (4.3 us each, tools/ubench/handoff_probe.hip).
+bool pick_window_config(const gs_ctx *ctx, uint64_t rows, uint64_t cols, int want_rpw, int want_k, int *rpw, int *k)
+{
+    if (ctx->cu_count <= 0 || rows == 0 || cols == 0 || rows > 0x7fffff || cols > 0x7fffff) return false;
+    const int kk = want_k > 0 ? want_k : 4;
+    if (kk < 2 || kk > 8 || (kk & 1)) return false;
+    for (int r : {5, 6}) {
+        if (want_rpw > 0 && want_rpw != r) continue;
+        const long ho = 16L * r - 2 * kk, wo = 128L - 2 * kk;
+        const long tiles = (long)((rows + ho - 1) / ho) * (long)((cols + wo - 1) / wo);
+        if (tiles <= ctx->cu_count && tiles <= kWindowMaxTiles) { *rpw = r; *k = kk; return true; }
+    }
+    return false;
+}
+
+// Exchange planes, flags and abort word for planes of this shape (allocated on first use, re-made when the shape changes).
+int32_t ensure_window_rt(gs_ctx *ctx, const gs_field *f)
+{
+    gs_ctx::WindowRt &w = ctx->win;
+    GS_HIP(hipSetDevice(ctx->slabs[0].device));
+    if (!w.words) {
+        GS_HIP(hipMalloc(reinterpret_cast<void **>(&w.words), (kWindowMaxTiles + 1) * sizeof(int32_t)));
+        GS_HIP(hipMemset(w.words, 0, (kWindowMaxTiles + 1) * sizeof(int32_t)));
+        w.epoch = 0;
+    }
+    if (w.rows != f->rows || w.pitch != (uint64_t)f->pitch || !w.planes[0]) {
+        GS_TRY(sync_all(ctx)); // nothing may still be exchanging through the old planes
+        for (auto &p : w.planes) {
+            if (p) GS_HIP(hipFree(p));
+            p = nullptr;
+        }
+        const size_t bytes = (size_t)(f->rows + 1) * (size_t)f->pitch * sizeof(float);
+        for (auto &p : w.planes) GS_HIP(hipMalloc(reinterpret_cast<void **>(&p), bytes));
+        w.rows = f->rows;
+        w.pitch = (uint64_t)f->pitch;
+    }
+    if (w.epoch > (1 << 30)) { // keep flag arithmetic far from wrapping: start over behind everything enqueued
+        GS_HIP(hipMemsetAsync(w.words, 0, kWindowMaxTiles * sizeof(int32_t), ctx->slabs[0].compute));
+        w.epoch = 0;
+    }
+    return GS_OK;
 }
 
 // ---- in-place row bands of a single slab -------------------------------------------------
@@ -1330,6 +1406,11 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
             if (b.halod[k]) (void)hipEventDestroy(b.halod[k]);
         }
     }
+    if (!ctx->slabs.empty() && (ctx->win.words || ctx->win.planes[0]) && hipSetDevice(ctx->slabs[0].device) == hipSuccess) {
+        for (auto p : ctx->win.planes)
+            if (p) (void)hipFree(p);
+        if (ctx->win.words) (void)hipFree(ctx->win.words);
+    }
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     if (ctx->band_join) (void)hipEventDestroy(ctx->band_join);
@@ -1401,6 +1482,7 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, sl.device) != hipSuccess)
             return bail(fail(GS_ERR_HIP, "hipGetDeviceProperties(%d) failed", sl.device));
+        if (i == 0) ctx->cu_count = prop.multiProcessorCount;
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return bail(fail(GS_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
                              sl.device, prop.gcnArchName));
@@ -1664,7 +1746,8 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     // Temporal blocking: `fuse` steps per pass over HBM (default 4, the measured optimum);
     // bounded by the ghost depth and by the smallest slab of the partition.
     int fuse = 1;
-    if (ctx->o.kernel == GS_KERNEL_AUTO || ctx->o.kernel == GS_KERNEL_TB || ctx->o.kernel == GS_KERNEL_TILE) {
+    if (ctx->o.kernel == GS_KERNEL_AUTO || ctx->o.kernel == GS_KERNEL_TB || ctx->o.kernel == GS_KERNEL_TILE ||
+        ctx->o.kernel == GS_KERNEL_WINDOW) {
         fuse = ctx->o.fuse_steps > 0 ? ctx->o.fuse_steps : kGhostRows;
         if (fuse > kGhostRows) fuse = kGhostRows;
         if (ctx->total_slabs() > 1 && fuse > min_slab_rows(ctx, u0)) fuse = min_slab_rows(ctx, u0);
@@ -1748,6 +1831,66 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
         ctx->last_kernel = full_name;
         if (result_slot) *result_slot = slot;
         return GS_OK;
+    }
+    // Grids of one round of register-resident windows (single slab; the reference's default 1080 x 1920): the whole
+    // call is ONE persistent launch of gs_run_window_k, which trades the windows' aprons between workgroups itself
+    // every k steps.  kernel = auto takes it from the LDS-window kernel's upper end (1.5 M cells) up to the largest grid
+    // that is one workgroup per CU (3.2 M cells on 256 CUs) when nothing is pinned; GS_KERNEL_WINDOW forces it
+    // (fuse_steps = steps per exchange, rows_per_block = window rows: 80 or 96).
+    {
+        int rpw = 0, wk = 0;
+        const bool forced = ctx->o.kernel == GS_KERNEL_WINDOW;
+        const bool automatic = ctx->o.kernel == GS_KERNEL_AUTO && ctx->o.fuse_steps == 0 && ctx->o.rows_per_block == 0 &&
+                               ctx->o.cols_per_lane == 0 && ctx->o.split <= 1 && !ctx->o.use_graph && cells >= kTileAutoCells &&
+                               !ctx->win.disabled;
+        if (single && cells > 0 && steps > 0 && (forced || automatic) &&
+            pick_window_config(ctx, u0->rows, u0->cols, forced && ctx->o.rows_per_block > 0 ? ctx->o.rows_per_block / 16 : 0,
+                               forced ? ctx->o.fuse_steps : 0, &rpw, &wk)) {
+            SlabRt &sl = ctx->slabs[0];
+            GS_HIP(hipSetDevice(sl.device));
+            GS_TRY(join_bands(ctx, sl.compute));
+            ctx->bands_active = false;
+            GS_TRY(ensure_window_rt(ctx, u0));
+            uint64_t left = steps;
+            int slot = 0;
+            while (left > 0) { // (the step count is an int in the kernel; a launch goes in-planes -> out-planes)
+                const int n = left > (1u << 20) ? (1 << 20) : (int)left;
+                GsStepArgs a = make_args(ctx, r.u[slot], r.v[slot], r.u[1 - slot], r.v[1 - slot], 0, 1);
+                GsWindowArgs x;
+                std::memset(&x, 0, sizeof x);
+                x.xu[0] = ctx->win.planes[0]; x.xu[1] = ctx->win.planes[1];
+                x.xv[0] = ctx->win.planes[2]; x.xv[1] = ctx->win.planes[3];
+                x.flags = ctx->win.words;
+                x.abort = ctx->win.words + kWindowMaxTiles;
+                x.steps = n;
+                x.k = wk;
+                x.epoch = ctx->win.epoch;
+                const long ho = 16L * rpw - 2 * wk, wo = 128L - 2 * wk;
+                x.tiles_r = (int32_t)((a.rows + ho - 1) / ho);
+                x.tiles_c = (int32_t)((a.cols + wo - 1) / wo);
+                x.patience = gs_env_int("GS_HIP_WINDOW_PATIENCE", 1 << 22, 1, 1 << 30); // polls of ~1 us each: ~4 s
+                const char *name = nullptr;
+                const hipError_t e = ctx->o.math == GS_MATH_FUSED ? gs_launch_window_fused(a, x, rpw, sl.compute, &name)
+                                                                   : gs_launch_window_strict(a, x, rpw, sl.compute, &name);
+                if (e != hipSuccess) return fail(GS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+                const int supers = (n + wk - 1) / wk;
+                ctx->win.epoch += supers;
+                ctx->win.pending = true;
+                ctx->last_kernel = name;
+                ctx->launches++;
+                ctx->passes += (uint64_t)supers;
+                ctx->steps_done += (uint64_t)n;
+                ctx->step_no++;
+                slot ^= 1;
+                left -= (uint64_t)n;
+            }
+            if (result_slot) *result_slot = slot;
+            return GS_OK;
+        }
+        if (forced && single && cells > 0 && steps > 0)
+            return fail(GS_ERR_UNSUPPORTED, "GS_KERNEL_WINDOW needs a grid of at most one %d x %d-cell window per compute unit (%d)",
+                        16 * (ctx->o.rows_per_block > 0 ? ctx->o.rows_per_block / 16 : 6) - 2 * (ctx->o.fuse_steps > 0 ? ctx->o.fuse_steps : 4),
+                        128 - 2 * (ctx->o.fuse_steps > 0 ? ctx->o.fuse_steps : 4), ctx->cu_count);
     }
     // The short pass goes first so that a run ends on a full pass -- a full-depth ghost exchange -- and the
     // next run can start without a blocking refresh.  It is sized with the steps per pass in force (a

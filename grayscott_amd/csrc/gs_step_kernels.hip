@@ -1234,18 +1234,17 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
                                              float (&u)[RPW][2], float (&v)[RPW][2])
 {
     constexpr int P = kWinPitch;
-    constexpr bool COLS = EDGE == 1 || EDGE == 2 || EDGE == 3, ROWS = EDGE == 1 || EDGE == 4;
+    constexpr bool ROWS = EDGE == 1 || EDGE == 4;
     // row `which` (0 = first, 1 = last row of a wave's band) of wave w, species sp, buffer buf
     auto row_of = [&](int buf, int sp, int w, int which) { return lds + ((((buf * 2 + sp) * kWinWaves + w) * 2 + which) * P) + 2 + 2 * lane; };
-    bool inside[RPW][2];
+    // cells outside the grid are zeros and stay zeros: rows are wave-uniform (scalar tests), columns per lane
+    bool col_in[2];
     uint32_t la[2], ra[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         la[j] = ((EDGE == 1 || EDGE == 2) && j == 0 && gc == 0) ? 0xffffffffu : 0u; // gc is even: only a lane's first cell
         ra[j] = ((EDGE == 1 || EDGE == 3) && (gc + j + 1 >= a.cols)) ? 0xffffffffu : 0u;
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-            inside[r][j] = EDGE == 0 || (gr + r >= 0 && gr + r < a.rows && gc + j >= 0 && gc + j < a.cols);
+        col_in[j] = gc + j >= 0 && gc + j < a.cols;
     }
     const int wa = wave > 0 ? wave - 1 : 0, wb = wave < kWinWaves - 1 ? wave + 1 : kWinWaves - 1;
     auto widen = [](const float (&cu)[2], const float (&cv)[2]) {
@@ -1263,48 +1262,65 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
         *reinterpret_cast<float2 *>(row_of(buf, 1, wave, 0)) = make_float2(v[0][0], v[0][1]);
         *reinterpret_cast<float2 *>(row_of(buf, 0, wave, 1)) = make_float2(u[RPW - 1][0], u[RPW - 1][1]);
         *reinterpret_cast<float2 *>(row_of(buf, 1, wave, 1)) = make_float2(v[RPW - 1][0], v[RPW - 1][1]);
-        RowT<2> R[RPW + 2]; // R[0]: the row above the band, R[1 + r]: its row r (old values), R[RPW + 1]: the row below
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) R[1 + r] = widen(u[r], v[r]);
-        auto update = [&](int r) {
+        // One cell row: old rows (m, z, p) -> new values of row r, written in place.
+        auto update = [&](int r, const RowT<2> &m, const RowT<2> &z, const RowT<2> &p) {
             const int row = gr + r; // wave-uniform
             const bool mrow = !ROWS || row > 0, prow = !ROWS || row + 1 < a.rows;
             float nu[2], nv[2];
             if constexpr (EDGE == 0) {
-                cells_interior<FAST, 2, ZH>(a, R[r], R[r + 1], R[r + 2], nu, nv);
+                cells_interior<FAST, 2, ZH>(a, m, z, p, nu, nv);
             } else if constexpr (EDGE == 4) {
                 if (mrow && prow) {
-                    cells_interior<FAST, 2, ZH>(a, R[r], R[r + 1], R[r + 2], nu, nv);
+                    cells_interior<FAST, 2, ZH>(a, m, z, p, nu, nv);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) cell<1, FAST, RowT<2>, ZH>(a, R[r], R[r + 1], R[r + 2], 1 + j, mrow, prow, 0u, 0u, nu[j], nv[j]);
+                    for (int j = 0; j < 2; ++j) cell<1, FAST, RowT<2>, ZH>(a, m, z, p, 1 + j, mrow, prow, 0u, 0u, nu[j], nv[j]);
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) cell<EDGE, FAST, RowT<2>, ZH>(a, R[r], R[r + 1], R[r + 2], 1 + j, mrow, prow, la[j], ra[j], nu[j], nv[j]);
+                for (int j = 0; j < 2; ++j) cell<EDGE, FAST, RowT<2>, ZH>(a, m, z, p, 1 + j, mrow, prow, la[j], ra[j], nu[j], nv[j]);
             }
+            const bool row_in = row >= 0 && row < a.rows;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                u[r][j] = inside[r][j] ? nu[j] : 0.0f;
-                v[r][j] = inside[r][j] ? nv[j] : 0.0f;
+                const bool in = EDGE == 0 || (row_in && col_in[j]);
+                u[r][j] = in ? nu[j] : 0.0f;
+                v[r][j] = in ? nv[j] : 0.0f;
             }
         };
-        // the rows that need nothing from other waves first: the other waves' rows arrive meanwhile
+        // The rows that need nothing from other waves first (the other waves' rows arrive meanwhile), top down with a
+        // sliding window of widened OLD rows: a row is widened just before the row above it is overwritten, so at most
+        // five widened rows are alive -- the window of three, old row 1 (kept for row 0) and old row RPW - 2 (for the
+        // last row) -- instead of all RPW + 2.
+        RowT<2> first = widen(u[0], v[0]);                 // old row 0
+        RowT<2> second = widen(u[RPW > 1 ? 1 : 0], v[RPW > 1 ? 1 : 0]); // old row 1: needed again for row 0
+        RowT<2> prev = first, cur = second;
 #pragma unroll
-        for (int r = 1; r < RPW - 1; ++r) update(r);
+        for (int r = 1; r < RPW - 1; ++r) {
+            const RowT<2> next = widen(u[r + 1], v[r + 1]); // old row r + 1 (not overwritten yet)
+            update(r, prev, cur, next);
+            prev = cur;
+            cur = next;
+        }
+        // now: prev = old row RPW - 2, cur = old row RPW - 1 (RPW >= 3); RPW == 2: prev = old row 0, cur = old row 1
         __syncthreads();
+        RowT<2> above, below;
         {
             const float *pu = row_of(buf, 0, wa, 1), *pv = row_of(buf, 1, wa, 1);
             const float2 cu = *reinterpret_cast<const float2 *>(pu), cv = *reinterpret_cast<const float2 *>(pv);
-            R[0].u[0] = pu[-1]; R[0].u[1] = cu.x; R[0].u[2] = cu.y; R[0].u[3] = pu[2];
-            R[0].v[0] = pv[-1]; R[0].v[1] = cv.x; R[0].v[2] = cv.y; R[0].v[3] = pv[2];
+            above.u[0] = pu[-1]; above.u[1] = cu.x; above.u[2] = cu.y; above.u[3] = pu[2];
+            above.v[0] = pv[-1]; above.v[1] = cv.x; above.v[2] = cv.y; above.v[3] = pv[2];
             const float *qu = row_of(buf, 0, wb, 0), *qv = row_of(buf, 1, wb, 0);
             const float2 du = *reinterpret_cast<const float2 *>(qu), dv = *reinterpret_cast<const float2 *>(qv);
-            R[RPW + 1].u[0] = qu[-1]; R[RPW + 1].u[1] = du.x; R[RPW + 1].u[2] = du.y; R[RPW + 1].u[3] = qu[2];
-            R[RPW + 1].v[0] = qv[-1]; R[RPW + 1].v[1] = dv.x; R[RPW + 1].v[2] = dv.y; R[RPW + 1].v[3] = qv[2];
+            below.u[0] = qu[-1]; below.u[1] = du.x; below.u[2] = du.y; below.u[3] = qu[2];
+            below.v[0] = qv[-1]; below.v[1] = dv.x; below.v[2] = dv.y; below.v[3] = qv[2];
         }
-        update(0);
-        if (RPW > 1) update(RPW - 1);
+        if (RPW == 1) {
+            update(0, above, first, below);
+        } else {
+            update(0, above, first, second);
+            update(RPW - 1, prev, cur, below);
+        }
     }
 }
 
@@ -1313,64 +1329,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t win_rsrc(const void *p)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000);
 }
 
-template <int RPW, int FAST>
-__global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsStepArgs a, GsWindowArgs x)
+// The whole run of one workgroup: super-steps of K steps, an exchange after each but the last, the final store.  One
+// instantiation per kind of window (the kernel branches ONCE: with the branch inside the loop the compiler hoists the
+// loop-invariant values of every kind above it and the register file does not hold them all).
+template <int RPW, int EDGE, int FAST, int ZH>
+__device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowArgs &x, float *lds, int *go, int wg, int tr, int tc,
+                                           int gr, int gc, int wave, int lane, float (&u)[RPW][2], float (&v)[RPW][2])
 {
-    if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0); // half_diff: MODE.IEEE = 0
-    extern __shared__ float lds[];
-    __shared__ int go;
     constexpr int H = win_rows(RPW), SC1 = 16;
     typedef float v2f __attribute__((ext_vector_type(2)));
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int K = x.k;
-    const int HO = H - 2 * K, WO = kWinCols - 2 * K; // rows / columns a workgroup owns
-    const int wg = (int)blockIdx.x, tr = wg / x.tiles_c, tc = wg - tr * x.tiles_c;
-    const int gr0 = tr * HO - K, gc0 = tc * WO - K;         // global coordinates of window cell (0, 0)
-    const int gr = gr0 + wave * RPW, gc = gc0 + 2 * lane;   // this lane's first cell
-    const int wc = 2 * lane;                                // its window column
-    // a launch enqueued behind one that gave up leaves at once (nothing of it is valid anyway)
-    if (__builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(win_rsrc(x.abort), 0, 0, SC1)) != 0) return;
-    // columns -1 and 128 .. 129 of this wave's published rows are never written by a step; they are read into cells
-    // that are discarded, and zeroed once so that nothing depends on earlier contents of the LDS
-    if (lane < 3)
-#pragma unroll
-        for (int b = 0; b < 8; ++b)
-            lds[(((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + (lane == 0 ? 1 : 129 + lane)] = 0.0f;
-    float u[RPW][2], v[RPW][2];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const bool in = gr + r >= 0 && gr + r < a.rows && gc >= 0 && gc < a.cols;
-        v2f fu = {0.0f, 0.0f}, fv = {0.0f, 0.0f};
-        if (in) { // 8-byte loads: gc is even and the row pitch a multiple of 64 floats
-            const int off = ((gr + r) * a.pitch + gc) * (int)sizeof(float);
-            fu = __builtin_amdgcn_raw_buffer_load_b64(win_rsrc(a.in_u), off, 0, 0);
-            fv = __builtin_amdgcn_raw_buffer_load_b64(win_rsrc(a.in_v), off, 0, 0);
-        }
-        const bool in1 = in && gc + 1 < a.cols;
-        u[r][0] = fu[0]; u[r][1] = in1 ? fu[1] : 0.0f;
-        v[r][0] = fv[0]; v[r][1] = in1 ? fv[1] : 0.0f;
-    }
-    const bool left = gc0 <= 0, right = gc0 + kWinCols >= a.cols, ends = gr0 <= 0 || gr0 + H >= a.rows;
-    const bool edge = left || right || ends;
-    constexpr bool KINDS = (FAST & 1) && !GS_MATH_FUSED;
+    const int K = x.k, wc = 2 * lane; // wc: this lane's first window column
     int step = 0;
     const int supers = (x.steps + K - 1) / K;
     for (int s = 0; s < supers; ++s) {
         // the short super-step first
-        const int n = (s == 0 && x.steps % K) ? x.steps % K : K;
-        if (!edge)
-            window_steps<RPW, 0, FAST, -1>(a, lds, n, step, gr, gc, wave, lane, u, v);
-        else if (a.zero_halo)
-            window_steps<RPW, 1, FAST, 1>(a, lds, n, step, gr, gc, wave, lane, u, v);
-        else if (KINDS && a.edge_kinds && left && !right && !ends)
-            window_steps<RPW, KINDS ? 2 : 1, FAST, 0>(a, lds, n, step, gr, gc, wave, lane, u, v);
-        else if (KINDS && a.edge_kinds && right && !left && !ends)
-            window_steps<RPW, KINDS ? 3 : 1, FAST, 0>(a, lds, n, step, gr, gc, wave, lane, u, v);
-        else if (KINDS && a.edge_kinds && ends && !left && !right)
-            window_steps<RPW, KINDS ? 4 : 1, FAST, 0>(a, lds, n, step, gr, gc, wave, lane, u, v);
-        else
-            window_steps<RPW, 1, FAST, 0>(a, lds, n, step, gr, gc, wave, lane, u, v);
+        window_steps<RPW, EDGE, FAST, ZH>(a, lds, (s == 0 && x.steps % K) ? x.steps % K : K, step, gr, gc, wave, lane, u, v);
         if (s == supers - 1) break;
         // ---- exchange s: ring out, flag, poll, apron in -------------------------------------------------------
         const __amdgpu_buffer_rsrc_t xu = win_rsrc(x.xu[s & 1]), xv = win_rsrc(x.xv[s & 1]);
@@ -1404,13 +1377,13 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
             }
             if (lane == 0) {
                 if (!ok) __builtin_amdgcn_raw_buffer_store_b32(1, win_rsrc(x.abort), 0, 0, SC1);
-                go = ok;
+                *go = ok;
             }
         }
         __syncthreads();
-        if (!go) return; // (workgroup-uniform)
-        const bool lane_apron = (wc < K || wc >= kWinCols - K) && gc >= 0 && gc < a.cols;
+        if (!*go) return; // (workgroup-uniform)
         const bool lane_in = gc >= 0 && gc < a.cols;
+        const bool lane_apron = (wc < K || wc >= kWinCols - K) && lane_in;
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int wr = wave * RPW + r;
@@ -1440,6 +1413,60 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
             }
         }
     }
+}
+
+template <int RPW, int FAST>
+__global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsStepArgs a, GsWindowArgs x)
+{
+    if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0); // half_diff: MODE.IEEE = 0
+    extern __shared__ float lds[];
+    __shared__ int go;
+    constexpr int H = win_rows(RPW), SC1 = 16;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = x.k;
+    const int HO = H - 2 * K, WO = kWinCols - 2 * K; // rows / columns a workgroup owns
+    const int wg = (int)blockIdx.x, tr = wg / x.tiles_c, tc = wg - tr * x.tiles_c;
+    const int gr0 = tr * HO - K, gc0 = tc * WO - K;         // global coordinates of window cell (0, 0)
+    const int gr = gr0 + wave * RPW, gc = gc0 + 2 * lane;   // this lane's first cell
+    // A launch enqueued behind one that gave up leaves at once (nothing of it is valid anyway).  ONE wave reads the
+    // word for the whole workgroup: waves that read it for themselves could disagree (a workgroup of this launch may
+    // give up at any time) and a barrier below would wait for waves that have left.
+    if (wave == 0 && lane == 0) go = __builtin_amdgcn_raw_buffer_load_b32(win_rsrc(x.abort), 0, 0, SC1) == 0;
+    __syncthreads();
+    if (!go) return; // (workgroup-uniform)
+    // columns -1 and 128 .. 129 of this wave's published rows are never written by a step; they are read into cells
+    // that are discarded, and zeroed once so that nothing depends on earlier contents of the LDS
+    if (lane < 3)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            lds[(((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + (lane == 0 ? 1 : 129 + lane)] = 0.0f;
+    float u[RPW][2], v[RPW][2];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const bool in = gr + r >= 0 && gr + r < a.rows && gc >= 0 && gc < a.cols;
+        v2f fu = {0.0f, 0.0f}, fv = {0.0f, 0.0f};
+        if (in) { // 8-byte loads: gc is even and the row pitch a multiple of 64 floats
+            const int off = ((gr + r) * a.pitch + gc) * (int)sizeof(float);
+            fu = __builtin_amdgcn_raw_buffer_load_b64(win_rsrc(a.in_u), off, 0, 0);
+            fv = __builtin_amdgcn_raw_buffer_load_b64(win_rsrc(a.in_v), off, 0, 0);
+        }
+        const bool in1 = in && gc + 1 < a.cols;
+        u[r][0] = fu[0]; u[r][1] = in1 ? fu[1] : 0.0f;
+        v[r][0] = fv[0]; v[r][1] = in1 ? fv[1] : 0.0f;
+    }
+    const bool left = gc0 <= 0, right = gc0 + kWinCols >= a.cols, ends = gr0 <= 0 || gr0 + H >= a.rows;
+    const bool edge = left || right || ends;
+    constexpr bool KINDS = (FAST & 1) && !GS_MATH_FUSED;
+#define GS_WIN_RUN(E, Z) window_run<RPW, E, FAST, Z>(a, x, lds, &go, wg, tr, tc, gr, gc, wave, lane, u, v)
+    if (!edge) GS_WIN_RUN(0, -1);
+    else if (a.zero_halo) GS_WIN_RUN(1, 1);
+    else if (KINDS && a.edge_kinds && left && !right && !ends) GS_WIN_RUN(KINDS ? 2 : 1, 0);
+    else if (KINDS && a.edge_kinds && right && !left && !ends) GS_WIN_RUN(KINDS ? 3 : 1, 0);
+    else if (KINDS && a.edge_kinds && ends && !left && !right) GS_WIN_RUN(KINDS ? 4 : 1, 0);
+    else GS_WIN_RUN(1, 0);
+#undef GS_WIN_RUN
 }
 #endif // !GS_TB_OP_ONLY
 

@@ -56,6 +56,8 @@
  *     GS_HIP_XCD_M          0 = plain workgroup order, n = XCD-aware renumbering in groups of 8 n workgroups
  *     GS_HIP_XCD_M_STREAM   the same for the single-step kernel
  *     GS_HIP_TILE_LDS_FLOOR least dynamic LDS (bytes) of the LDS-window kernel: limits its workgroups per CU
+ *     GS_HIP_WINDOW_PATIENCE polls (~1 us each) a workgroup of the persistent window kernel waits for a neighbour
+ *                           before the launch gives up (default 2^22: ~4 s)
  */
 #ifndef GS_HIP_H
 #define GS_HIP_H
@@ -102,9 +104,9 @@ typedef struct gs_params {
 typedef enum gs_math { GS_MATH_STRICT = 0, GS_MATH_FUSED = 1 } gs_math;
 
 /* Which step kernel runs.  AUTO = STREAM for a single gs_step; inside gs_run, by grid size when nothing
- * is pinned: the LDS-resident whole-run kernel up to 1536 cells, TILE up to 1.5 M cells, TB with
- * fuse_steps (default 4) above, for slab chains and whenever fuse_steps, rows_per_block, cols_per_lane,
- * split or use_graph pin a schedule. */
+ * is pinned: the LDS-resident whole-run kernel up to 1536 cells, TILE up to 1.5 M cells, WINDOW up to one
+ * window per compute unit (3.2 M cells), TB with fuse_steps (default 4) above, for slab chains and whenever
+ * fuse_steps, rows_per_block, cols_per_lane, split or use_graph pin a schedule. */
 typedef enum gs_kernel {
     GS_KERNEL_AUTO = 0,    /* best measured variant for the shape                          */
     GS_KERNEL_SIMPLE = 1,  /* one thread per cell, global loads only (cross-check kernel)  */
@@ -112,9 +114,14 @@ typedef enum gs_kernel {
     GS_KERNEL_TB = 3,      /* temporally blocked streaming kernel: fuse_steps steps / launch */
     GS_KERNEL_LDS = 4,     /* LDS-staged (tile + halo) window, one step per launch (measured
                               alternative to STREAM; never chosen by AUTO)                   */
-    GS_KERNEL_TILE = 5     /* gs_run only, single slab: up to 8 steps per launch on LDS-resident windows
+    GS_KERNEL_TILE = 5,    /* gs_run only, single slab: up to 8 steps per launch on LDS-resident windows
                               with a K-cell apron, one cell per lane and 16 waves per window (gs_step and
                               slab chains fall back to STREAM / TB); what AUTO runs on mid-size grids  */
+    GS_KERNEL_WINDOW = 6   /* gs_run only, single slab, grids of at most one 72 x 120- or 88 x 120-cell window per
+                              compute unit (1.5 - 3.2 M cells on 256 CUs: the reference's default 1080 x 1920): the
+                              whole call is ONE persistent launch; every workgroup keeps its window in registers
+                              and trades its k-cell apron with its neighbours every k steps (fuse_steps = k:
+                              2, 4, 6 or 8; rows_per_block = window rows, 80 or 96).  What AUTO runs there  */
 } gs_kernel;
 
 /* Rule on the edges of the global grid.  The reference has two:
