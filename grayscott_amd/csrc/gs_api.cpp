@@ -300,7 +300,8 @@ int32_t sync_all(gs_ctx *ctx)
         GS_HIP(hipSetDevice(ctx->slabs[0].device));
         GS_HIP(hipMemcpy(&gave_up, ctx->win.words + kWindowMaxTiles, sizeof gave_up, hipMemcpyDeviceToHost));
         if (gave_up) {
-            GS_HIP(hipMemset(ctx->win.words, 0, (kWindowMaxTiles + 1) * sizeof(int32_t)));
+            GS_HIP(hipMemsetAsync(ctx->win.words, 0, (kWindowMaxTiles + 1) * sizeof(int32_t), ctx->slabs[0].compute));
+            GS_HIP(hipStreamSynchronize(ctx->slabs[0].compute));
             ctx->win.epoch = 0;
             ctx->win.disabled = true;
             return fail(GS_ERR_HIP, "a persistent window launch gave up waiting for a neighbouring workgroup (is another "
@@ -660,7 +661,9 @@ int32_t ensure_window_rt(gs_ctx *ctx, const gs_field *f)
     GS_HIP(hipSetDevice(ctx->slabs[0].device));
     if (!w.words) {
         GS_HIP(hipMalloc(reinterpret_cast<void **>(&w.words), (kWindowMaxTiles + 1) * sizeof(int32_t)));
-        GS_HIP(hipMemset(w.words, 0, (kWindowMaxTiles + 1) * sizeof(int32_t)));
+        // on the stream the launches use: the context's streams are non-blocking, a hipMemset on the null stream
+        // would not be ordered before them (and the words may hold a freed context's flags)
+        GS_HIP(hipMemsetAsync(w.words, 0, (kWindowMaxTiles + 1) * sizeof(int32_t), ctx->slabs[0].compute));
         w.epoch = 0;
     }
     if (w.rows != f->rows || w.pitch != (uint64_t)f->pitch || !w.planes[0]) {
@@ -1832,20 +1835,19 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
         if (result_slot) *result_slot = slot;
         return GS_OK;
     }
-    // Grids of one round of register-resident windows (single slab; the reference's default 1080 x 1920): the whole
-    // call is ONE persistent launch of gs_run_window_k, which trades the windows' aprons between workgroups itself
-    // every k steps.  kernel = auto takes it from the LDS-window kernel's upper end (1.5 M cells) up to the largest grid
-    // that is one workgroup per CU (3.2 M cells on 256 CUs) when nothing is pinned; GS_KERNEL_WINDOW forces it
-    // (fuse_steps = steps per exchange, rows_per_block = window rows: 80 or 96).
+    // GS_KERNEL_WINDOW (single slab, grids of at most one window per compute unit; the reference's default 1080 x 1920
+    // is 15 x 16 of them): the whole call is ONE persistent launch of gs_run_window_k, which trades the windows' aprons
+    // between workgroups itself every k steps (fuse_steps = k, rows_per_block = window rows: 80 or 96).  A measured
+    // alternative, never chosen by kernel = auto: 383 k Mcells x steps / s at 1080 x 1920 under the clipped rule against
+    // 435 k for the marching kernel (441 k / 437 k under the zero-halo rule) -- a step costs 3.0 us per window (3.6 in the
+    // windows on the grid's left edge, which set the pace) and an exchange 6.9 us on the critical path
+    // (profiles/r04_window_kernel.md).
     {
         int rpw = 0, wk = 0;
-        const bool forced = ctx->o.kernel == GS_KERNEL_WINDOW;
-        const bool automatic = ctx->o.kernel == GS_KERNEL_AUTO && ctx->o.fuse_steps == 0 && ctx->o.rows_per_block == 0 &&
-                               ctx->o.cols_per_lane == 0 && ctx->o.split <= 1 && !ctx->o.use_graph && cells >= kTileAutoCells &&
-                               !ctx->win.disabled;
-        if (single && cells > 0 && steps > 0 && (forced || automatic) &&
-            pick_window_config(ctx, u0->rows, u0->cols, forced && ctx->o.rows_per_block > 0 ? ctx->o.rows_per_block / 16 : 0,
-                               forced ? ctx->o.fuse_steps : 0, &rpw, &wk)) {
+        const bool forced = ctx->o.kernel == GS_KERNEL_WINDOW && !ctx->win.disabled;
+        if (single && cells > 0 && steps > 0 && forced &&
+            pick_window_config(ctx, u0->rows, u0->cols, ctx->o.rows_per_block > 0 ? ctx->o.rows_per_block / 16 : 0, ctx->o.fuse_steps,
+                               &rpw, &wk)) {
             SlabRt &sl = ctx->slabs[0];
             GS_HIP(hipSetDevice(sl.device));
             GS_TRY(join_bands(ctx, sl.compute));

@@ -34,6 +34,8 @@
 #ifndef GS_TB_AUX_STORE
 #define GS_TB_AUX_STORE 0
 #endif
+// GS_WIN_TRACE     (defined = on; tools/window_timeline.py) wave 0 of every workgroup of the persistent window kernel
+//                  stamps the 100 MHz real-time counter at seven points of each of its last 8 super-steps.
 // GS_TB_TRACE      (defined = on; tools/wave_timeline.py) every wave of gs_step_tb_k leaves five stamps of the
 //                  100 MHz real-time counter -- entry, first level-0 rows used (tick 3), level pipeline full (tick
 //                  2K), last level-0 row taken (tick nticks - 2K), exit -- plus the shader-clock counter at entry

@@ -1226,15 +1226,19 @@ __host__ __device__ constexpr int win_rows(int rpw) { return kWinWaves * rpw; }
 // 2 buffers x 2 species x 16 waves x (first row, last row) x pitch
 __host__ __device__ constexpr size_t win_lds_bytes() { return (size_t)2 * 2 * kWinWaves * 2 * kWinPitch * sizeof(float); }
 
-// `n` time steps of a window.  EDGE / ZH as in tb_march: 0 = window inside the grid; 1 = general path; 2 / 3 = window
-// on the grid's left / right edge (touching neither top nor bottom); 4 = window on the top or bottom edge only.
-// `step` counts the steps of the launch (parity of the LDS buffer).
+// `n` time steps of a window.  EDGE: 0 = window inside the grid; 1 = general path for every cell; 2 / 3 = window on the
+// grid's left / right edge, touching neither top nor bottom (cell<2> / cell<3>); 4 = window on the top or bottom edge
+// only (interior code but for the grid's first / last row, which take the general cell); 5 / 6 = corner windows,
+// left / right (cell<2> / cell<3> but for the grid's first / last row); 7 = edge window under the zero-halo rule:
+// interior code over cells that are zeros outside the grid and stay zeros.  `step` counts the steps of the launch
+// (parity of the LDS buffer).
 template <int RPW, int EDGE, int FAST, int ZH>
 __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, int n, int &step, int gr, int gc, int wave, int lane,
                                              float (&u)[RPW][2], float (&v)[RPW][2])
 {
     constexpr int P = kWinPitch;
-    constexpr bool ROWS = EDGE == 1 || EDGE == 4;
+    constexpr bool ROWS = EDGE == 1 || EDGE == 4 || EDGE == 5 || EDGE == 6;
+    constexpr int SIDE = (EDGE == 2 || EDGE == 5) ? 2 : ((EDGE == 3 || EDGE == 6) ? 3 : 0);
     // row `which` (0 = first, 1 = last row of a wave's band) of wave w, species sp, buffer buf
     auto row_of = [&](int buf, int sp, int w, int which) { return lds + ((((buf * 2 + sp) * kWinWaves + w) * 2 + which) * P) + 2 + 2 * lane; };
     // cells outside the grid are zeros and stay zeros: rows are wave-uniform (scalar tests), columns per lane
@@ -1242,11 +1246,14 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
     uint32_t la[2], ra[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        la[j] = ((EDGE == 1 || EDGE == 2) && j == 0 && gc == 0) ? 0xffffffffu : 0u; // gc is even: only a lane's first cell
-        ra[j] = ((EDGE == 1 || EDGE == 3) && (gc + j + 1 >= a.cols)) ? 0xffffffffu : 0u;
+        la[j] = ((EDGE == 1 || SIDE == 2) && j == 0 && gc == 0) ? 0xffffffffu : 0u; // gc is even: only a lane's first cell
+        ra[j] = ((EDGE == 1 || SIDE == 3) && (gc + j + 1 >= a.cols)) ? 0xffffffffu : 0u;
         col_in[j] = gc + j >= 0 && gc + j < a.cols;
     }
     const int wa = wave > 0 ? wave - 1 : 0, wb = wave < kWinWaves - 1 ? wave + 1 : kWinWaves - 1;
+    // The columns next to a lane's two come from the adjacent lanes by DPP wave shifts: VALU work (4 % of a step) rather
+    // than the LDS crossbar, which 16 waves in lock-step all want at the same moment (ds_bpermute_b32: a step 24 % longer,
+    // profiles/r04_sweeps.md, section 2).
     auto widen = [](const float (&cu)[2], const float (&cv)[2]) {
         RowT<2> w;
         w.u[1] = cu[0]; w.u[2] = cu[1]; w.v[1] = cv[0]; w.v[2] = cv[1];
@@ -1267,14 +1274,19 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
             const int row = gr + r; // wave-uniform
             const bool mrow = !ROWS || row > 0, prow = !ROWS || row + 1 < a.rows;
             float nu[2], nv[2];
-            if constexpr (EDGE == 0) {
+            if constexpr (EDGE == 0 || EDGE == 7) {
                 cells_interior<FAST, 2, ZH>(a, m, z, p, nu, nv);
-            } else if constexpr (EDGE == 4) {
+            } else if constexpr (EDGE == 4 || EDGE == 5 || EDGE == 6) {
                 if (mrow && prow) {
-                    cells_interior<FAST, 2, ZH>(a, m, z, p, nu, nv);
+                    if constexpr (EDGE == 4) {
+                        cells_interior<FAST, 2, ZH>(a, m, z, p, nu, nv);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) cell<SIDE, FAST, RowT<2>, ZH>(a, m, z, p, 1 + j, true, true, la[j], ra[j], nu[j], nv[j]);
+                    }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) cell<1, FAST, RowT<2>, ZH>(a, m, z, p, 1 + j, mrow, prow, 0u, 0u, nu[j], nv[j]);
+                    for (int j = 0; j < 2; ++j) cell<1, FAST, RowT<2>, ZH>(a, m, z, p, 1 + j, mrow, prow, la[j], ra[j], nu[j], nv[j]);
                 }
             } else {
 #pragma unroll
@@ -1332,6 +1344,24 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t win_rsrc(const void *p)
 // The whole run of one workgroup: super-steps of K steps, an exchange after each but the last, the final store.  One
 // instantiation per kind of window (the kernel branches ONCE: with the branch inside the loop the compiler hoists the
 // loop-invariant values of every kind above it and the register file does not hold them all).
+// GS_WIN_TRACE (diagnostic builds, tools/window_timeline.py): wave 0 of every workgroup stamps the 100 MHz real-time
+// counter at seven points of each of its last 8 super-steps: start, steps done, ring stored and drained, barrier
+// passed, poll matched, barrier passed, apron loaded.
+#if defined(GS_WIN_TRACE)
+__device__ unsigned long long gs_win_trace[1024 * 8 * 8];
+#define GS_WIN_TRACE_AT(SLOT)                                                                                      \
+    do {                                                                                                           \
+        if (wave == 0 && lane == 0 && s >= supers - 9) {                                                           \
+            unsigned long long t_;                                                                                 \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+            gs_win_trace[(wg * 8 + ((s - (supers - 9)) & 7)) * 8 + (SLOT)] = t_;                                   \
+            if ((SLOT) == 0) gs_win_trace[(wg * 8 + ((s - (supers - 9)) & 7)) * 8 + 7] = (unsigned long long)EDGE;  \
+        }                                                                                                          \
+    } while (0)
+#else
+#define GS_WIN_TRACE_AT(SLOT) do { } while (0)
+#endif
+
 template <int RPW, int EDGE, int FAST, int ZH>
 __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowArgs &x, float *lds, int *go, int wg, int tr, int tc,
                                            int gr, int gc, int wave, int lane, float (&u)[RPW][2], float (&v)[RPW][2])
@@ -1342,8 +1372,10 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
     int step = 0;
     const int supers = (x.steps + K - 1) / K;
     for (int s = 0; s < supers; ++s) {
+        GS_WIN_TRACE_AT(0);
         // the short super-step first
         window_steps<RPW, EDGE, FAST, ZH>(a, lds, (s == 0 && x.steps % K) ? x.steps % K : K, step, gr, gc, wave, lane, u, v);
+        GS_WIN_TRACE_AT(1);
         if (s == supers - 1) break;
         // ---- exchange s: ring out, flag, poll, apron in -------------------------------------------------------
         const __amdgpu_buffer_rsrc_t xu = win_rsrc(x.xu[s & 1]), xv = win_rsrc(x.xv[s & 1]);
@@ -1362,7 +1394,9 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GS_WIN_TRACE_AT(2);
         __syncthreads();
+        GS_WIN_TRACE_AT(3);
         if (wave == 0) {
             const int target = x.epoch + s + 1;
             if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(target, win_rsrc(x.flags), wg * 4, 0, SC1);
@@ -1380,8 +1414,10 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
                 *go = ok;
             }
         }
+        GS_WIN_TRACE_AT(4);
         __syncthreads();
         if (!*go) return; // (workgroup-uniform)
+        GS_WIN_TRACE_AT(5);
         const bool lane_in = gc >= 0 && gc < a.cols;
         const bool lane_apron = (wc < K || wc >= kWinCols - K) && lane_in;
 #pragma unroll
@@ -1398,6 +1434,10 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
                 v[r][0] = fv[0]; v[r][1] = in1 ? fv[1] : 0.0f;
             }
         }
+#if defined(GS_WIN_TRACE)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        GS_WIN_TRACE_AT(6);
     }
     // the cells this workgroup owns, where they lie in the grid (8-byte stores; a second column beyond `cols` lands in
     // the planes' padding columns, which nothing reads)
@@ -1460,11 +1500,17 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
     const bool edge = left || right || ends;
     constexpr bool KINDS = (FAST & 1) && !GS_MATH_FUSED;
 #define GS_WIN_RUN(E, Z) window_run<RPW, E, FAST, Z>(a, x, lds, &go, wg, tr, tc, gr, gc, wave, lane, u, v)
+    // One branch per workgroup, one instantiation per kind of window (as gs_step_tb_k): the cheap kinds exist for the
+    // clipped rule with the default side weights in the strict build; a grid narrower than one window, general
+    // weights and the fused build take the general path in their edge windows.
+    const bool cheap = KINDS && a.edge_kinds;
     if (!edge) GS_WIN_RUN(0, -1);
-    else if (a.zero_halo) GS_WIN_RUN(1, 1);
-    else if (KINDS && a.edge_kinds && left && !right && !ends) GS_WIN_RUN(KINDS ? 2 : 1, 0);
-    else if (KINDS && a.edge_kinds && right && !left && !ends) GS_WIN_RUN(KINDS ? 3 : 1, 0);
-    else if (KINDS && a.edge_kinds && ends && !left && !right) GS_WIN_RUN(KINDS ? 4 : 1, 0);
+    else if (a.zero_halo) GS_WIN_RUN(7, 1);
+    else if (cheap && left && !right && !ends) GS_WIN_RUN(KINDS ? 2 : 1, 0);
+    else if (cheap && right && !left && !ends) GS_WIN_RUN(KINDS ? 3 : 1, 0);
+    else if (cheap && ends && !left && !right) GS_WIN_RUN(KINDS ? 4 : 1, 0);
+    else if (cheap && left && !right) GS_WIN_RUN(KINDS ? 5 : 1, 0);
+    else if (cheap && right && !left) GS_WIN_RUN(KINDS ? 6 : 1, 0);
     else GS_WIN_RUN(1, 0);
 #undef GS_WIN_RUN
 }
@@ -1988,6 +2034,13 @@ hipError_t GS_SUFFIX(gs_launch_lds)(const GsStepArgs &a, hipStream_t s, const ch
                            dim3(256), kargs, 0, s);
 }
 #endif // !GS_TB_OP_ONLY
+
+#if defined(GS_WIN_TRACE) && !GS_TB_OP_ONLY
+extern "C" int32_t GS_SUFFIX(gs_debug_win_trace_read)(unsigned long long *dst)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(gs_win_trace), sizeof(unsigned long long) * 1024 * 8 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #if defined(GS_TB_TRACE)
 // Copies the trace buffer of THIS translation unit's kernels out (diagnostic builds only).

@@ -104,9 +104,9 @@ typedef struct gs_params {
 typedef enum gs_math { GS_MATH_STRICT = 0, GS_MATH_FUSED = 1 } gs_math;
 
 /* Which step kernel runs.  AUTO = STREAM for a single gs_step; inside gs_run, by grid size when nothing
- * is pinned: the LDS-resident whole-run kernel up to 1536 cells, TILE up to 1.5 M cells, WINDOW up to one
- * window per compute unit (3.2 M cells), TB with fuse_steps (default 4) above, for slab chains and whenever
- * fuse_steps, rows_per_block, cols_per_lane, split or use_graph pin a schedule. */
+ * is pinned: the LDS-resident whole-run kernel up to 1536 cells, TILE up to 1.5 M cells, TB with
+ * fuse_steps (default 4) above, for slab chains and whenever fuse_steps, rows_per_block, cols_per_lane,
+ * split or use_graph pin a schedule. */
 typedef enum gs_kernel {
     GS_KERNEL_AUTO = 0,    /* best measured variant for the shape                          */
     GS_KERNEL_SIMPLE = 1,  /* one thread per cell, global loads only (cross-check kernel)  */
@@ -121,7 +121,10 @@ typedef enum gs_kernel {
                               compute unit (1.5 - 3.2 M cells on 256 CUs: the reference's default 1080 x 1920): the
                               whole call is ONE persistent launch; every workgroup keeps its window in registers
                               and trades its k-cell apron with its neighbours every k steps (fuse_steps = k:
-                              2, 4, 6 or 8; rows_per_block = window rows, 80 or 96).  What AUTO runs there  */
+                              2, 4, 6 or 8; rows_per_block = window rows, 80 or 96).  Bit-exact, measured slower than
+                              TB on such grids (383 k against 435 k Mcells x steps / s at 1080 x 1920): never chosen
+                              by AUTO.  A launch whose workgroups are not all resident gives up after a bounded wait:
+                              gs_sync then fails, no step of that gs_run was taken and its input planes are intact  */
 } gs_kernel;
 
 /* Rule on the edges of the global grid.  The reference has two:

@@ -4,7 +4,9 @@ flags, inside the launch.  Bit for bit against the oracle: every shape class (si
 window, several windows each way with ragged right / bottom ends, exactly one owned region), both boundary rules,
 both window heights, every k, step counts that are a short super-step, whole ones and both; general parameters
 (no specialised variant); the fused flavour; NaN / Inf spreading; Species::new through uneven calls with single
-steps in between; BASELINE config 1 (1080 x 1920 x 1000 steps) end to end; what kernel = auto picks.
+steps in between; BASELINE config 1 (1080 x 1920 x 1000 steps) end to end; a launch that gives up; a soak against the
+marching kernel under chaotic dynamics (every exchanged word matters).  A measured alternative: kernel = auto never
+picks it (profiles/r04_window_kernel.md).
 Spec: compute/naive/src/lib.rs:42-83 (arithmetic, clipped window), compute/shared/src/cpu.rs:30-42 (step; flip);
 zero-halo rule: compute/gpu/naive/src/pipeline.rs:105-113."""
 import numpy as np
@@ -144,7 +146,7 @@ def test_a_launch_that_gives_up_is_reported_and_destroys_nothing(monkeypatch):
     monkeypatch.setenv("GS_HIP_WINDOW_PATIENCE", "1")
     rows, cols = 1080, 1920
     u0, v0 = stress_fields((rows, cols), 5)
-    sim = Simulation.new(Parameters(), args())
+    sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_WINDOW))
     from tests.helpers import species_from_arrays
     sp = species_from_arrays(sim, u0, v0)
     gave_up = False
@@ -164,3 +166,36 @@ def test_a_launch_that_gives_up_is_reported_and_destroys_nothing(monkeypatch):
     in_u, in_v, _, _ = sp.in_out()
     assert_bits_equal(in_u.make_scalar_view(sim.context), ref_u, "U after the fallback")
     assert_bits_equal(in_v.make_scalar_view(sim.context), ref_v, "V after the fallback")
+
+
+def test_window_kernel_soak_against_the_marching_kernel():
+    """1080 x 1920, a pattern-forming start, 3000 steps in uneven calls, three contexts in a row: ~750 exchanges of 240
+    workgroups each -- one stale or misplaced exchange word anywhere changes bits that the dynamics then spread --
+    against the default schedule (the marching kernel), every word of U and V."""
+    import torch
+
+    import bench
+
+    rows, cols = 1080, 1920
+    u0, v0 = bench.developed_start(rows, cols)
+    ref = Simulation.new(Parameters(), args())
+    sr = bench.upload_species(ref, u0, v0)
+    calls = (997, 1003, 1000)
+    for n in calls:
+        ref.perform_steps(sr, n)
+    assert ref.context.info()[0].startswith("tb-k")
+    for attempt in range(3):
+        sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_WINDOW))
+        sp = bench.upload_species(sim, u0, v0)
+        for n in calls:
+            sim.perform_steps(sp, n)
+        assert sim.context.info()[0] == "window80x128/strict.op"
+        torch.cuda.synchronize()
+        for name, a, b in (("U", sp.in_out()[0], sr.in_out()[0]), ("V", sp.in_out()[1], sr.in_out()[1])):
+            (_, _, x), = a.torch_views()
+            (_, _, y), = b.torch_views()
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), f"{name} differs after {sum(calls)} steps (context {attempt})"
+        sim.context.close()
+    (_, _, v), = sr.in_out()[1].torch_views()
+    assert float(v.max()) > 0.3
+    ref.context.close()
