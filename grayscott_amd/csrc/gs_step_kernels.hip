@@ -1351,11 +1351,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t win_rsrc(const void *p)
 __device__ unsigned long long gs_win_trace[1024 * 8 * 8];
 #define GS_WIN_TRACE_AT(SLOT)                                                                                      \
     do {                                                                                                           \
-        if (wave == 0 && lane == 0 && s >= supers - 9) {                                                           \
+        if (wave == 0 && lane == 0 && s >= supers - 8) {                                                           \
             unsigned long long t_;                                                                                 \
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
-            gs_win_trace[(wg * 8 + ((s - (supers - 9)) & 7)) * 8 + (SLOT)] = t_;                                   \
-            if ((SLOT) == 0) gs_win_trace[(wg * 8 + ((s - (supers - 9)) & 7)) * 8 + 7] = (unsigned long long)EDGE;  \
+            gs_win_trace[(wg * 8 + ((s - (supers - 8)) & 7)) * 8 + (SLOT)] = t_;                                   \
+            if ((SLOT) == 0) gs_win_trace[(wg * 8 + ((s - (supers - 8)) & 7)) * 8 + 7] = (unsigned long long)EDGE;  \
         }                                                                                                          \
     } while (0)
 #else
