@@ -216,6 +216,9 @@ struct gs_ctx {
     struct WindowRt {
         float *planes[4] = {nullptr, nullptr, nullptr, nullptr}; // xu[0], xu[1], xv[0], xv[1]
         int32_t *words = nullptr;                                // kWindowMaxTiles flags, then the abort word
+        GsWindowDesc *desc = nullptr;                            // kWindowMaxTiles window descriptors (device)
+        uint64_t plan_rows = 0, plan_cols = 0;                   // the tiling `desc` holds ...
+        int plan_rpw = 0, plan_k = 0, plan_n = 0, plan_key = -1; // ... its windows, and what else it was made for
         uint64_t rows = 0, pitch = 0;
         int32_t epoch = 0;
         bool pending = false;  // a launch has been enqueued since the abort word was last read
@@ -635,23 +638,89 @@ void pick_tile_config(long rows, long cols, int *shape, int *k)
 }
 
 // ---- gs_run_window_k: grids of one round of register-resident windows ----------------------------------------
-// Window (rows per wave) and steps per exchange for a grid, or false when the grid is not one round of workgroups:
-// a workgroup owns (16 rpw - 2 k) x (128 - 2 k) cells and there is one workgroup per CU at most, all of them resident
-// for the whole launch.  Work per step is proportional to rpw (every CU updates its whole 16 rpw x 128 window), so the
-// smallest window that covers the grid wins; k = 4 is the measured balance between apron work (window cells outside
-// the owned ones: 16 % at 80 x 128) and exchanges (4.3 us each, tools/ubench/handoff_probe.hip).
-bool pick_window_config(const gs_ctx *ctx, uint64_t rows, uint64_t cols, int want_rpw, int want_k, int *rpw, int *k)
+// The tiling of a grid into windows, or an empty plan when the grid is not one round of workgroups (one workgroup per
+// CU at most, all of them resident for the whole launch).  Tile columns are 128 - 2 k owned columns wide; the windows of
+// a tile column share their height.  Every workgroup waits for its neighbours at every exchange, so the slowest
+// window sets the pace of the whole grid: columns whose cells cost more instructions get LOWER windows (fewer waves
+// in use), so that a step takes every workgroup the same time.  Costs relative to an interior window (ISA and
+// tools/window_timeline.py, profiles/r04_window_kernel.md): the grid's left edge under the clipped rule 1.20 (cell<2>: 18
+// selects for the cell on column 0's lane), the right edge 1.13 (cell<3>), general path (general weights, the fused
+// build, a grid of one tile column) 1.6, edge columns under the zero-halo rule 1.05 (a select per cell).
+// `waves_env`: GS_HIP_WINDOW_WAVES = "left,interior,right" overrides the waves in use per column class (experiments).
+std::vector<GsWindowDesc> plan_windows(const gs_ctx *ctx, uint64_t rows, uint64_t cols, int want_rpw, int want_k, int *rpw_out, int *k_out)
 {
-    if (ctx->cu_count <= 0 || rows == 0 || cols == 0 || rows > 0x7fffff || cols > 0x7fffff) return false;
-    const int kk = want_k > 0 ? want_k : 4;
-    if (kk < 2 || kk > 8 || (kk & 1)) return false;
-    for (int r : {5, 6}) {
-        if (want_rpw > 0 && want_rpw != r) continue;
-        const long ho = 16L * r - 2 * kk, wo = 128L - 2 * kk;
-        const long tiles = (long)((rows + ho - 1) / ho) * (long)((cols + wo - 1) / wo);
-        if (tiles <= ctx->cu_count && tiles <= kWindowMaxTiles) { *rpw = r; *k = kk; return true; }
+    std::vector<GsWindowDesc> plan;
+    if (ctx->cu_count <= 0 || rows == 0 || cols == 0 || rows > 0x7fffff || cols > 0x7fffff) return plan;
+    const int k = want_k > 0 ? want_k : 4;
+    if (k < 2 || k > 8 || (k & 1)) return plan;
+    const bool cheap = fast_of(ctx) & 1 && ctx->o.math == GS_MATH_STRICT && gs_env_int("GS_HIP_EDGE_KINDS", 1, 0, 1) != 0;
+    const bool zero_halo = ctx->o.boundary == GS_BOUNDARY_ZERO_HALO;
+    const long wo = 128 - 2 * k;
+    const long tiles_c = (long)((cols + wo - 1) / wo);
+    int forced[3] = {0, 0, 0};
+    if (const char *e = std::getenv("GS_HIP_WINDOW_WAVES")) (void)std::sscanf(e, "%d,%d,%d", &forced[0], &forced[1], &forced[2]);
+    for (int rpw : {5, 6}) {
+        if (want_rpw > 0 && want_rpw != rpw) continue;
+        const int min_waves = (2 * k + rpw) / rpw; // at least one owned row
+        plan.clear();
+        bool ok = true;
+        std::vector<long> col_first; // index of the first window of every tile column
+        std::vector<int> col_oh;
+        for (long tc = 0; tc < tiles_c && ok; ++tc) {
+            const bool left = tc == 0, right = tc == tiles_c - 1;
+            double cost = 1.0;
+            if (left || right) {
+                if (zero_halo) cost = 1.05;
+                else if (!cheap || (left && right)) cost = 1.6;
+                else cost = left ? 1.20 : 1.13;
+            }
+            int waves = (int)(16.0 / cost + 0.5);
+            const int f = left ? forced[0] : (right ? forced[2] : forced[1]);
+            if (f > 0) waves = f;
+            if (waves > 16) waves = 16;
+            if (waves < min_waves) waves = min_waves;
+            const int active = waves * rpw, oh = active - 2 * k;
+            col_first.push_back((long)plan.size());
+            col_oh.push_back(oh);
+            for (uint64_t r0 = 0; r0 < rows; r0 += (uint64_t)oh) {
+                GsWindowDesc d;
+                std::memset(&d, 0, sizeof d);
+                d.r0 = (int32_t)r0;
+                d.c0 = (int32_t)(tc * wo);
+                d.oh = oh;
+                d.ow = (int32_t)wo;
+                d.active = active;
+                plan.push_back(d);
+                if ((long)plan.size() > ctx->cu_count || plan.size() > (size_t)kWindowMaxTiles) { ok = false; break; }
+            }
+        }
+        if (!ok) continue;
+        // neighbours: every window whose owned cells (inside the grid) lie in this window's apron
+        for (size_t i = 0; i < plan.size() && ok; ++i) {
+            GsWindowDesc &d = plan[i];
+            const long tc = d.c0 / wo;
+            for (long nc = tc - 1; nc <= tc + 1 && ok; ++nc) {
+                if (nc < 0 || nc >= tiles_c) continue;
+                const long first = col_first[(size_t)nc], oh = col_oh[(size_t)nc];
+                const long last = (nc + 1 < tiles_c ? col_first[(size_t)nc + 1] : (long)plan.size()) - 1;
+                // rows [r0 - k, r0 + oh + k) clipped to the grid, in that column's windows
+                long lo = (long)d.r0 - k, hi = (long)d.r0 + d.oh + k - 1;
+                if (lo < 0) lo = 0;
+                if (hi > (long)rows - 1) hi = (long)rows - 1;
+                for (long j = first + lo / oh; j <= first + hi / oh && j <= last; ++j) {
+                    if ((size_t)j == i) continue;
+                    if (d.n_nbr >= kGsWindowMaxNbr) { ok = false; break; }
+                    d.nbr[d.n_nbr++] = (int32_t)j;
+                }
+            }
+        }
+        if (!ok) continue;
+        *rpw_out = rpw;
+        *k_out = k;
+        return plan;
     }
-    return false;
+    plan.clear();
+    return plan;
 }
 
 // Exchange planes, flags and abort word for planes of this shape (allocated on first use, re-made when the shape changes).
@@ -664,6 +733,7 @@ int32_t ensure_window_rt(gs_ctx *ctx, const gs_field *f)
         // on the stream the launches use: the context's streams are non-blocking, a hipMemset on the null stream
         // would not be ordered before them (and the words may hold a freed context's flags)
         GS_HIP(hipMemsetAsync(w.words, 0, (kWindowMaxTiles + 1) * sizeof(int32_t), ctx->slabs[0].compute));
+        GS_HIP(hipMalloc(reinterpret_cast<void **>(&w.desc), kWindowMaxTiles * sizeof(GsWindowDesc)));
         w.epoch = 0;
     }
     if (w.rows != f->rows || w.pitch != (uint64_t)f->pitch || !w.planes[0]) {
@@ -1409,10 +1479,11 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
             if (b.halod[k]) (void)hipEventDestroy(b.halod[k]);
         }
     }
-    if (!ctx->slabs.empty() && (ctx->win.words || ctx->win.planes[0]) && hipSetDevice(ctx->slabs[0].device) == hipSuccess) {
+    if (!ctx->slabs.empty() && (ctx->win.words || ctx->win.planes[0] || ctx->win.desc) && hipSetDevice(ctx->slabs[0].device) == hipSuccess) {
         for (auto p : ctx->win.planes)
             if (p) (void)hipFree(p);
         if (ctx->win.words) (void)hipFree(ctx->win.words);
+        if (ctx->win.desc) (void)hipFree(ctx->win.desc);
     }
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
@@ -1842,57 +1913,66 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     // 435 k for the marching kernel (441 k / 437 k under the zero-halo rule) -- a step costs 3.0 us per window (3.6 in the
     // windows on the grid's left edge, which set the pace) and an exchange 6.9 us on the critical path
     // (profiles/r04_window_kernel.md).
-    {
-        int rpw = 0, wk = 0;
-        const bool forced = ctx->o.kernel == GS_KERNEL_WINDOW && !ctx->win.disabled;
-        if (single && cells > 0 && steps > 0 && forced &&
-            pick_window_config(ctx, u0->rows, u0->cols, ctx->o.rows_per_block > 0 ? ctx->o.rows_per_block / 16 : 0, ctx->o.fuse_steps,
-                               &rpw, &wk)) {
-            SlabRt &sl = ctx->slabs[0];
-            GS_HIP(hipSetDevice(sl.device));
-            GS_TRY(join_bands(ctx, sl.compute));
-            ctx->bands_active = false;
+    if (single && cells > 0 && steps > 0 && ctx->o.kernel == GS_KERNEL_WINDOW && !ctx->win.disabled) {
+        gs_ctx::WindowRt &w = ctx->win;
+        SlabRt &sl = ctx->slabs[0];
+        GS_HIP(hipSetDevice(sl.device));
+        // the tiling of this grid (made once per shape and configuration, kept on the device)
+        const int want_rpw = ctx->o.rows_per_block > 0 ? ctx->o.rows_per_block / 16 : 0;
+        const int key = ((ctx->o.boundary * 2 + (ctx->o.math == GS_MATH_FUSED)) * 4 + fast_of(ctx)) * 64 + want_rpw * 8 + ctx->o.fuse_steps;
+        if (w.plan_n == 0 || w.plan_rows != u0->rows || w.plan_cols != u0->cols || w.plan_key != key) {
+            int rpw = 0, wk = 0;
+            const std::vector<GsWindowDesc> plan = plan_windows(ctx, u0->rows, u0->cols, want_rpw, ctx->o.fuse_steps, &rpw, &wk);
+            if (plan.empty())
+                return fail(GS_ERR_UNSUPPORTED, "GS_KERNEL_WINDOW needs a grid of at most one window per compute unit (%d); "
+                                                "%llu x %llu cells do not fit", ctx->cu_count, (unsigned long long)u0->rows,
+                            (unsigned long long)u0->cols);
             GS_TRY(ensure_window_rt(ctx, u0));
-            uint64_t left = steps;
-            int slot = 0;
-            while (left > 0) { // (the step count is an int in the kernel; a launch goes in-planes -> out-planes)
-                const int n = left > (1u << 20) ? (1 << 20) : (int)left;
-                GsStepArgs a = make_args(ctx, r.u[slot], r.v[slot], r.u[1 - slot], r.v[1 - slot], 0, 1);
-                GsWindowArgs x;
-                std::memset(&x, 0, sizeof x);
-                x.xu[0] = ctx->win.planes[0]; x.xu[1] = ctx->win.planes[1];
-                x.xv[0] = ctx->win.planes[2]; x.xv[1] = ctx->win.planes[3];
-                x.flags = ctx->win.words;
-                x.abort = ctx->win.words + kWindowMaxTiles;
-                x.steps = n;
-                x.k = wk;
-                x.epoch = ctx->win.epoch;
-                const long ho = 16L * rpw - 2 * wk, wo = 128L - 2 * wk;
-                x.tiles_r = (int32_t)((a.rows + ho - 1) / ho);
-                x.tiles_c = (int32_t)((a.cols + wo - 1) / wo);
-                x.patience = gs_env_int("GS_HIP_WINDOW_PATIENCE", 1 << 22, 1, 1 << 30); // polls of ~1 us each: ~4 s
-                const char *name = nullptr;
-                const hipError_t e = ctx->o.math == GS_MATH_FUSED ? gs_launch_window_fused(a, x, rpw, sl.compute, &name)
-                                                                   : gs_launch_window_strict(a, x, rpw, sl.compute, &name);
-                if (e != hipSuccess) return fail(GS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-                const int supers = (n + wk - 1) / wk;
-                ctx->win.epoch += supers;
-                ctx->win.pending = true;
-                ctx->last_kernel = name;
-                ctx->launches++;
-                ctx->passes += (uint64_t)supers;
-                ctx->steps_done += (uint64_t)n;
-                ctx->step_no++;
-                slot ^= 1;
-                left -= (uint64_t)n;
-            }
-            if (result_slot) *result_slot = slot;
-            return GS_OK;
+            GS_TRY(sync_all(ctx)); // no launch may still be reading the old tiling
+            GS_HIP(hipMemcpy(w.desc, plan.data(), plan.size() * sizeof(GsWindowDesc), hipMemcpyHostToDevice));
+            w.plan_rows = u0->rows; w.plan_cols = u0->cols; w.plan_key = key;
+            w.plan_rpw = rpw; w.plan_k = wk; w.plan_n = (int)plan.size();
+            // the flags belong to the workgroups of the old tiling: start over
+            GS_HIP(hipMemsetAsync(w.words, 0, kWindowMaxTiles * sizeof(int32_t), sl.compute));
+            w.epoch = 0;
         }
-        if (forced && single && cells > 0 && steps > 0)
-            return fail(GS_ERR_UNSUPPORTED, "GS_KERNEL_WINDOW needs a grid of at most one %d x %d-cell window per compute unit (%d)",
-                        16 * (ctx->o.rows_per_block > 0 ? ctx->o.rows_per_block / 16 : 6) - 2 * (ctx->o.fuse_steps > 0 ? ctx->o.fuse_steps : 4),
-                        128 - 2 * (ctx->o.fuse_steps > 0 ? ctx->o.fuse_steps : 4), ctx->cu_count);
+        GS_TRY(join_bands(ctx, sl.compute));
+        ctx->bands_active = false;
+        GS_TRY(ensure_window_rt(ctx, u0));
+        uint64_t left = steps;
+        int slot = 0;
+        while (left > 0) { // (the step count is an int in the kernel; a launch goes in-planes -> out-planes)
+            const int n = left > (1u << 20) ? (1 << 20) : (int)left;
+            GsStepArgs a = make_args(ctx, r.u[slot], r.v[slot], r.u[1 - slot], r.v[1 - slot], 0, 1);
+            GsWindowArgs x;
+            std::memset(&x, 0, sizeof x);
+            x.xu[0] = w.planes[0]; x.xu[1] = w.planes[1];
+            x.xv[0] = w.planes[2]; x.xv[1] = w.planes[3];
+            x.flags = w.words;
+            x.abort = w.words + kWindowMaxTiles;
+            x.desc = w.desc;
+            x.n_windows = w.plan_n;
+            x.steps = n;
+            x.k = w.plan_k;
+            x.epoch = w.epoch;
+            x.patience = gs_env_int("GS_HIP_WINDOW_PATIENCE", 1 << 22, 1, 1 << 30); // polls of ~1 us each: ~4 s
+            const char *name = nullptr;
+            const hipError_t e = ctx->o.math == GS_MATH_FUSED ? gs_launch_window_fused(a, x, w.plan_rpw, sl.compute, &name)
+                                                               : gs_launch_window_strict(a, x, w.plan_rpw, sl.compute, &name);
+            if (e != hipSuccess) return fail(GS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+            const int supers = (n + w.plan_k - 1) / w.plan_k;
+            w.epoch += supers;
+            w.pending = true;
+            ctx->last_kernel = name;
+            ctx->launches++;
+            ctx->passes += (uint64_t)supers;
+            ctx->steps_done += (uint64_t)n;
+            ctx->step_no++;
+            slot ^= 1;
+            left -= (uint64_t)n;
+        }
+        if (result_slot) *result_slot = slot;
+        return GS_OK;
     }
     // The short pass goes first so that a run ends on a full pass -- a full-depth ghost exchange -- and the
     // next run can start without a blocking refresh.  It is sized with the steps per pass in force (a

@@ -72,20 +72,32 @@ struct GsStepArgs {
 };
 
 // gs_launch_window_*: one persistent launch for a whole gs_run on grids of ONE round of register-resident windows.
-// Workgroup (tr, tc) owns rows [tr * HO, (tr + 1) * HO) x columns [tc * WO, (tc + 1) * WO) of the grid, HO = 16 * rpw
-// - 2 k, WO = 128 - 2 k, and keeps them plus a k-cell apron in registers; every k steps it stores the k-cell ring of its
-// owned cells into the exchange planes, raises its flag, waits for the flags of its (up to 8) neighbours and loads its
-// apron from their rings.  Exchange e uses the planes of parity e & 1.  The input planes are never written: a launch
-// that gives up (abort set) has destroyed nothing.
+// Every workgroup owns a rectangle of the grid (GsWindowDesc; the rectangles tile the grid) and keeps it plus a k-cell
+// apron in registers: `active` window rows (waves beyond them idle) x 128 columns.  Every k steps it stores the k-cell
+// ring of its owned cells into the exchange planes, raises its flag, waits for the flags of the workgroups whose
+// cells its apron covers (`nbr`) and loads its apron from their rings.  Exchange e uses the planes of parity e & 1.
+// The input planes are never written: a launch that gives up (abort set) has destroyed nothing.
+// Windows of one tile column share their height, and columns whose cells cost more (the grid's left and right edge
+// under the clipped rule) get lower windows, so that every workgroup's step takes the same time: they all wait for
+// their neighbours at every exchange, the slowest sets the pace (gs_api.cpp: plan_windows).
+constexpr int kGsWindowMaxNbr = 14;
+struct GsWindowDesc {
+    int32_t r0, c0;    // first owned row / column (global)
+    int32_t oh, ow;    // owned rows / columns (the last window of a tile column / row may reach beyond the grid)
+    int32_t active;    // window rows in use: oh + 2 k rounded up to whole waves (a multiple of rpw, <= 16 rpw)
+    int32_t n_nbr;     // workgroups whose owned cells lie in this window's apron
+    int32_t nbr[kGsWindowMaxNbr];
+};
 struct GsWindowArgs {
-    float *xu[2], *xv[2]; // exchange planes: local row 0, column 0; the field planes' pitch, at least the grid's rows
-    int32_t *flags;       // one per workgroup; a workgroup that has finished exchange e holds epoch + e + 1
-    int32_t *abort;       // sticky: a poll ran out of patience (workgroups not co-resident); every workgroup then leaves
-    int32_t steps;        // time steps of this launch (>= 1)
-    int32_t k;            // steps per exchange: even, 2 ... 8, less than half the window's rows
-    int32_t epoch;        // flags left by earlier launches are <= epoch
-    int32_t tiles_r, tiles_c;
-    int32_t patience;     // polls before a workgroup gives up
+    float *xu[2], *xv[2];      // exchange planes: local row 0, column 0; the field planes' pitch, at least the grid's rows
+    int32_t *flags;            // one per workgroup; a workgroup that has finished exchange e holds epoch + e + 1
+    int32_t *abort;            // sticky: a poll ran out of patience (workgroups not co-resident); every workgroup then leaves
+    const GsWindowDesc *desc;  // one per workgroup (device memory)
+    int32_t n_windows;
+    int32_t steps;             // time steps of this launch (>= 1)
+    int32_t k;                 // steps per exchange: even, 2 ... 8
+    int32_t epoch;             // flags left by earlier launches are <= epoch
+    int32_t patience;          // polls before a workgroup gives up
 };
 
 // Launchers, one set per arithmetic flavour (see gs_math in include/gs_hip.h).  Each

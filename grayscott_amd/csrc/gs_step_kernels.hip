@@ -1234,7 +1234,7 @@ __host__ __device__ constexpr size_t win_lds_bytes() { return (size_t)2 * 2 * kW
 // (parity of the LDS buffer).
 template <int RPW, int EDGE, int FAST, int ZH>
 __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, int n, int &step, int gr, int gc, int wave, int lane,
-                                             float (&u)[RPW][2], float (&v)[RPW][2])
+                                             bool active, float (&u)[RPW][2], float (&v)[RPW][2])
 {
     constexpr int P = kWinPitch;
     constexpr bool ROWS = EDGE == 1 || EDGE == 4 || EDGE == 5 || EDGE == 6;
@@ -1265,6 +1265,10 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
     };
     for (int s = 0; s < n; ++s, ++step) {
         const int buf = step & 1;
+        if (!active) { // a wave beyond the window's rows in use only keeps the barrier count
+            __syncthreads();
+            continue;
+        }
         *reinterpret_cast<float2 *>(row_of(buf, 0, wave, 0)) = make_float2(u[0][0], u[0][1]);
         *reinterpret_cast<float2 *>(row_of(buf, 1, wave, 0)) = make_float2(v[0][0], v[0][1]);
         *reinterpret_cast<float2 *>(row_of(buf, 0, wave, 1)) = make_float2(u[RPW - 1][0], u[RPW - 1][1]);
@@ -1272,6 +1276,7 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
         // One cell row: old rows (m, z, p) -> new values of row r, written in place.
         auto update = [&](int r, const RowT<2> &m, const RowT<2> &z, const RowT<2> &p) {
             const int row = gr + r; // wave-uniform
+            if (EDGE != 0 && (row < 0 || row >= a.rows)) return; // a row outside the grid: zeros that stay zeros
             const bool mrow = !ROWS || row > 0, prow = !ROWS || row + 1 < a.rows;
             float nu[2], nv[2];
             if constexpr (EDGE == 0 || EDGE == 7) {
@@ -1292,10 +1297,9 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
 #pragma unroll
                 for (int j = 0; j < 2; ++j) cell<EDGE, FAST, RowT<2>, ZH>(a, m, z, p, 1 + j, mrow, prow, la[j], ra[j], nu[j], nv[j]);
             }
-            const bool row_in = row >= 0 && row < a.rows;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const bool in = EDGE == 0 || (row_in && col_in[j]);
+                const bool in = EDGE == 0 || col_in[j];
                 u[r][j] = in ? nu[j] : 0.0f;
                 v[r][j] = in ? nv[j] : 0.0f;
             }
@@ -1363,29 +1367,31 @@ __device__ unsigned long long gs_win_trace[1024 * 8 * 8];
 #endif
 
 template <int RPW, int EDGE, int FAST, int ZH>
-__device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowArgs &x, float *lds, int *go, int wg, int tr, int tc,
+__device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowArgs &x, const GsWindowDesc *d, float *lds, int *go, int wg,
                                            int gr, int gc, int wave, int lane, float (&u)[RPW][2], float (&v)[RPW][2])
 {
-    constexpr int H = win_rows(RPW), SC1 = 16;
+    constexpr int SC1 = 16;
     typedef float v2f __attribute__((ext_vector_type(2)));
     const int K = x.k, wc = 2 * lane; // wc: this lane's first window column
+    const int H = d->active, OW = d->ow; // window rows in use; owned columns (window columns [K, K + OW))
+    const bool active = wave * RPW < H;
     int step = 0;
     const int supers = (x.steps + K - 1) / K;
     for (int s = 0; s < supers; ++s) {
         GS_WIN_TRACE_AT(0);
         // the short super-step first
-        window_steps<RPW, EDGE, FAST, ZH>(a, lds, (s == 0 && x.steps % K) ? x.steps % K : K, step, gr, gc, wave, lane, u, v);
+        window_steps<RPW, EDGE, FAST, ZH>(a, lds, (s == 0 && x.steps % K) ? x.steps % K : K, step, gr, gc, wave, lane, active, u, v);
         GS_WIN_TRACE_AT(1);
         if (s == supers - 1) break;
         // ---- exchange s: ring out, flag, poll, apron in -------------------------------------------------------
         const __amdgpu_buffer_rsrc_t xu = win_rsrc(x.xu[s & 1]), xv = win_rsrc(x.xv[s & 1]);
-        const bool lane_owned = wc >= K && wc < kWinCols - K && gc < a.cols;
-        const bool lane_ring = wc < 2 * K || wc >= kWinCols - 2 * K;
+        const bool lane_owned = wc >= K && wc < K + OW && gc < a.cols;
+        const bool lane_ring = wc < 2 * K || wc >= OW;
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int wr = wave * RPW + r; // wave-uniform
-            const bool row_owned = wr >= K && wr < H - K && gr + r < a.rows;
-            const bool row_ring = wr < 2 * K || wr >= H - 2 * K;
+            const bool row_owned = wr >= K && wr < K + d->oh && gr + r < a.rows;
+            const bool row_ring = wr < 2 * K || wr >= d->oh;
             if (row_owned && lane_owned && (row_ring || lane_ring)) {
                 const int off = ((gr + r) * a.pitch + gc) * (int)sizeof(float);
                 const v2f su = {u[r][0], u[r][1]}, sv = {v[r][0], v[r][1]};
@@ -1400,11 +1406,12 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
         if (wave == 0) {
             const int target = x.epoch + s + 1;
             if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(target, win_rsrc(x.flags), wg * 4, 0, SC1);
-            const int dy = lane / 3 - 1, dx = lane % 3 - 1, ny = tr + dy, nx = tc + dx;
-            const bool watch = lane < 9 && lane != 4 && ny >= 0 && ny < x.tiles_r && nx >= 0 && nx < x.tiles_c;
+            // one lane per workgroup whose cells this window's apron covers: one vector load polls them all
+            const bool watch = lane < d->n_nbr;
+            const int theirs = watch ? d->nbr[lane] : 0;
             int ok = 1, spins = 0;
             for (;;) {
-                const int seen = watch ? __builtin_amdgcn_raw_buffer_load_b32(win_rsrc(x.flags), (ny * x.tiles_c + nx) * 4, 0, SC1) : target;
+                const int seen = watch ? __builtin_amdgcn_raw_buffer_load_b32(win_rsrc(x.flags), theirs * 4, 0, SC1) : target;
                 if (!__builtin_amdgcn_ballot_w64(seen - target < 0)) break;
                 if (++spins > x.patience || __builtin_amdgcn_raw_buffer_load_b32(win_rsrc(x.abort), 0, 0, SC1) != 0) { ok = 0; break; }
                 __builtin_amdgcn_s_sleep(2);
@@ -1419,13 +1426,13 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
         if (!*go) return; // (workgroup-uniform)
         GS_WIN_TRACE_AT(5);
         const bool lane_in = gc >= 0 && gc < a.cols;
-        const bool lane_apron = (wc < K || wc >= kWinCols - K) && lane_in;
+        const bool lane_apron = (wc < K || wc >= K + OW) && wc < 2 * K + OW && lane_in;
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int wr = wave * RPW + r;
             const bool row_in = gr + r >= 0 && gr + r < a.rows;
-            const bool row_apron = wr < K || wr >= H - K;
-            if (row_in && ((row_apron && lane_in) || lane_apron)) {
+            const bool row_apron = (wr < K || wr >= K + d->oh) && wr < 2 * K + d->oh;
+            if (row_in && wr < 2 * K + d->oh && ((row_apron && lane_in && wc < 2 * K + OW) || lane_apron)) {
                 const int off = ((gr + r) * a.pitch + gc) * (int)sizeof(float);
                 const v2f fu = __builtin_amdgcn_raw_buffer_load_b64(xu, off, 0, SC1);
                 const v2f fv = __builtin_amdgcn_raw_buffer_load_b64(xv, off, 0, SC1);
@@ -1441,11 +1448,11 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
     }
     // the cells this workgroup owns, where they lie in the grid (8-byte stores; a second column beyond `cols` lands in
     // the planes' padding columns, which nothing reads)
-    if (wc >= K && wc < kWinCols - K && gc < a.cols) {
+    if (wc >= K && wc < K + OW && gc < a.cols) {
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int wr = wave * RPW + r;
-            if (wr >= K && wr < H - K && gr + r < a.rows) {
+            if (wr >= K && wr < K + d->oh && gr + r < a.rows) {
                 const int off = ((gr + r) * a.pitch + gc) * (int)sizeof(float);
                 const v2f su = {u[r][0], u[r][1]}, sv = {v[r][0], v[r][1]};
                 __builtin_amdgcn_raw_buffer_store_b64(su, win_rsrc(a.out_u), off, 0, 0);
@@ -1461,14 +1468,15 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
     if ((FAST & 1) && !GS_MATH_FUSED) __builtin_amdgcn_s_setreg(1 | (9 << 6), 0); // half_diff: MODE.IEEE = 0
     extern __shared__ float lds[];
     __shared__ int go;
-    constexpr int H = win_rows(RPW), SC1 = 16;
+    constexpr int SC1 = 16;
     typedef float v2f __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int K = x.k;
-    const int HO = H - 2 * K, WO = kWinCols - 2 * K; // rows / columns a workgroup owns
-    const int wg = (int)blockIdx.x, tr = wg / x.tiles_c, tc = wg - tr * x.tiles_c;
-    const int gr0 = tr * HO - K, gc0 = tc * WO - K;         // global coordinates of window cell (0, 0)
+    const int wg = (int)blockIdx.x;
+    const GsWindowDesc *d = x.desc + wg;                    // (uniform: scalar loads)
+    const int H = d->active;                                // window rows in use
+    const int gr0 = d->r0 - K, gc0 = d->c0 - K;             // global coordinates of window cell (0, 0)
     const int gr = gr0 + wave * RPW, gc = gc0 + 2 * lane;   // this lane's first cell
     // A launch enqueued behind one that gave up leaves at once (nothing of it is valid anyway).  ONE wave reads the
     // word for the whole workgroup: waves that read it for themselves could disagree (a workgroup of this launch may
@@ -1482,10 +1490,14 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
 #pragma unroll
         for (int b = 0; b < 8; ++b)
             lds[(((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + (lane == 0 ? 1 : 129 + lane)] = 0.0f;
+    if (wave * RPW >= H) // a wave beyond the window's rows in use publishes zeros once: the last wave in use reads them
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            *reinterpret_cast<float2 *>(lds + (((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + 2 + 2 * lane) = make_float2(0.0f, 0.0f);
     float u[RPW][2], v[RPW][2];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-        const bool in = gr + r >= 0 && gr + r < a.rows && gc >= 0 && gc < a.cols;
+        const bool in = gr + r >= 0 && gr + r < a.rows && gc >= 0 && gc < a.cols && wave * RPW + r < H;
         v2f fu = {0.0f, 0.0f}, fv = {0.0f, 0.0f};
         if (in) { // 8-byte loads: gc is even and the row pitch a multiple of 64 floats
             const int off = ((gr + r) * a.pitch + gc) * (int)sizeof(float);
@@ -1496,10 +1508,10 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
         u[r][0] = fu[0]; u[r][1] = in1 ? fu[1] : 0.0f;
         v[r][0] = fv[0]; v[r][1] = in1 ? fv[1] : 0.0f;
     }
-    const bool left = gc0 <= 0, right = gc0 + kWinCols >= a.cols, ends = gr0 <= 0 || gr0 + H >= a.rows;
+    const bool left = gc0 <= 0, right = gc0 + 2 * K + d->ow >= a.cols, ends = gr0 <= 0 || gr0 + H >= a.rows;
     const bool edge = left || right || ends;
     constexpr bool KINDS = (FAST & 1) && !GS_MATH_FUSED;
-#define GS_WIN_RUN(E, Z) window_run<RPW, E, FAST, Z>(a, x, lds, &go, wg, tr, tc, gr, gc, wave, lane, u, v)
+#define GS_WIN_RUN(E, Z) window_run<RPW, E, FAST, Z>(a, x, d, lds, &go, wg, gr, gc, wave, lane, u, v)
     // One branch per workgroup, one instantiation per kind of window (as gs_step_tb_k): the cheap kinds exist for the
     // clipped rule with the default side weights in the strict build; a grid narrower than one window, general
     // weights and the fused build take the general path in their edge windows.
@@ -1759,16 +1771,15 @@ hipError_t GS_SUFFIX(gs_launch_tile)(const GsStepArgs &a, int k, int shape, hipS
 }
 
 // One persistent launch of gs_run_window_k: `x.steps` time steps of a single slab, in-planes -> out-planes.
-// rpw: rows per wave (window = 16 rpw rows x 128 columns); the caller sized x.tiles_r / x.tiles_c for it.
+// rpw: rows per wave (a window is at most 16 rpw rows x 128 columns); x.desc holds the caller's tiling of the grid.
 hipError_t GS_SUFFIX(gs_launch_window)(const GsStepArgs &a, const GsWindowArgs &x, int rpw, hipStream_t s, const char **name)
 {
-    static const char *const names[2][2] = {{"window80x128/" GS_MATH_NAME, "window80x128/" GS_MATH_NAME ".op"},
-                                            {"window96x128/" GS_MATH_NAME, "window96x128/" GS_MATH_NAME ".op"}};
+    static const char *const names[2][2] = {{"window-r5/" GS_MATH_NAME, "window-r5/" GS_MATH_NAME ".op"},
+                                            {"window-r6/" GS_MATH_NAME, "window-r6/" GS_MATH_NAME ".op"}};
     if (a.rows <= 0 || a.cols <= 0 || a.top_present || a.bottom_present || (rpw != 5 && rpw != 6) || x.steps < 1 || x.k < 2 ||
-        x.k > 8 || (x.k & 1) || 2 * x.k >= win_rows(rpw) || !x.flags || !x.abort || !x.xu[0] || !x.xu[1] || !x.xv[0] || !x.xv[1])
+        x.k > 8 || (x.k & 1) || 2 * x.k >= win_rows(rpw) || 2 * x.k + 2 > kWinCols || !x.flags || !x.abort || !x.xu[0] || !x.xu[1] || !x.xv[0] || !x.xv[1])
         return hipErrorInvalidValue;
-    const long ho = win_rows(rpw) - 2 * x.k, wo = kWinCols - 2 * x.k;
-    if (x.tiles_r != (a.rows + ho - 1) / ho || x.tiles_c != (a.cols + wo - 1) / wo) return hipErrorInvalidValue;
+    if (!x.desc || x.n_windows < 1) return hipErrorInvalidValue;
     // byte offsets inside a plane are 32-bit in the kernel
     if ((long)(a.rows + 8) * a.pitch * 4 > 0x7fffffffL) return hipErrorInvalidValue;
     int fast = a.fast & (GS_MATH_FUSED ? 0 : 3);
@@ -1787,7 +1798,7 @@ hipError_t GS_SUFFIX(gs_launch_window)(const GsStepArgs &a, const GsWindowArgs &
     GsStepArgs args = a;
     GsWindowArgs xa = x;
     void *kargs[] = {&args, &xa};
-    return hipLaunchKernel(fn, dim3((unsigned)(x.tiles_r * x.tiles_c)), dim3(kWinWaves * 64), kargs, lds, s);
+    return hipLaunchKernel(fn, dim3((unsigned)x.n_windows), dim3(kWinWaves * 64), kargs, lds, s);
 }
 
 hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const char **name)

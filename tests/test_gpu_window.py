@@ -36,7 +36,7 @@ def test_window_kernel_bit_exact(boundary, window_rows, k):
             ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True, boundary=boundary)
             got_u, got_v, info = gpu_run(u0, v0, steps, args=args(kernel=capi.GS_KERNEL_WINDOW, boundary=boundary,
                                                                   rows_per_block=window_rows, fuse_steps=k))
-            assert info[0] == f"window{window_rows or 80}x128/strict.op" and info[1] == 1, info    # ONE launch
+            assert info[0] == f"window-r{(window_rows or 80) // 16}/strict.op" and info[1] == 1, info    # ONE launch
             assert_bits_equal(got_u, ref_u, f"window U {shape} steps {steps} k {k}")
             assert_bits_equal(got_v, ref_v, f"window V {shape} steps {steps} k {k}")
 
@@ -48,13 +48,13 @@ def test_window_kernel_variants():
         for boundary in (capi.GS_BOUNDARY_CLIPPED, capi.GS_BOUNDARY_ZERO_HALO):
             ref_u, ref_v = oracle.run(u0, v0, 19, params=oracle_params(params), ftz=True, boundary=boundary)
             got_u, got_v, info = gpu_run(u0, v0, 19, params=params, args=args(kernel=capi.GS_KERNEL_WINDOW, boundary=boundary))
-            assert info[0].startswith("window80x128/strict"), info
+            assert info[0].startswith("window-r5/strict"), info
             assert info[0].endswith(".op") == (params.weights == Parameters().weights and params.time_step == 1.0), info
             assert_bits_equal(got_u, ref_u, f"window U {params}")
             assert_bits_equal(got_v, ref_v, f"window V {params}")
     ref_u, ref_v = oracle.run(u0, v0, 19, ftz=False)
     got_u, got_v, info = gpu_run(u0, v0, 19, args=args(math=capi.GS_MATH_FUSED, kernel=capi.GS_KERNEL_WINDOW))
-    assert info[0] == "window80x128/fused", info
+    assert info[0] == "window-r5/fused", info
     assert np.max(np.abs(got_u - ref_u)) <= 1e-37 and np.max(np.abs(got_v - ref_v)) <= 1e-37
     # the general path of every edge window (no cheap kinds): same bits
     import os
@@ -89,7 +89,7 @@ def test_window_kernel_species_new_uneven_calls_and_single_steps():
     total = 0
     for steps in (1, 7, 256, 333, 403):
         sim.perform_steps(species, steps)
-        assert sim.context.info()[0] == "window80x128/strict.op"
+        assert sim.context.info()[0] == "window-r5/strict.op"
         sim.perform_step(species)          # gs_step: the stream kernel, then back
         total += steps + 1
     u, v = oracle.run(u, v, total, ftz=True)
@@ -106,7 +106,7 @@ def test_config1_1080x1920_1000_steps_through_the_window_kernel():
     sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_WINDOW))
     species = sim.make_species([rows, cols])
     sim.perform_steps(species, steps)
-    assert sim.context.info() == ("window80x128/strict.op", 1)
+    assert sim.context.info() == ("window-r5/strict.op", 1)
     u, v = oracle.run(*oracle.init_species(rows, cols), steps, ftz=True)
     in_u, in_v, _, _ = species.in_out()
     assert_bits_equal(in_u.make_scalar_view(sim.context), u, "config 1 U")
@@ -189,7 +189,7 @@ def test_window_kernel_soak_against_the_marching_kernel():
         sp = bench.upload_species(sim, u0, v0)
         for n in calls:
             sim.perform_steps(sp, n)
-        assert sim.context.info()[0] == "window80x128/strict.op"
+        assert sim.context.info()[0] == "window-r5/strict.op"
         torch.cuda.synchronize()
         for name, a, b in (("U", sp.in_out()[0], sr.in_out()[0]), ("V", sp.in_out()[1], sr.in_out()[1])):
             (_, _, x), = a.torch_views()
