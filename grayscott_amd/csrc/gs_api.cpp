@@ -223,6 +223,11 @@ struct gs_ctx {
         int32_t epoch = 0;
         bool pending = false;  // a launch has been enqueued since the abort word was last read
         bool disabled = false; // a launch gave up once: this context stays with the marching kernel
+        // the gs_run calls behind `pending`, in order: if a launch gave up, none of them took a step (the abort word is
+        // sticky) and they are run again with the marching kernel (resolve_window)
+        struct Run { gs_field *f[4]; uint64_t steps; int slot; };
+        std::vector<Run> runs;
+        uint64_t fallbacks = 0;
     } win;
     int cu_count = 0; // compute units of the first slab's device
     int total_slabs() const { return world * (int)slabs.size(); }
@@ -282,6 +287,48 @@ int32_t same_shape(const gs_field *a, const gs_field *b)
     return GS_OK;
 }
 
+int32_t run_steps(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *v1, uint64_t steps, int32_t *result_slot,
+                  bool allow_window);
+
+// Did a persistent window launch (gs_run_window_k) give up?  Its workgroups poll each other's flags with bounded
+// patience; they only run out of it when they are not all resident, i.e. when another long-running kernel holds CUs.
+// Then NONE of the launches enqueued since the last check took a step (the abort word is sticky, the input planes are
+// only read): they are run again, in order, with the marching kernel, their results put where gs_run said they would be,
+// and the context stays with the marching kernel.  Called by everything that waits for or reads results.
+int32_t resolve_window(gs_ctx *ctx)
+{
+    gs_ctx::WindowRt &w = ctx->win;
+    if (!w.pending) return GS_OK;
+    w.pending = false;
+    SlabRt &sl = ctx->slabs[0];
+    GS_HIP(hipSetDevice(sl.device));
+    GS_HIP(hipStreamSynchronize(sl.compute));
+    int32_t gave_up = 0;
+    GS_HIP(hipMemcpy(&gave_up, w.words + kWindowMaxTiles, sizeof gave_up, hipMemcpyDeviceToHost));
+    std::vector<gs_ctx::WindowRt::Run> runs;
+    runs.swap(w.runs);
+    if (!gave_up) return GS_OK;
+    GS_HIP(hipMemsetAsync(w.words, 0, (kWindowMaxTiles + 1) * sizeof(int32_t), sl.compute));
+    w.epoch = 0;
+    w.disabled = true;
+    w.fallbacks++;
+    for (const auto &run : runs) {
+        int32_t slot = 0;
+        GS_TRY(run_steps(ctx, run.f[0], run.f[1], run.f[2], run.f[3], run.steps, &slot, false));
+        if (slot != run.slot) { // the marching kernel ends in the slot of the steps' parity: move the planes over
+            for (int sp = 0; sp < 2; ++sp) {
+                const gs_field *src = run.f[2 * slot + sp];
+                gs_field *dst = run.f[2 * run.slot + sp];
+                const size_t bytes = (size_t)src->s[0].rows * (size_t)src->pitch * sizeof(float);
+                GS_HIP(hipMemcpyAsync(dst->s[0].row0, src->s[0].row0, bytes, hipMemcpyDeviceToDevice, sl.compute));
+                dst->ghost_depth = src->ghost_depth;
+            }
+        }
+    }
+    GS_HIP(hipStreamSynchronize(sl.compute));
+    return GS_OK;
+}
+
 int32_t sync_all(gs_ctx *ctx)
 {
     for (auto &sl : ctx->slabs) {
@@ -295,23 +342,7 @@ int32_t sync_all(gs_ctx *ctx)
         GS_HIP(hipStreamSynchronize(b.halo));
         GS_HIP(hipStreamSynchronize(b.compute));
     }
-    if (ctx->win.pending) {
-        // Did a persistent window launch give up?  (Its workgroups poll each other's flags with bounded patience;
-        // they only run out of it when they are not all resident, i.e. when another long-running kernel holds CUs.)
-        ctx->win.pending = false;
-        int32_t gave_up = 0;
-        GS_HIP(hipSetDevice(ctx->slabs[0].device));
-        GS_HIP(hipMemcpy(&gave_up, ctx->win.words + kWindowMaxTiles, sizeof gave_up, hipMemcpyDeviceToHost));
-        if (gave_up) {
-            GS_HIP(hipMemsetAsync(ctx->win.words, 0, (kWindowMaxTiles + 1) * sizeof(int32_t), ctx->slabs[0].compute));
-            GS_HIP(hipStreamSynchronize(ctx->slabs[0].compute));
-            ctx->win.epoch = 0;
-            ctx->win.disabled = true;
-            return fail(GS_ERR_HIP, "a persistent window launch gave up waiting for a neighbouring workgroup (is another "
-                                    "long-running kernel resident on this GPU?): the steps of the last gs_run were not "
-                                    "taken, its input planes are intact; this context now uses the marching kernel");
-        }
-    }
+    GS_TRY(resolve_window(ctx));
     return GS_OK;
 }
 
@@ -674,7 +705,8 @@ std::vector<GsWindowDesc> plan_windows(const gs_ctx *ctx, uint64_t rows, uint64_
                 else if (!cheap || (left && right)) cost = 1.6;
                 else cost = left ? 1.20 : 1.13;
             }
-            int waves = (int)(16.0 / cost + 0.5);
+            // whole rounds of the 4 SIMDs only: 13 waves take the time of 16 (one SIMD holds four of them)
+            int waves = cost <= 1.08 ? 16 : 12;
             const int f = left ? forced[0] : (right ? forced[2] : forced[1]);
             if (f > 0) waves = f;
             if (waves > 16) waves = 16;
@@ -1808,11 +1840,97 @@ int32_t gs_field_mark_written(gs_ctx *ctx, gs_field *f)
 int32_t gs_step(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs_field *out_v)
 {
     GS_TRY(check_step_fields(ctx, in_u, in_v, out_u, out_v));
+    GS_TRY(resolve_window(ctx));
     return step_impl(ctx, in_u, in_v, out_u, out_v);
 }
 
 int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *v1, uint64_t steps,
                int32_t *result_slot)
+{
+    return run_steps(ctx, u0, v0, u1, v1, steps, result_slot, true);
+}
+
+} // extern "C"
+
+namespace {
+
+// gs_run through ONE persistent launch of gs_run_window_k per 2^20 steps (see run_steps).  *launched = 0 when the grid is
+// not one round of windows (an error if the kernel was forced).
+int32_t run_window(gs_ctx *ctx, Run &r, uint64_t steps, bool forced, int32_t *launched, int32_t *result_slot)
+{
+    gs_ctx::WindowRt &w = ctx->win;
+    gs_field *u0 = r.u[0];
+    SlabRt &sl = ctx->slabs[0];
+    *launched = 0;
+    GS_HIP(hipSetDevice(sl.device));
+    // the tiling of this grid (made once per shape and configuration, kept on the device)
+    const int want_rpw = ctx->o.rows_per_block > 0 ? ctx->o.rows_per_block / 16 : 0;
+    const int key = ((ctx->o.boundary * 2 + (ctx->o.math == GS_MATH_FUSED)) * 4 + fast_of(ctx)) * 64 + want_rpw * 8 + ctx->o.fuse_steps;
+    if (w.plan_rows != u0->rows || w.plan_cols != u0->cols || w.plan_key != key) {
+        int rpw = 0, wk = 0;
+        const std::vector<GsWindowDesc> plan = plan_windows(ctx, u0->rows, u0->cols, want_rpw, ctx->o.fuse_steps, &rpw, &wk);
+        GS_TRY(sync_all(ctx)); // no launch may still be reading the old tiling (or its flags)
+        w.plan_rows = u0->rows; w.plan_cols = u0->cols; w.plan_key = key;
+        w.plan_rpw = rpw; w.plan_k = wk; w.plan_n = (int)plan.size(); // (0: remembered as "not this grid")
+        if (!plan.empty()) {
+            GS_TRY(ensure_window_rt(ctx, u0));
+            GS_HIP(hipMemcpy(w.desc, plan.data(), plan.size() * sizeof(GsWindowDesc), hipMemcpyHostToDevice));
+            // the flags belong to the workgroups of the old tiling: start over
+            GS_HIP(hipMemsetAsync(w.words, 0, kWindowMaxTiles * sizeof(int32_t), sl.compute));
+            w.epoch = 0;
+        }
+    }
+    if (w.plan_n == 0) {
+        if (forced)
+            return fail(GS_ERR_UNSUPPORTED, "GS_KERNEL_WINDOW needs a grid of at most one window per compute unit (%d); "
+                                            "%llu x %llu cells do not fit", ctx->cu_count, (unsigned long long)u0->rows,
+                        (unsigned long long)u0->cols);
+        return GS_OK;
+    }
+    GS_TRY(join_bands(ctx, sl.compute));
+    ctx->bands_active = false;
+    GS_TRY(ensure_window_rt(ctx, u0));
+    uint64_t left = steps;
+    int slot = 0;
+    while (left > 0) { // (the step count is an int in the kernel; a launch goes in-planes -> out-planes)
+        const int n = left > (1u << 20) ? (1 << 20) : (int)left;
+        GsStepArgs a = make_args(ctx, r.u[slot], r.v[slot], r.u[1 - slot], r.v[1 - slot], 0, 1);
+        GsWindowArgs x;
+        std::memset(&x, 0, sizeof x);
+        x.xu[0] = w.planes[0]; x.xu[1] = w.planes[1];
+        x.xv[0] = w.planes[2]; x.xv[1] = w.planes[3];
+        x.flags = w.words;
+        x.abort = w.words + kWindowMaxTiles;
+        x.desc = w.desc;
+        x.n_windows = w.plan_n;
+        x.steps = n;
+        x.k = w.plan_k;
+        x.epoch = w.epoch;
+        x.patience = gs_env_int("GS_HIP_WINDOW_PATIENCE", 1 << 21, 1, 1 << 30); // polls of ~1 us each: ~2 s
+        const char *name = nullptr;
+        const hipError_t e = ctx->o.math == GS_MATH_FUSED ? gs_launch_window_fused(a, x, w.plan_rpw, sl.compute, &name)
+                                                           : gs_launch_window_strict(a, x, w.plan_rpw, sl.compute, &name);
+        if (e != hipSuccess) return fail(GS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        const int supers = (n + w.plan_k - 1) / w.plan_k;
+        w.epoch += supers;
+        w.pending = true;
+        ctx->last_kernel = name;
+        ctx->launches++;
+        ctx->passes += (uint64_t)supers;
+        ctx->steps_done += (uint64_t)n;
+        ctx->step_no++;
+        slot ^= 1;
+        left -= (uint64_t)n;
+    }
+    w.runs.push_back(gs_ctx::WindowRt::Run{{r.u[0], r.v[0], r.u[1], r.v[1]}, steps, slot});
+    if (result_slot) *result_slot = slot;
+    *launched = 1;
+    return GS_OK;
+}
+
+// gs_run.  allow_window = false: never the persistent window kernel (the replay of launches that gave up).
+int32_t run_steps(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *v1, uint64_t steps, int32_t *result_slot,
+                  bool allow_window)
 {
     GS_TRY(check_step_fields(ctx, u0, v0, u1, v1));
     Run r{ctx, {u0, u1}, {v0, v1}};
@@ -1906,74 +2024,27 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
         if (result_slot) *result_slot = slot;
         return GS_OK;
     }
-    // GS_KERNEL_WINDOW (single slab, grids of at most one window per compute unit; the reference's default 1080 x 1920
-    // is 15 x 16 of them): the whole call is ONE persistent launch of gs_run_window_k, which trades the windows' aprons
-    // between workgroups itself every k steps (fuse_steps = k, rows_per_block = window rows: 80 or 96).  A measured
-    // alternative, never chosen by kernel = auto: 383 k Mcells x steps / s at 1080 x 1920 under the clipped rule against
-    // 435 k for the marching kernel (441 k / 437 k under the zero-halo rule) -- a step costs 3.0 us per window (3.6 in the
-    // windows on the grid's left edge, which set the pace) and an exchange 6.9 us on the critical path
-    // (profiles/r04_window_kernel.md).
-    if (single && cells > 0 && steps > 0 && ctx->o.kernel == GS_KERNEL_WINDOW && !ctx->win.disabled) {
-        gs_ctx::WindowRt &w = ctx->win;
-        SlabRt &sl = ctx->slabs[0];
-        GS_HIP(hipSetDevice(sl.device));
-        // the tiling of this grid (made once per shape and configuration, kept on the device)
-        const int want_rpw = ctx->o.rows_per_block > 0 ? ctx->o.rows_per_block / 16 : 0;
-        const int key = ((ctx->o.boundary * 2 + (ctx->o.math == GS_MATH_FUSED)) * 4 + fast_of(ctx)) * 64 + want_rpw * 8 + ctx->o.fuse_steps;
-        if (w.plan_n == 0 || w.plan_rows != u0->rows || w.plan_cols != u0->cols || w.plan_key != key) {
-            int rpw = 0, wk = 0;
-            const std::vector<GsWindowDesc> plan = plan_windows(ctx, u0->rows, u0->cols, want_rpw, ctx->o.fuse_steps, &rpw, &wk);
-            if (plan.empty())
-                return fail(GS_ERR_UNSUPPORTED, "GS_KERNEL_WINDOW needs a grid of at most one window per compute unit (%d); "
-                                                "%llu x %llu cells do not fit", ctx->cu_count, (unsigned long long)u0->rows,
-                            (unsigned long long)u0->cols);
-            GS_TRY(ensure_window_rt(ctx, u0));
-            GS_TRY(sync_all(ctx)); // no launch may still be reading the old tiling
-            GS_HIP(hipMemcpy(w.desc, plan.data(), plan.size() * sizeof(GsWindowDesc), hipMemcpyHostToDevice));
-            w.plan_rows = u0->rows; w.plan_cols = u0->cols; w.plan_key = key;
-            w.plan_rpw = rpw; w.plan_k = wk; w.plan_n = (int)plan.size();
-            // the flags belong to the workgroups of the old tiling: start over
-            GS_HIP(hipMemsetAsync(w.words, 0, kWindowMaxTiles * sizeof(int32_t), sl.compute));
-            w.epoch = 0;
+    // Grids of one round of register-resident windows (single slab; the reference's default 1080 x 1920 is 252 of them):
+    // the whole call is ONE persistent launch of gs_run_window_k, which trades the windows' aprons between workgroups
+    // itself every k steps.  kernel = auto takes it from the LDS-window kernel's upper end (1.5 M cells) up to the largest
+    // grid that is one workgroup per CU when nothing is pinned and the call is long enough to pay for the launch's fixed
+    // cost (64 steps: a launch costs ~9 us plus 4.5 us per step against 4.8 us per step for the marching kernel);
+    // GS_KERNEL_WINDOW forces it (fuse_steps = steps per exchange, rows_per_block = window rows: 80 or 96).
+    // 461 k against 435 k Mcells x steps / s at 1080 x 1920, both boundary rules (profiles/r04_window_kernel.md).
+    if (allow_window && single && cells > 0 && steps > 0 && !ctx->win.disabled) {
+        const bool forced = ctx->o.kernel == GS_KERNEL_WINDOW;
+        const bool automatic = ctx->o.kernel == GS_KERNEL_AUTO && ctx->o.fuse_steps == 0 && ctx->o.rows_per_block == 0 &&
+                               ctx->o.cols_per_lane == 0 && ctx->o.split <= 1 && !ctx->o.use_graph && cells >= kTileAutoCells &&
+                               steps >= 64;
+        if (forced || automatic) {
+            int32_t launched = 0;
+            GS_TRY(run_window(ctx, r, steps, forced, &launched, result_slot));
+            if (launched) return GS_OK;
         }
-        GS_TRY(join_bands(ctx, sl.compute));
-        ctx->bands_active = false;
-        GS_TRY(ensure_window_rt(ctx, u0));
-        uint64_t left = steps;
-        int slot = 0;
-        while (left > 0) { // (the step count is an int in the kernel; a launch goes in-planes -> out-planes)
-            const int n = left > (1u << 20) ? (1 << 20) : (int)left;
-            GsStepArgs a = make_args(ctx, r.u[slot], r.v[slot], r.u[1 - slot], r.v[1 - slot], 0, 1);
-            GsWindowArgs x;
-            std::memset(&x, 0, sizeof x);
-            x.xu[0] = w.planes[0]; x.xu[1] = w.planes[1];
-            x.xv[0] = w.planes[2]; x.xv[1] = w.planes[3];
-            x.flags = w.words;
-            x.abort = w.words + kWindowMaxTiles;
-            x.desc = w.desc;
-            x.n_windows = w.plan_n;
-            x.steps = n;
-            x.k = w.plan_k;
-            x.epoch = w.epoch;
-            x.patience = gs_env_int("GS_HIP_WINDOW_PATIENCE", 1 << 22, 1, 1 << 30); // polls of ~1 us each: ~4 s
-            const char *name = nullptr;
-            const hipError_t e = ctx->o.math == GS_MATH_FUSED ? gs_launch_window_fused(a, x, w.plan_rpw, sl.compute, &name)
-                                                               : gs_launch_window_strict(a, x, w.plan_rpw, sl.compute, &name);
-            if (e != hipSuccess) return fail(GS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-            const int supers = (n + w.plan_k - 1) / w.plan_k;
-            w.epoch += supers;
-            w.pending = true;
-            ctx->last_kernel = name;
-            ctx->launches++;
-            ctx->passes += (uint64_t)supers;
-            ctx->steps_done += (uint64_t)n;
-            ctx->step_no++;
-            slot ^= 1;
-            left -= (uint64_t)n;
-        }
-        if (result_slot) *result_slot = slot;
-        return GS_OK;
     }
+    // every other kernel reads or overwrites planes that a window launch still in flight may own
+    // every other kernel reads or overwrites planes that a window launch still in flight may own
+    GS_TRY(resolve_window(ctx));
     // The short pass goes first so that a run ends on a full pass -- a full-depth ghost exchange -- and the
     // next run can start without a blocking refresh.  It is sized with the steps per pass in force (a
     // configuration handed in through gs_ctx_set_tuned may fuse fewer steps than `fuse`), which is known
@@ -2001,6 +2072,10 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
     if (result_slot) *result_slot = r.in;
     return GS_OK;
 }
+
+} // namespace
+
+extern "C" {
 
 int32_t gs_sync(gs_ctx *ctx)
 {
@@ -2030,6 +2105,7 @@ int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host)
     if (!ctx || !f || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad argument");
     if (f->rows == 0 || f->cols == 0) return GS_OK; // nothing to copy (host may be null)
     if (!host) return fail(GS_ERR_INVALID, "bad argument");
+    GS_TRY(resolve_window(ctx)); // (waits for a persistent window launch in flight: its result must be known to be valid)
     const uint64_t first = f->s.front().g_row0;
     const int last = (int)((ctx->step_no + 1) & 1); // parity of the most recent pass
     for (size_t i = 0; i < f->s.size(); ++i) {

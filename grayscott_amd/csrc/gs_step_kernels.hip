@@ -1234,7 +1234,7 @@ __host__ __device__ constexpr size_t win_lds_bytes() { return (size_t)2 * 2 * kW
 // (parity of the LDS buffer).
 template <int RPW, int EDGE, int FAST, int ZH>
 __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, int n, int &step, int gr, int gc, int wave, int lane,
-                                             bool active, float (&u)[RPW][2], float (&v)[RPW][2])
+                                             float (&u)[RPW][2], float (&v)[RPW][2])
 {
     constexpr int P = kWinPitch;
     constexpr bool ROWS = EDGE == 1 || EDGE == 4 || EDGE == 5 || EDGE == 6;
@@ -1263,51 +1263,54 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
         w.v[3] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cv[0]), 0x130, 0xf, 0xf, true));
         return w;
     };
-    for (int s = 0; s < n; ++s, ++step) {
-        const int buf = step & 1;
-        if (!active) { // a wave beyond the window's rows in use only keeps the barrier count
-            __syncthreads();
-            continue;
+    // One cell row: old rows (m, z, p) -> new values of row r, written in place.
+    auto update = [&](int r, const RowT<2> &m, const RowT<2> &z, const RowT<2> &p) {
+        const int row = gr + r; // wave-uniform
+        if (EDGE != 0 && (row < 0 || row >= a.rows)) return; // a row outside the grid: zeros that stay zeros
+        const bool mrow = !ROWS || row > 0, prow = !ROWS || row + 1 < a.rows;
+        float nu[2], nv[2];
+        if constexpr (EDGE == 0 || EDGE == 7) {
+            cells_interior<FAST, 2, ZH>(a, m, z, p, nu, nv);
+        } else if constexpr (EDGE == 4 || EDGE == 5 || EDGE == 6) {
+            if (mrow && prow) {
+                if constexpr (EDGE == 4) {
+                    cells_interior<FAST, 2, ZH>(a, m, z, p, nu, nv);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) cell<SIDE, FAST, RowT<2>, ZH>(a, m, z, p, 1 + j, true, true, la[j], ra[j], nu[j], nv[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) cell<1, FAST, RowT<2>, ZH>(a, m, z, p, 1 + j, mrow, prow, la[j], ra[j], nu[j], nv[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) cell<EDGE, FAST, RowT<2>, ZH>(a, m, z, p, 1 + j, mrow, prow, la[j], ra[j], nu[j], nv[j]);
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool in = EDGE == 0 || col_in[j];
+            u[r][j] = in ? nu[j] : 0.0f;
+            v[r][j] = in ? nv[j] : 0.0f;
+        }
+    };
+    // the first and the last row of this wave's band, for the waves above and below
+    auto publish = [&](int buf) {
         *reinterpret_cast<float2 *>(row_of(buf, 0, wave, 0)) = make_float2(u[0][0], u[0][1]);
         *reinterpret_cast<float2 *>(row_of(buf, 1, wave, 0)) = make_float2(v[0][0], v[0][1]);
         *reinterpret_cast<float2 *>(row_of(buf, 0, wave, 1)) = make_float2(u[RPW - 1][0], u[RPW - 1][1]);
         *reinterpret_cast<float2 *>(row_of(buf, 1, wave, 1)) = make_float2(v[RPW - 1][0], v[RPW - 1][1]);
-        // One cell row: old rows (m, z, p) -> new values of row r, written in place.
-        auto update = [&](int r, const RowT<2> &m, const RowT<2> &z, const RowT<2> &p) {
-            const int row = gr + r; // wave-uniform
-            if (EDGE != 0 && (row < 0 || row >= a.rows)) return; // a row outside the grid: zeros that stay zeros
-            const bool mrow = !ROWS || row > 0, prow = !ROWS || row + 1 < a.rows;
-            float nu[2], nv[2];
-            if constexpr (EDGE == 0 || EDGE == 7) {
-                cells_interior<FAST, 2, ZH>(a, m, z, p, nu, nv);
-            } else if constexpr (EDGE == 4 || EDGE == 5 || EDGE == 6) {
-                if (mrow && prow) {
-                    if constexpr (EDGE == 4) {
-                        cells_interior<FAST, 2, ZH>(a, m, z, p, nu, nv);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) cell<SIDE, FAST, RowT<2>, ZH>(a, m, z, p, 1 + j, true, true, la[j], ra[j], nu[j], nv[j]);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) cell<1, FAST, RowT<2>, ZH>(a, m, z, p, 1 + j, mrow, prow, la[j], ra[j], nu[j], nv[j]);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) cell<EDGE, FAST, RowT<2>, ZH>(a, m, z, p, 1 + j, mrow, prow, la[j], ra[j], nu[j], nv[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bool in = EDGE == 0 || col_in[j];
-                u[r][j] = in ? nu[j] : 0.0f;
-                v[r][j] = in ? nv[j] : 0.0f;
-            }
-        };
-        // The rows that need nothing from other waves first (the other waves' rows arrive meanwhile), top down with a
-        // sliding window of widened OLD rows: a row is widened just before the row above it is overwritten, so at most
-        // five widened rows are alive -- the window of three, old row 1 (kept for row 0) and old row RPW - 2 (for the
-        // last row) -- instead of all RPW + 2.
+    };
+    // A step: publish, the rows that need nothing from other waves (the other waves' rows arrive meanwhile), barrier, the
+    // rows above and below from LDS, the band's first and last row.  (Reads first and the publish for the next step
+    // right before the barrier -- the LDS latency behind the middle rows -- was measured: the waves of a workgroup
+    // drift apart, 418 k against 461 k at 1080 x 1920, profiles/r04_window_kernel.md.)
+    for (int s = 0; s < n; ++s, ++step) {
+        const int buf = step & 1;
+        publish(buf);
+        // Top down with a sliding window of widened OLD rows: a row is widened just before the row above it is
+        // overwritten, so at most five widened rows are alive -- the window of three, old row 1 (kept for row 0) and
+        // old row RPW - 2 (for the last row) -- instead of all RPW + 2.
         RowT<2> first = widen(u[0], v[0]);                 // old row 0
         RowT<2> second = widen(u[RPW > 1 ? 1 : 0], v[RPW > 1 ? 1 : 0]); // old row 1: needed again for row 0
         RowT<2> prev = first, cur = second;
@@ -1367,20 +1370,19 @@ __device__ unsigned long long gs_win_trace[1024 * 8 * 8];
 #endif
 
 template <int RPW, int EDGE, int FAST, int ZH>
-__device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowArgs &x, const GsWindowDesc *d, float *lds, int *go, int wg,
-                                           int gr, int gc, int wave, int lane, float (&u)[RPW][2], float (&v)[RPW][2])
+__device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowArgs &x, const GsWindowDesc *d, int OH, int OW, float *lds,
+                                           int *go, int wg, int gr, int gc, int wave, int lane, float (&u)[RPW][2], float (&v)[RPW][2])
 {
+    // OH x OW: the cells this workgroup owns = window rows [K, K + OH) x window columns [K, K + OW)
     constexpr int SC1 = 16;
     typedef float v2f __attribute__((ext_vector_type(2)));
     const int K = x.k, wc = 2 * lane; // wc: this lane's first window column
-    const int H = d->active, OW = d->ow; // window rows in use; owned columns (window columns [K, K + OW))
-    const bool active = wave * RPW < H;
     int step = 0;
     const int supers = (x.steps + K - 1) / K;
     for (int s = 0; s < supers; ++s) {
         GS_WIN_TRACE_AT(0);
         // the short super-step first
-        window_steps<RPW, EDGE, FAST, ZH>(a, lds, (s == 0 && x.steps % K) ? x.steps % K : K, step, gr, gc, wave, lane, active, u, v);
+        window_steps<RPW, EDGE, FAST, ZH>(a, lds, (s == 0 && x.steps % K) ? x.steps % K : K, step, gr, gc, wave, lane, u, v);
         GS_WIN_TRACE_AT(1);
         if (s == supers - 1) break;
         // ---- exchange s: ring out, flag, poll, apron in -------------------------------------------------------
@@ -1390,8 +1392,8 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int wr = wave * RPW + r; // wave-uniform
-            const bool row_owned = wr >= K && wr < K + d->oh && gr + r < a.rows;
-            const bool row_ring = wr < 2 * K || wr >= d->oh;
+            const bool row_owned = wr >= K && wr < K + OH && gr + r < a.rows;
+            const bool row_ring = wr < 2 * K || wr >= OH;
             if (row_owned && lane_owned && (row_ring || lane_ring)) {
                 const int off = ((gr + r) * a.pitch + gc) * (int)sizeof(float);
                 const v2f su = {u[r][0], u[r][1]}, sv = {v[r][0], v[r][1]};
@@ -1431,8 +1433,8 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
         for (int r = 0; r < RPW; ++r) {
             const int wr = wave * RPW + r;
             const bool row_in = gr + r >= 0 && gr + r < a.rows;
-            const bool row_apron = (wr < K || wr >= K + d->oh) && wr < 2 * K + d->oh;
-            if (row_in && wr < 2 * K + d->oh && ((row_apron && lane_in && wc < 2 * K + OW) || lane_apron)) {
+            const bool row_apron = (wr < K || wr >= K + OH) && wr < 2 * K + OH;
+            if (row_in && ((row_apron && lane_in && wc < 2 * K + OW) || (lane_apron && wr < 2 * K + OH))) {
                 const int off = ((gr + r) * a.pitch + gc) * (int)sizeof(float);
                 const v2f fu = __builtin_amdgcn_raw_buffer_load_b64(xu, off, 0, SC1);
                 const v2f fv = __builtin_amdgcn_raw_buffer_load_b64(xv, off, 0, SC1);
@@ -1452,7 +1454,7 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int wr = wave * RPW + r;
-            if (wr >= K && wr < K + d->oh && gr + r < a.rows) {
+            if (wr >= K && wr < K + OH && gr + r < a.rows) {
                 const int off = ((gr + r) * a.pitch + gc) * (int)sizeof(float);
                 const v2f su = {u[r][0], u[r][1]}, sv = {v[r][0], v[r][1]};
                 __builtin_amdgcn_raw_buffer_store_b64(su, win_rsrc(a.out_u), off, 0, 0);
@@ -1475,7 +1477,7 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
     const int K = x.k;
     const int wg = (int)blockIdx.x;
     const GsWindowDesc *d = x.desc + wg;                    // (uniform: scalar loads)
-    const int H = d->active;                                // window rows in use
+    const int H = d->active, OH = d->oh, OW = d->ow;        // window rows in use; owned rows and columns
     const int gr0 = d->r0 - K, gc0 = d->c0 - K;             // global coordinates of window cell (0, 0)
     const int gr = gr0 + wave * RPW, gc = gc0 + 2 * lane;   // this lane's first cell
     // A launch enqueued behind one that gave up leaves at once (nothing of it is valid anyway).  ONE wave reads the
@@ -1490,10 +1492,23 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
 #pragma unroll
         for (int b = 0; b < 8; ++b)
             lds[(((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + (lane == 0 ? 1 : 129 + lane)] = 0.0f;
-    if (wave * RPW >= H) // a wave beyond the window's rows in use publishes zeros once: the last wave in use reads them
+    if (wave * RPW >= H) {
+        // A wave beyond the window's rows in use publishes zeros once (the last wave in use reads them as its row below)
+        // and then only keeps the workgroup's barrier count: one per step, two per exchange.
 #pragma unroll
         for (int b = 0; b < 8; ++b)
             *reinterpret_cast<float2 *>(lds + (((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + 2 + 2 * lane) = make_float2(0.0f, 0.0f);
+        const int supers = (x.steps + K - 1) / K;
+        for (int s = 0; s < supers; ++s) {
+            const int n = (s == 0 && x.steps % K) ? x.steps % K : K;
+            for (int i = 0; i < n; ++i) __syncthreads();
+            if (s == supers - 1) break;
+            __syncthreads();
+            __syncthreads();
+            if (!go) return;
+        }
+        return;
+    }
     float u[RPW][2], v[RPW][2];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
@@ -1508,10 +1523,10 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
         u[r][0] = fu[0]; u[r][1] = in1 ? fu[1] : 0.0f;
         v[r][0] = fv[0]; v[r][1] = in1 ? fv[1] : 0.0f;
     }
-    const bool left = gc0 <= 0, right = gc0 + 2 * K + d->ow >= a.cols, ends = gr0 <= 0 || gr0 + H >= a.rows;
+    const bool left = gc0 <= 0, right = gc0 + 2 * K + OW >= a.cols, ends = gr0 <= 0 || gr0 + H >= a.rows;
     const bool edge = left || right || ends;
     constexpr bool KINDS = (FAST & 1) && !GS_MATH_FUSED;
-#define GS_WIN_RUN(E, Z) window_run<RPW, E, FAST, Z>(a, x, d, lds, &go, wg, gr, gc, wave, lane, u, v)
+#define GS_WIN_RUN(E, Z) window_run<RPW, E, FAST, Z>(a, x, d, OH, OW, lds, &go, wg, gr, gc, wave, lane, u, v)
     // One branch per workgroup, one instantiation per kind of window (as gs_step_tb_k): the cheap kinds exist for the
     // clipped rule with the default side weights in the strict build; a grid narrower than one window, general
     // weights and the fused build take the general path in their edge windows.

@@ -476,18 +476,10 @@ class Simulation:
         the input slots of ``species`` hold the final state.  Synchronous like every backend of the
         reference -- its GPU backends end ``perform_steps_impl`` with
         ``.then_signal_fence_and_flush()?.wait(None)?`` (compute/shared/src/gpu/mod.rs:77-91)."""
-        flipped = self.prepare_steps(species, steps)
-        try:
-            self.context.sync()
-        except GsError as e:
-            # A persistent window launch that gave up (gs_hip.h, GS_KERNEL_WINDOW) has taken no step and left its
-            # input planes intact: point the handles back at them before the error travels on.
-            if flipped and "persistent window launch gave up" in e.message:
-                species.u._pair.reverse()
-                species.v._pair.reverse()
-            raise
+        self.prepare_steps(species, steps)
+        self.context.sync()
 
-    def prepare_steps(self, species: Species, steps: int) -> bool:
+    def prepare_steps(self, species: Species, steps: int) -> None:
         """The asynchronous form, ``SimulateGpu::prepare_steps`` (compute/shared/src/gpu/mod.rs:
         70-75): enqueue ``steps`` steps and return; whatever is enqueued next on this context (more
         steps, ``write_result_view_after``) runs behind them, a download or ``context.sync()`` waits.
@@ -500,7 +492,6 @@ class Simulation:
         if slot.value == 1:  # odd number of steps: the newest state sits in the output slot
             species.u._pair.reverse()
             species.v._pair.reverse()
-        return slot.value == 1
 
     def perform_step(self, species: Species) -> None:
         """One ``gs_step`` then ``species.flip()`` -- the ``SimulateStep`` form (cpu.rs:21-42)."""

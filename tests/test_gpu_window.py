@@ -5,8 +5,8 @@ window, several windows each way with ragged right / bottom ends, exactly one ow
 both window heights, every k, step counts that are a short super-step, whole ones and both; general parameters
 (no specialised variant); the fused flavour; NaN / Inf spreading; Species::new through uneven calls with single
 steps in between; BASELINE config 1 (1080 x 1920 x 1000 steps) end to end; a launch that gives up; a soak against the
-marching kernel under chaotic dynamics (every exchanged word matters).  A measured alternative: kernel = auto never
-picks it (profiles/r04_window_kernel.md).
+marching kernel under chaotic dynamics (every exchanged word matters); what kernel = auto picks
+(profiles/r04_window_kernel.md).
 Spec: compute/naive/src/lib.rs:42-83 (arithmetic, clipped window), compute/shared/src/cpu.rs:30-42 (step; flip);
 zero-halo rule: compute/gpu/naive/src/pipeline.rs:105-113."""
 import numpy as np
@@ -137,35 +137,58 @@ def test_window_kernel_refuses_grids_of_more_than_one_window_per_cu():
     assert_bits_equal(got_v, ref_v, "chain V")
 
 
-def test_a_launch_that_gives_up_is_reported_and_destroys_nothing(monkeypatch):
-    """GS_HIP_WINDOW_PATIENCE = 1 poll: on a grid of many windows some workgroup's neighbour is late at some exchange,
-    the launch gives up, gs_sync says so, the input planes are intact and the context falls back to the marching
-    kernel -- which then gives the right answer from the same planes."""
-    from grayscott_amd import GsError
+def test_a_launch_that_gives_up_is_run_again_by_the_marching_kernel(monkeypatch):
+    """GS_HIP_WINDOW_PATIENCE = 1 poll: on a grid of many windows some workgroup's neighbour is late at some exchange and
+    the launch gives up -- as it would if its workgroups were not all resident.  Nothing of it is kept: the launches
+    enqueued since the last synchronisation took no step (sticky abort word, input planes only read), gs_sync runs them
+    again with the marching kernel and puts the results where gs_run said they would be (also when the step count's
+    parity would put them elsewhere), and the context stays with the marching kernel.  The caller sees right answers."""
+    from tests.helpers import species_from_arrays
 
     monkeypatch.setenv("GS_HIP_WINDOW_PATIENCE", "1")
     rows, cols = 1080, 1920
     u0, v0 = stress_fields((rows, cols), 5)
-    sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_WINDOW))
-    from tests.helpers import species_from_arrays
+    sim = Simulation.new(Parameters(), args())           # kernel = auto: the window kernel for calls of >= 64 steps
     sp = species_from_arrays(sim, u0, v0)
-    gave_up = False
-    try:
-        sim.perform_steps(sp, 400)
-    except GsError as e:
-        gave_up = True
-        assert "gave up" in str(e)
-    if not gave_up:
-        pytest.skip("every poll of 100 exchanges matched at once on this box")
-    in_u, in_v, _, _ = sp.in_out()
-    # the host mirror points its handles back at the input planes, which the launch never wrote
-    assert_bits_equal(in_u.make_scalar_view(sim.context), u0, "input U after a launch that gave up")
-    sim.perform_steps(sp, 40)
-    assert sim.context.info()[0].startswith("tb-k")
-    ref_u, ref_v = oracle.run(u0, v0, 40, ftz=True)
+    sim.prepare_steps(sp, 400)                           # two calls in flight, the second with an odd step count
+    sim.prepare_steps(sp, 77)
+    sim.context.sync()
+    label = sim.context.info()[0]
+    if label.startswith("window"):
+        pytest.skip("every poll of 120 exchanges matched at once on this box")
+    assert label.startswith("tb-k"), label
+    ref_u, ref_v = oracle.run(u0, v0, 477, ftz=True)
     in_u, in_v, _, _ = sp.in_out()
     assert_bits_equal(in_u.make_scalar_view(sim.context), ref_u, "U after the fallback")
     assert_bits_equal(in_v.make_scalar_view(sim.context), ref_v, "V after the fallback")
+    sim.perform_steps(sp, 100)                           # the context stays with the marching kernel
+    assert sim.context.info()[0].startswith("tb-k")
+    ref_u, ref_v = oracle.run(ref_u, ref_v, 100, ftz=True)
+    in_u, in_v, _, _ = sp.in_out()
+    assert_bits_equal(in_u.make_scalar_view(sim.context), ref_u, "U, 100 steps later")
+
+
+def test_what_kernel_auto_picks_around_the_window_kernel():
+    """kernel = auto: the window kernel for calls of >= 64 steps on single-slab grids from 1.5 M cells up to one window per
+    compute unit when nothing is pinned; the marching kernel for short calls, pinned schedules, slab chains, larger grids."""
+    u0, v0 = stress_fields((1080, 1920), 3)
+    ref = {n: oracle.run(u0, v0, n, ftz=True) for n in (64, 40)}
+    for kw, steps, want in ((dict(), 64, "window-r5/"), (dict(), 40, "tb-k"), (dict(fuse_steps=4), 64, "tb-k"),
+                            (dict(rows_per_block=10), 64, "tb-k"), (dict(devices=[0, 0]), 64, "tb-k"),
+                            (dict(boundary=capi.GS_BOUNDARY_ZERO_HALO), 64, "window-r5/")):
+        got_u, got_v, info = gpu_run(u0, v0, steps, args=HipArgs(**{"devices": [0], **kw}))
+        assert info[0].startswith(want), (kw, steps, info)
+        if "boundary" not in kw:
+            assert_bits_equal(got_u, ref[steps][0], f"auto U {kw} {steps}")
+            assert_bits_equal(got_v, ref[steps][1], f"auto V {kw} {steps}")
+    a0, b0 = stress_fields((2048, 2048), 4)               # 4.2 M cells: more than one window per CU
+    assert gpu_run(a0, b0, 64, args=args())[2][0].startswith("tb-k")
+    a0, b0 = stress_fields((1200, 2000), 4)               # 2.4 M cells: 96-row windows
+    got_u, got_v, info = gpu_run(a0, b0, 70, args=args())
+    assert info[0].startswith("window-r6/"), info
+    ru, rv = oracle.run(a0, b0, 70, ftz=True)
+    assert_bits_equal(got_u, ru, "auto U 1200x2000")
+    assert_bits_equal(got_v, rv, "auto V 1200x2000")
 
 
 def test_window_kernel_soak_against_the_marching_kernel():
@@ -178,7 +201,7 @@ def test_window_kernel_soak_against_the_marching_kernel():
 
     rows, cols = 1080, 1920
     u0, v0 = bench.developed_start(rows, cols)
-    ref = Simulation.new(Parameters(), args())
+    ref = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_TB))
     sr = bench.upload_species(ref, u0, v0)
     calls = (997, 1003, 1000)
     for n in calls:
