@@ -1864,7 +1864,9 @@ int32_t run_window(gs_ctx *ctx, Run &r, uint64_t steps, bool forced, int32_t *la
     *launched = 0;
     GS_HIP(hipSetDevice(sl.device));
     // the tiling of this grid (made once per shape and configuration, kept on the device)
-    const int want_rpw = ctx->o.rows_per_block > 0 ? ctx->o.rows_per_block / 16 : 0;
+    // (kernel = auto only takes grids that 80-row windows cover: with 96-row windows -- 1200 x 2000: 450 k against the
+    // marching kernel's 452 k -- nothing is gained, profiles/r04_window_kernel.md)
+    const int want_rpw = forced ? (ctx->o.rows_per_block > 0 ? ctx->o.rows_per_block / 16 : 0) : 5;
     const int key = ((ctx->o.boundary * 2 + (ctx->o.math == GS_MATH_FUSED)) * 4 + fast_of(ctx)) * 64 + want_rpw * 8 + ctx->o.fuse_steps;
     if (w.plan_rows != u0->rows || w.plan_cols != u0->cols || w.plan_key != key) {
         int rpw = 0, wk = 0;

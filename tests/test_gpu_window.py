@@ -183,12 +183,13 @@ def test_what_kernel_auto_picks_around_the_window_kernel():
             assert_bits_equal(got_v, ref[steps][1], f"auto V {kw} {steps}")
     a0, b0 = stress_fields((2048, 2048), 4)               # 4.2 M cells: more than one window per CU
     assert gpu_run(a0, b0, 64, args=args())[2][0].startswith("tb-k")
-    a0, b0 = stress_fields((1200, 2000), 4)               # 2.4 M cells: 96-row windows
-    got_u, got_v, info = gpu_run(a0, b0, 70, args=args())
+    a0, b0 = stress_fields((1200, 2000), 4)               # 2.4 M cells: 96-row windows would cover it; auto does not use them
+    assert gpu_run(a0, b0, 70, args=args())[2][0].startswith("tb-k")
+    got_u, got_v, info = gpu_run(a0, b0, 70, args=args(kernel=capi.GS_KERNEL_WINDOW))
     assert info[0].startswith("window-r6/"), info
     ru, rv = oracle.run(a0, b0, 70, ftz=True)
-    assert_bits_equal(got_u, ru, "auto U 1200x2000")
-    assert_bits_equal(got_v, rv, "auto V 1200x2000")
+    assert_bits_equal(got_u, ru, "U 1200x2000, 96-row windows")
+    assert_bits_equal(got_v, rv, "V 1200x2000, 96-row windows")
 
 
 def test_window_kernel_soak_against_the_marching_kernel():
