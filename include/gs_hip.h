@@ -57,7 +57,9 @@
  *     GS_HIP_XCD_M_STREAM   the same for the single-step kernel
  *     GS_HIP_TILE_LDS_FLOOR least dynamic LDS (bytes) of the LDS-window kernel: limits its workgroups per CU
  *     GS_HIP_WINDOW_PATIENCE polls (~1 us each) a workgroup of the persistent window kernel waits for a neighbour
- *                           before the launch gives up (default 2^22: ~4 s)
+ *                           before the launch gives up (default 2^21: ~2 s)
+ *     GS_HIP_WINDOW_WAVES   "left,interior,right": waves in use (of 16) in the windows of the grid's left-most, inner
+ *                           and right-most tile column (default 12,16,12 under the clipped rule, 16,16,16 otherwise)
  */
 #ifndef GS_HIP_H
 #define GS_HIP_H
@@ -104,9 +106,9 @@ typedef struct gs_params {
 typedef enum gs_math { GS_MATH_STRICT = 0, GS_MATH_FUSED = 1 } gs_math;
 
 /* Which step kernel runs.  AUTO = STREAM for a single gs_step; inside gs_run, by grid size when nothing
- * is pinned: the LDS-resident whole-run kernel up to 1536 cells, TILE up to 1.5 M cells, TB with
- * fuse_steps (default 4) above, for slab chains and whenever fuse_steps, rows_per_block, cols_per_lane,
- * split or use_graph pin a schedule. */
+ * is pinned: the LDS-resident whole-run kernel up to 1536 cells, TILE up to 1.5 M cells, WINDOW for calls of
+ * >= 64 steps on grids of one round of 80-row windows, TB with fuse_steps (default 4) otherwise, for slab
+ * chains and whenever fuse_steps, rows_per_block, cols_per_lane, split or use_graph pin a schedule. */
 typedef enum gs_kernel {
     GS_KERNEL_AUTO = 0,    /* best measured variant for the shape                          */
     GS_KERNEL_SIMPLE = 1,  /* one thread per cell, global loads only (cross-check kernel)  */
@@ -117,14 +119,18 @@ typedef enum gs_kernel {
     GS_KERNEL_TILE = 5,    /* gs_run only, single slab: up to 8 steps per launch on LDS-resident windows
                               with a K-cell apron, one cell per lane and 16 waves per window (gs_step and
                               slab chains fall back to STREAM / TB); what AUTO runs on mid-size grids  */
-    GS_KERNEL_WINDOW = 6   /* gs_run only, single slab, grids of at most one 72 x 120- or 88 x 120-cell window per
-                              compute unit (1.5 - 3.2 M cells on 256 CUs: the reference's default 1080 x 1920): the
-                              whole call is ONE persistent launch; every workgroup keeps its window in registers
-                              and trades its k-cell apron with its neighbours every k steps (fuse_steps = k:
-                              2, 4, 6 or 8; rows_per_block = window rows, 80 or 96).  Bit-exact, measured slower than
-                              TB on such grids (383 k against 435 k Mcells x steps / s at 1080 x 1920): never chosen
-                              by AUTO.  A launch whose workgroups are not all resident gives up after a bounded wait:
-                              gs_sync then fails, no step of that gs_run was taken and its input planes are intact  */
+    GS_KERNEL_WINDOW = 6   /* gs_run only, single slab, grids of at most one register-resident window per compute unit
+                              (1.5 - 2.3 M cells on 256 CUs: the reference's default 1080 x 1920 is 252 windows): the
+                              whole call is ONE persistent launch; every workgroup keeps its window (72 x 120 owned
+                              cells + a k-cell apron; lower windows on the grid's left and right edge, whose cells cost
+                              more) in registers and trades its apron with its neighbours every k steps through
+                              exchange planes, flags and sc1 accesses (fuse_steps = k: 2, 4, 6 or 8; rows_per_block =
+                              full window rows, 80 or 96).  What AUTO runs for calls of >= 64 steps where 80-row windows
+                              cover the grid: 456-461 k against TB's 435 k Mcells x steps / s at 1080 x 1920, both rules.
+                              A launch whose workgroups are not all resident (another long-running kernel holds CUs)
+                              gives up after a bounded wait without having written anything but its exchange planes:
+                              the next call that waits for or reads results runs the steps again with TB, and the
+                              context stays with TB  */
 } gs_kernel;
 
 /* Rule on the edges of the global grid.  The reference has two:
