@@ -38,7 +38,7 @@ EXPORTS = (
     "gs_host_alloc", "gs_host_free", "gs_field_download_async", "gs_download_wait",
     "gs_ctx_get_tuned", "gs_ctx_set_tuned", "gs_ctx_comm_info", "gs_field_colormap",
     "gs_ctx_stats", "gs_ctx_set_pass_timing", "gs_field_mark_written", "gs_rccl_selftest",
-    "gs_debug_dyn_lds_key",
+    "gs_debug_dyn_lds_key", "gs_debug_window_plan",
 )
 
 

@@ -678,14 +678,21 @@ void pick_tile_config(long rows, long cols, int *shape, int *k)
 // selects for the cell on column 0's lane), the right edge 1.13 (cell<3>), general path (general weights, the fused
 // build, a grid of one tile column) 1.6, edge columns under the zero-halo rule 1.05 (a select per cell).
 // `waves_env`: GS_HIP_WINDOW_WAVES = "left,interior,right" overrides the waves in use per column class (experiments).
+std::vector<GsWindowDesc> plan_windows(int cu_count, bool zero_halo, bool cheap, uint64_t rows, uint64_t cols, int want_rpw, int want_k,
+                                       int *rpw_out, int *k_out);
 std::vector<GsWindowDesc> plan_windows(const gs_ctx *ctx, uint64_t rows, uint64_t cols, int want_rpw, int want_k, int *rpw_out, int *k_out)
 {
+    const bool cheap = fast_of(ctx) & 1 && ctx->o.math == GS_MATH_STRICT && gs_env_int("GS_HIP_EDGE_KINDS", 1, 0, 1) != 0;
+    return plan_windows(ctx->cu_count, ctx->o.boundary == GS_BOUNDARY_ZERO_HALO, cheap, rows, cols, want_rpw, want_k, rpw_out, k_out);
+}
+// (the geometry alone: no device needed -- tests/test_capi_cpu.py checks it through gs_debug_window_plan)
+std::vector<GsWindowDesc> plan_windows(int cu_count, bool zero_halo, bool cheap, uint64_t rows, uint64_t cols, int want_rpw, int want_k,
+                                       int *rpw_out, int *k_out)
+{
     std::vector<GsWindowDesc> plan;
-    if (ctx->cu_count <= 0 || rows == 0 || cols == 0 || rows > 0x7fffff || cols > 0x7fffff) return plan;
+    if (cu_count <= 0 || rows == 0 || cols == 0 || rows > 0x7fffff || cols > 0x7fffff) return plan;
     const int k = want_k > 0 ? want_k : 4;
     if (k < 2 || k > 8 || (k & 1)) return plan;
-    const bool cheap = fast_of(ctx) & 1 && ctx->o.math == GS_MATH_STRICT && gs_env_int("GS_HIP_EDGE_KINDS", 1, 0, 1) != 0;
-    const bool zero_halo = ctx->o.boundary == GS_BOUNDARY_ZERO_HALO;
     const long wo = 128 - 2 * k;
     const long tiles_c = (long)((cols + wo - 1) / wo);
     int forced[3] = {0, 0, 0};
@@ -723,7 +730,7 @@ std::vector<GsWindowDesc> plan_windows(const gs_ctx *ctx, uint64_t rows, uint64_
                 d.ow = (int32_t)wo;
                 d.active = active;
                 plan.push_back(d);
-                if ((long)plan.size() > ctx->cu_count || plan.size() > (size_t)kWindowMaxTiles) { ok = false; break; }
+                if ((long)plan.size() > cu_count || plan.size() > (size_t)kWindowMaxTiles) { ok = false; break; }
             }
         }
         if (!ok) continue;
@@ -2298,6 +2305,20 @@ int32_t gs_ctx_stats(gs_ctx *ctx, gs_stats *out)
         }
     }
     return GS_OK;
+}
+
+int32_t gs_debug_window_plan(uint64_t rows, uint64_t cols, int32_t compute_units, int32_t boundary, int32_t cheap_edge_kinds,
+                             int32_t window_rows, int32_t k, int32_t *out, int32_t cap_windows, int32_t *rows_per_wave, int32_t *k_out)
+{
+    int rpw = 0, kk = 0;
+    const std::vector<GsWindowDesc> plan = plan_windows(compute_units, boundary == GS_BOUNDARY_ZERO_HALO, cheap_edge_kinds != 0, rows, cols,
+                                                        window_rows > 0 ? window_rows / 16 : 0, k, &rpw, &kk);
+    if (rows_per_wave) *rows_per_wave = rpw;
+    if (k_out) *k_out = kk;
+    constexpr int words = (int)(sizeof(GsWindowDesc) / sizeof(int32_t));
+    if (out)
+        for (size_t i = 0; i < plan.size() && (int)i < cap_windows; ++i) std::memcpy(out + i * words, &plan[i], sizeof(GsWindowDesc));
+    return (int32_t)plan.size();
 }
 
 int32_t gs_ctx_info(const gs_ctx *ctx, char *kernel_name, size_t cap, uint64_t *launches)

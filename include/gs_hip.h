@@ -331,6 +331,12 @@ int32_t gs_ctx_info(const gs_ctx *ctx, char *kernel_name, size_t cap, uint64_t *
  * of dynamic LDS were opted into -- 1 when (device, slot, bytes) is new (and is recorded), 0 when a launch on that
  * device would skip the opt-in, -1 for a bad slot (tests/test_capi_cpu.py). */
 int32_t gs_debug_dyn_lds_key(int32_t device, int32_t slot, int32_t bytes);
+/* Test hook, not for bindings: the tiling GS_KERNEL_WINDOW would use for a grid on a device of `compute_units` CUs (no
+ * device needed).  Returns the number of windows (0: the grid is not one round of windows) and writes up to cap_windows
+ * descriptors of 6 + 14 int32 each: first owned row, first owned column, owned rows, owned columns, window rows in use,
+ * number of neighbours, neighbour indices. */
+int32_t gs_debug_window_plan(uint64_t rows, uint64_t cols, int32_t compute_units, int32_t boundary, int32_t cheap_edge_kinds,
+                             int32_t window_rows, int32_t k, int32_t *out, int32_t cap_windows, int32_t *rows_per_wave, int32_t *k_out);
 
 #ifdef __cplusplus
 }

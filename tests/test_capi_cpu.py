@@ -145,3 +145,57 @@ def test_simulate_driver_flattens_the_backend_flags(monkeypatch):
     for flag in ("hip_devices", "hip_math", "hip_rows_per_block", "hip_fuse_steps", "hip_cols_per_lane", "hip_no_tune"):
         assert f"pub {flag}:" in shim, flag
         assert hasattr(driver.parse([]), flag), flag
+
+
+def test_window_tilings_cover_the_grid_and_name_every_neighbour():
+    """The host side of GS_KERNEL_WINDOW (gs_api.cpp: plan_windows, through the test hook gs_debug_window_plan; no GPU):
+    the windows' owned rectangles tile the grid exactly, a window's rows in use are its owned rows + 2 k in whole waves
+    of 4-SIMD rounds, the edge columns are lower under the clipped rule, there is at most one window per compute unit,
+    and a window's neighbour list is exactly the set of windows whose owned cells lie within k cells of its own --
+    the workgroups whose flags it must wait for at an exchange (a missing one would be a stale apron)."""
+    import ctypes
+
+    import numpy as np
+
+    from grayscott_amd import capi
+
+    lib = capi.load()
+    f = lib.gs_debug_window_plan
+    f.restype = ctypes.c_int32
+    f.argtypes = [ctypes.c_uint64, ctypes.c_uint64] + [ctypes.c_int32] * 5 + [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    words = 20
+
+    def plan(rows, cols, cus=256, boundary=0, cheap=1, window_rows=0, k=0):
+        out = np.zeros((1024, words), np.int32)
+        rpw, kk = ctypes.c_int32(0), ctypes.c_int32(0)
+        n = f(rows, cols, cus, boundary, cheap, window_rows, k, out.ctypes.data_as(ctypes.c_void_p), 1024, ctypes.byref(rpw), ctypes.byref(kk))
+        return out[:n], rpw.value, kk.value
+
+    # the reference's default size: 14 interior tile columns of 15 windows, two edge columns of 21 lower ones
+    d, rpw, k = plan(1080, 1920)
+    assert (len(d), rpw, k) == (252, 5, 4)
+    assert sorted(set(d[:, 4].tolist())) == [60, 80] and (d[d[:, 1] == 0][:, 4] == 60).all() and (d[d[:, 1] == 15 * 120][:, 4] == 60).all()
+    assert len(plan(1080, 1920, boundary=1)[0]) == 240 and set(plan(1080, 1920, boundary=1)[0][:, 4].tolist()) == {80}
+    assert len(plan(4096, 4096)[0]) == 0 and len(plan(1080, 1920, cus=128)[0]) == 0          # not one round of windows
+    assert plan(1200, 2000)[1] == 6 and len(plan(1200, 2000, window_rows=80)[0]) == 0
+    rng = np.random.default_rng(5)
+    shapes = [(1, 1), (7, 50), (72, 120), (73, 121), (300, 500), (1080, 1920), (1300, 1300), (1000, 40), (40, 3000), (1200, 2000)]
+    shapes += [(int(rng.integers(1, 1500)), int(rng.integers(1, 2500))) for _ in range(12)]
+    for rows, cols in shapes:
+        for boundary, cheap, k in ((0, 1, 4), (1, 1, 4), (0, 0, 4), (0, 1, 2), (0, 1, 8), (1, 0, 6)):
+            d, rpw, kk = plan(rows, cols, boundary=boundary, cheap=cheap, k=k)
+            if len(d) == 0:
+                continue
+            assert kk == k and rpw in (5, 6) and len(d) <= 256
+            cover = np.zeros((rows, cols), np.int32)
+            for i, (r0, c0, oh, ow, active, n_nbr) in enumerate(d[:, :6].tolist()):
+                assert active == oh + 2 * k and active % (4 * rpw) == 0 and active <= 16 * rpw and ow == 128 - 2 * k
+                cover[r0:r0 + oh, c0:c0 + ow] += 1
+            assert (cover == 1).all(), (rows, cols)
+            # neighbours by brute force: owned rectangles (clipped to the grid) within k cells of each other
+            rect = [(r0, min(r0 + oh, rows), c0, min(c0 + ow, cols)) for r0, c0, oh, ow in d[:, :4].tolist()]
+            for i, (a0, a1, b0, b1) in enumerate(rect):
+                want = {j for j, (p0, p1, q0, q1) in enumerate(rect)
+                        if j != i and p0 < a1 + k and p1 > a0 - k and q0 < b1 + k and q1 > b0 - k}
+                got = set(d[i, 6:6 + d[i, 5]].tolist())
+                assert got == want and d[i, 5] <= 14, (rows, cols, i, got, want)
