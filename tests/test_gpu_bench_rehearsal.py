@@ -37,6 +37,7 @@ def test_gpus_2_rehearsal_without_torchrun_prints_a_verified_line(built):
     assert line["config"]["grid"] == [4096, 2048] and "REHEARSAL" in line["data"]
     v = line["verified"]
     assert v["equal"] is True and v["mismatching_ranks"] == [] and v["blocks"] >= 4 and v["steps"] > 24, v
+    assert v["random_start"] == {"steps": 203, "equal": True, "mismatching_ranks": []}, v     # signal on every seam
     assert "closing barrier outside" in line["timing"]
     assert line["value"] > 0 and line["value_first_region"] > 0 and line["untimed_steps_before_first_region"] >= 24 + 5
 
