@@ -1656,6 +1656,7 @@ int32_t gs_ctx_set_params(gs_ctx *ctx, const gs_params *params)
 {
     if (!ctx || !params) return fail(GS_ERR_INVALID, "null argument");
     GS_TRY(check_math(*params, ctx->o.math));
+    GS_TRY(resolve_window(ctx)); // (a window launch in flight that gave up is run again with the parameters it was enqueued with)
     ctx->p = *params;
     return GS_OK;
 }
