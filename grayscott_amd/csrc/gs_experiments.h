@@ -50,8 +50,12 @@ __device__ __forceinline__ unsigned long long trace_now()
     return t;
 }
 #define GS_TRACE_AT(COND, SLOT) do { if (COND) ts[SLOT] = trace_now(); } while (0)
+#define GS_TRACE_PARAM , unsigned long long (&ts)[5] /* tb_march's extra parameter ... */
+#define GS_TRACE_ARG , ts                            /* ... and what gs_step_tb_k passes for it */
 #else
 #define GS_TRACE_AT(COND, SLOT) do { } while (0)
+#define GS_TRACE_PARAM
+#define GS_TRACE_ARG
 #endif
 
 // ---- (2) run-time ----------------------------------------------------------------------------------------

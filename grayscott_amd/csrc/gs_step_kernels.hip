@@ -765,11 +765,7 @@ struct FairBoard {
 // every row but the grid's first / last, which take the general cell (wave-uniform branch per level-row).
 template <int K, int EDGE, int FAST, int CPL, int ZH = -1, bool FAIR = false>
 __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, int strip, int lane,
-                                         const FairBoard &fb
-#if defined(GS_TB_TRACE)
-                                         , unsigned long long (&ts)[5]
-#endif
-                                         )
+                                         const FairBoard &fb GS_TRACE_PARAM)
 {
     constexpr int S = tb_sacrificial_lanes(K, CPL), W = tb_cols_per_wave(K, CPL);
     const int c = strip * W + (lane - S) * CPL; // first column of this lane (may be negative)
@@ -1004,9 +1000,6 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
 #if defined(GS_TB_TRACE)
     unsigned long long ts[5] = {trace_now(), 0, 0, 0, 0};
     const unsigned long long cycles0 = __builtin_readcyclecounter(); // s_memtime: the shader clock's counter
-#define GS_TRACE_ARG , ts
-#else
-#define GS_TRACE_ARG
 #endif
     // One branch per unit (all of it wave-uniform), one instantiation per kind of unit and boundary rule: with a
     // run-time test inside the cell the compiler hoists the other kinds' selects above the branch.  The cheap edge
@@ -1026,7 +1019,6 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         tb_march<K, KINDS ? 4 : 1, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
     else
         tb_march<K, 1, FAST, CPL, 0, FAIR>(a, ur0, ur1, strip, lane, fb GS_TRACE_ARG);
-#undef GS_TRACE_ARG
     if constexpr (FAIR) { if (lane == 0) fb.progress[wave] = 0x7fffffff; }
 #undef GS_TB_LEAVE
 #if defined(GS_TB_TRACE)
