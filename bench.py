@@ -318,6 +318,24 @@ def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_
         "hbm_physical_GBps": pmc["traffic"] / (step_ms * 1e-3) / 1e9 if pmc.get("traffic") else None,
         "profile_launch_ms": pmc.get("launch_ms"), "counters_source": pmc.get("source"),
     }
+    # The same kernel on two more, separately allocated sets of planes: where four 1 GiB allocations land in HBM decides
+    # which of three levels (~330 / 350 / 375 k at 16384^2) this HBM-bound kernel reads, from box to box and from one
+    # Species to the next (profiles/r04_sweeps.md, section 8).  `value` above is the Species the replay uses.
+    placements = [rate]
+    for _ in range(2):
+        extra = sim_s.make_species([rows, cols])
+        sim_s.perform_steps(extra, n_region)
+        r3 = []
+        for _ in range(3):
+            ctx_s.timer_start()
+            sim_s.prepare_steps(extra, n_region)
+            r3.append(cells * n_region / (ctx_s.timer_stop() * 1e-3) / 1e6)
+        ctx_s.sync()
+        placements.append(statistics.median(r3))
+        for c in extra.u._pair + extra.v._pair:
+            c.destroy()
+    single_step["by_plane_placement"] = [round(x) for x in placements]
+    single_step["frac_of_8TBps_best_placement"] = max(placements) * 1e6 * BYTES_PER_CELL_STEP / 1e9 / HBM_PEAK_GBS
     left = species.steps_done - sp_s.steps_done
     if left < 0:
         raise RuntimeError(f"the replay is ahead of the timed Species ({sp_s.steps_done} > {species.steps_done} steps)")
