@@ -321,7 +321,7 @@ def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_
     # The same kernel on two more, separately allocated sets of planes: where four 1 GiB allocations land in HBM decides
     # which of three levels (~330 / 350 / 375 k at 16384^2) this HBM-bound kernel reads, from box to box and from one
     # Species to the next (profiles/r04_sweeps.md, section 8).  `value` above is the Species the replay uses.
-    placements = [rate]
+    placements = [cells / (step_ms * 1e-3) / 1e6]        # (HIP-event rates, like the two below)
     for _ in range(2):
         extra = sim_s.make_species([rows, cols])
         sim_s.perform_steps(extra, n_region)
