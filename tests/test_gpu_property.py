@@ -25,10 +25,13 @@ def cases(draw):
     steps = draw(st.integers(1, 13))
     seed = draw(st.integers(0, 2 ** 16))
     kernel = draw(st.sampled_from([capi.GS_KERNEL_AUTO, capi.GS_KERNEL_AUTO, capi.GS_KERNEL_STREAM, capi.GS_KERNEL_TB, capi.GS_KERNEL_SIMPLE,
-                                   capi.GS_KERNEL_LDS, capi.GS_KERNEL_TILE]))
+                                   capi.GS_KERNEL_LDS, capi.GS_KERNEL_TILE, capi.GS_KERNEL_WINDOW]))
     fuse = draw(st.integers(0, 8 if kernel == capi.GS_KERNEL_TILE else 4))
     tile_shape = draw(st.integers(0, 3))
     rpb = draw(st.sampled_from([0, 1, 2, 3, 5, 8, 16, 33]))
+    if kernel == capi.GS_KERNEL_WINDOW:           # steps per exchange (even) and full window rows
+        fuse = draw(st.sampled_from([0, 2, 4, 6, 8]))
+        rpb = draw(st.sampled_from([0, 80, 96]))
     split = draw(st.integers(0, 4))
     slabs = draw(st.integers(1, 4))
     cpl = draw(st.sampled_from([0, 1, 2, 4]))
@@ -78,6 +81,20 @@ def test_any_schedule_matches_the_oracle(built, case):
     assert_bits_equal(got_v, ref_v, "V " + what)
 
 
+def _window_plan_exists(rows, cols, boundary, window_rows, k):
+    """Is the grid one round of windows on this device (the planner's own answer, gs_debug_window_plan)?"""
+    import ctypes
+
+    import torch
+
+    lib = capi.load()
+    f = lib.gs_debug_window_plan
+    f.restype = ctypes.c_int32
+    f.argtypes = [ctypes.c_uint64, ctypes.c_uint64] + [ctypes.c_int32] * 5 + [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    return f(rows, cols, cus, boundary, 1, window_rows, k, None, 0, None, None) > 0
+
+
 @st.composite
 def larger_cases(draw):
     """Grids from 40 k to 2.7 M cells: the window kernel's three windows, its hand-over to the marching kernel at
@@ -86,10 +103,13 @@ def larger_cases(draw):
     cols = draw(st.integers(200, 2100))
     steps = draw(st.integers(1, 12))
     seed = draw(st.integers(0, 2 ** 16))
-    kernel = draw(st.sampled_from([capi.GS_KERNEL_AUTO, capi.GS_KERNEL_AUTO, capi.GS_KERNEL_TB, capi.GS_KERNEL_TILE]))
+    kernel = draw(st.sampled_from([capi.GS_KERNEL_AUTO, capi.GS_KERNEL_AUTO, capi.GS_KERNEL_TB, capi.GS_KERNEL_TILE, capi.GS_KERNEL_WINDOW]))
     pinned = kernel != capi.GS_KERNEL_AUTO or draw(st.booleans())
     fuse = draw(st.integers(0, 8 if kernel == capi.GS_KERNEL_TILE else 4)) if pinned else 0
     rpb = draw(st.sampled_from([0, 0, 3, 8, 10, 16, 21, 39, 64])) if pinned else 0
+    if kernel == capi.GS_KERNEL_WINDOW:           # (grids that are not one round of windows: the test falls back to auto)
+        fuse = draw(st.sampled_from([0, 4, 8]))
+        rpb = draw(st.sampled_from([0, 80, 96]))
     cpl = draw(st.sampled_from([0, 1, 2, 4])) if pinned else 0
     slabs = draw(st.sampled_from([1, 1, 2, 3])) if pinned else 1
     tile_shape = draw(st.integers(0, 3))
@@ -107,6 +127,8 @@ def test_any_schedule_matches_the_oracle_larger_grids(built, case):
     v0 = (rng.random((rows, cols), dtype=np.float32) * np.float32(0.5)).astype(np.float32)
     p = Parameters() if default_params else Parameters(feed_rate=0.03, kill_rate=0.06, time_step=0.5)
     ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True, boundary=boundary)
+    if kernel == capi.GS_KERNEL_WINDOW and slabs == 1 and not _window_plan_exists(rows, cols, boundary, rpb, fuse):
+        kernel, fuse, rpb = capi.GS_KERNEL_AUTO, 0, 0
     got_u, got_v, info = gpu_run(u0, v0, steps, params=p,
                                  args=args(kernel=kernel, fuse_steps=fuse, rows_per_block=rpb, devices=[0] * slabs,
                                            cols_per_lane=cpl, boundary=boundary, tile_shape=tile_shape))
