@@ -32,514 +32,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BYTES_PER_CELL_STEP = 16          # read U,V + write U,V, 4 B each
-HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip table)
-HBM_COPY_CEILING_GBS = 6290.0     # measured float4-copy ceiling, same table
-# VALU issue roof for plain f32 ops: 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz (half the
-# 157.3 TFLOP/s FMA peak of the same table: the strict kernel issues no FMA)
-VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-# arithmetic the reference's update needs per cell-step when each op is one instruction (taps:
-# 4 corners x (sub, mul, add) + 4 sides x (sub with div:2, add), two species; reaction: 13)
-USEFUL_VALU_PER_CELL_STEP = 53
-
-
-def grid_for(n_gpus: int, scaling: str):
-    if scaling == "strong":
-        return (65536, 32768) if n_gpus > 4 else (32768, 16384)   # BASELINE configs 5 / 4
-    if n_gpus == 8:
-        return 65536, 32768       # BASELINE config 5
-    return 16384 * n_gpus, 16384  # config 3 (N=1), config 4 (N=2), same cells per GPU
-
-
-def usable_cpus() -> int:
-    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU
-    box exposes 256 logical CPUs but grants a 16-CPU share per GPU)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            text = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if text[0] != "max":
-                    n = min(n, max(1, int(int(text[0]) / int(text[1]))))
-            else:
-                quota = int(text[0])
-                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                if quota > 0:
-                    n = min(n, max(1, quota // period))
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    return n
-
-
-def cpu_baseline(target_seconds: float = 12.0):
-    """Times the CPU side on a bounded sample of the SAME workload (16384 x 16384, Species::new
-    init, a few steps) on every core this process may use: the port of the reference's
-    parallel(block(autovec)) backend (oracle/gs_cpu_parallel.c) -- the reported baseline -- and
-    the strict restatement of its naive backend (oracle/gs_oracle.c, OpenMP over rows) beside it."""
-    import numpy as np
-
-    import oracle
-    from oracle import cpu_parallel
-
-    rows, cols = 16384, 16384
-    threads = usable_cpus()
-    sim = cpu_parallel.ParallelSimulation(rows, cols, num_threads=threads, ftz=True)
-    sim.perform_steps(1)                                  # touch pages / warm the thread team
-    t0 = time.perf_counter()
-    sim.perform_steps(1)
-    one = time.perf_counter() - t0
-    n = max(2, min(200, int(target_seconds / max(one, 1e-3))))
-    t0 = time.perf_counter()
-    sim.perform_steps(n)
-    dt = time.perf_counter() - t0
-    info = {
-        "value": rows * cols * n / dt / 1e6,
-        "unit": "Mcells×steps/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": f"{rows}x{cols} f32, Species::new init, {n} steps of the parallel(block(autovec)) "
-                  f"port (oracle/gs_cpu_parallel.c), SIMD width {cpu_parallel.simd_width()}, FTZ on, "
-                  f"L1/L2 block {sim.l1_block_size}/{sim.l2_block_size} B, {dt:.1f} s",
-        "logical_cpus": os.cpu_count(),
-    }
-    sim.close()
-    # the strict naive restatement (the parity oracle) on the same cores, a few steps
-    u, v = oracle.init_species(rows, cols)
-    t0 = time.perf_counter()
-    u, v = oracle.run(u, v, 1, ftz=True, nthreads=threads)
-    one = time.perf_counter() - t0
-    m = max(1, min(20, int(6.0 / max(one, 1e-3))))
-    t0 = time.perf_counter()
-    oracle.run(u, v, m, ftz=True, nthreads=threads)
-    dt = time.perf_counter() - t0
-    info["naive"] = {"value": rows * cols * m / dt / 1e6, "unit": "Mcells×steps/s", "cores": threads,
-                     "sample": f"{m} steps of the strict naive restatement (oracle/gs_oracle.c), {dt:.1f} s"}
-    del u, v, np
-    return info
-
-
-def measured_counters(kernel_name: str, rows: int, cols: int, tuned):
-    """Per-launch PMC figures of the committed rocprofv3 profile of this kernel on this grid
-    (profiles/counters.json, a list written by tools/summarize_profile.py from separate --pmc passes; every
-    entry names the layout it was measured with):
-    {"traffic": HBM bytes, "valu_insts": SQ_INSTS_VALU wave-instructions, "launch_ms": rocprofv3's average
-    launch duration, "rows_per_unit", "cols_per_lane", "steps_per_pass", "source"}; {} when no profile of
-    this kernel on this grid is committed."""
-    path = os.path.join(ROOT, "profiles", "counters.json")
-    try:
-        with open(path) as f:
-            data = json.load(f)
-    except (OSError, ValueError):
-        return {}
-    label = kernel_name.split("@")[0]
-    best = {}
-    for e in data if isinstance(data, list) else []:
-        if e.get("kernel") == label and e.get("rows") == rows and e.get("cols") == cols:
-            if not best or e.get("rows_per_unit") == tuned[0]:
-                best = e
-    return best
-
-
-def scaled_valu_insts(pmc, tuned):
-    """SQ_INSTS_VALU of the committed profile, re-scaled when this run's tuner picked another unit height of
-    the same lane layout: a unit of h rows computes 4 h + 12 level-rows for 4 h stored ones (the 2K apron rows
-    of the level pipeline), everything else is the same instruction stream.  Returns (instructions, how)."""
-    insts = pmc.get("valu_insts")
-    if not insts:
-        return None, None
-    h0, h = pmc.get("rows_per_unit"), tuned[0]
-    if not h:
-        return insts, f"profile of {h0}-row units; this run's layout is not known (nothing tuned or pinned)"
-    if not h0 or h0 == h:
-        return insts, "measured (profile of this layout)"
-    if pmc.get("cols_per_lane") != tuned[2] or pmc.get("steps_per_pass") != tuned[1]:
-        return None, f"profile is for {pmc.get('cols_per_lane')} col/lane, {pmc.get('steps_per_pass')} steps/pass"
-    k = tuned[1] or 4
-    return insts * ((k * h + k * (k - 1)) / (k * h)) / ((k * h0 + k * (k - 1)) / (k * h0)), \
-        f"scaled from the profile's {h0}-row units to this run's {h}-row units"
-
-
-def developed_start(rows, cols):
-    """Start of a pattern-forming run instead of the reference's benchmark input: U = 1, V = 0 with one
-    12 x 12 seed (U = 0.5, V = 0.25) per 40 000 cells and 1 % noise (tools/pattern_rate.py, profiles/r01_soak.md:
-    4000 steps later spots fill the grid).  Returns dense host arrays (u0, v0)."""
-    import numpy as np
-
-    rng = np.random.default_rng(2024)
-    u0 = np.ones((rows, cols), np.float32)
-    v0 = np.zeros((rows, cols), np.float32)
-    for _ in range(max(4, rows * cols // 40000)):
-        r, c = int(rng.integers(0, max(1, rows - 12))), int(rng.integers(0, max(1, cols - 12)))
-        u0[r:r + 12, c:c + 12] = 0.5
-        v0[r:r + 12, c:c + 12] = 0.25
-    u0 += rng.random(u0.shape, dtype=np.float32) * np.float32(0.01)
-    v0 += rng.random(v0.shape, dtype=np.float32) * np.float32(0.01)
-    return u0, v0
-
-
-def upload_species(sim, u0, v0):
-    """A Species of `sim`'s context whose input planes hold (u0, v0); `steps_done` counts what it has run."""
-    from grayscott_amd import Evolving, HipConcentration, Species
-
-    ctx = sim.context
-    u = Evolving([HipConcentration(ctx, u0.shape), HipConcentration(ctx, u0.shape)])
-    v = Evolving([HipConcentration(ctx, u0.shape), HipConcentration(ctx, u0.shape)])
-    u.in_out()[0].upload(ctx, u0)
-    v.in_out()[0].upload(ctx, v0)
-    species = Species(ctx, u, v)
-    species.steps_done = 0
-    return species
-
-
-NOMINAL_SCLK_MHZ = 2400.0  # the clock VALU_PEAK_TLANEOPS is priced at
-
-
-def sample_clock_and_power(work, device: int, cell_steps: float = 0.0):
-    """Medians of rocm-smi's shader clock (MHz) and socket power (W) sampled while `work()` runs, the board's
-    power cap, and -- from the card's accumulated-energy counter, first and last sample taken while the kernel
-    ran -- the average power over that window and the energy per cell-step (`work` returns (wall seconds, ...)
-    for `cell_steps` cell-steps, so pJ per cell-step = watts x seconds / cell-steps).  None when rocm-smi is
-    missing or says nothing useful (informational fields, never part of `value`)."""
-    import re
-    import shutil
-    import statistics
-    import subprocess
-    import threading
-
-    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
-    if not os.path.exists(smi):
-        return None
-    sclk, power, energy, stop = [], [], [], threading.Event()
-    cap = [None]
-
-    def sampler():
-        try:
-            out = subprocess.run([smi, "-d", str(device), "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
-            m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", out)
-            if m:
-                cap[0] = float(m.group(1))
-        except Exception:
-            pass
-        while not stop.is_set():
-            t0 = time.monotonic()
-            try:
-                out = subprocess.run([smi, "-d", str(device), "--showclocks", "--showpower", "--showenergycounter"],
-                                     capture_output=True, text=True, timeout=10).stdout
-            except Exception:
-                return
-            t1 = time.monotonic()
-            busy = False
-            m = re.search(r"sclk clock level:[^(]*\((\d+)Mhz\)", out)
-            if m:
-                busy = float(m.group(1)) > 1000.0
-                sclk.append(float(m.group(1)))
-            m = re.search(r"Power \(W\):\s*([0-9.]+)", out)
-            if m:
-                power.append(float(m.group(1)))
-            m = re.search(r"Accumulated Energy \(uJ\):\s*([0-9.]+)", out)
-            if m and busy:
-                energy.append((0.5 * (t0 + t1), float(m.group(1))))
-            stop.wait(0.2)
-
-    thread = threading.Thread(target=sampler, daemon=True)
-    thread.start()
-    try:
-        ret = work()
-    finally:
-        stop.set()
-        thread.join(timeout=15)
-    busy = [c for c in sclk if c > 1000.0]          # samples taken while the kernel ran
-    if not busy:
-        return None
-    out = {"sclk_MHz": statistics.median(busy), "power_W": statistics.median(power) if power else None,
-           "samples": len(busy), "power_cap_W": cap[0]}
-    # the last sample may have been taken after the kernel ended: leave it out when there are enough
-    win = energy[:-1] if len(energy) >= 4 else energy
-    if len(win) >= 2 and win[-1][0] - win[0][0] > 0.5 and cell_steps > 0 and ret:
-        watts = (win[-1][1] - win[0][1]) * 1e-6 / (win[-1][0] - win[0][0])
-        out["energy_W"] = watts
-        out["energy_window_s"] = win[-1][0] - win[0][0]
-        out["energy_pJ_per_cell_step"] = watts * ret[0] / cell_steps * 1e12
-    return out
-
-
-def planes_equal(a, b) -> bool:
-    """Bit-for-bit equality of two HipConcentrations of one shape, compared on the device (the planes are
-    1 GiB each at 16384^2): int32 views, so that NaNs and signed zeros count as what they are."""
-    import torch
-
-    ok = True
-    for (_, _, x), (_, _, y) in zip(a.torch_views(), b.torch_views()):
-        ok = ok and bool(torch.equal(x.view(torch.int32), y.view(torch.int32)))
-    return ok
-
-
-def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_kernel):
-    """In-run proof that the timed launches did the work, and the HBM-bound single-step leg north_star asks the
-    rocprof evidence for.  A second context pinned to the single-step stream kernel (one launch = one step =
-    one read and one write of U and V: 16 B per cell-step of HBM traffic) starts from the same Species::new,
-    is timed over 5 regions of steps (`single_step`), then runs on to exactly the number of steps the timed
-    Species has taken -- tuning passes, warm-ups and every timed region included -- and both planes must be
-    equal bit for bit; the same for the developed pattern (same upload, same step count)."""
-    import statistics
-
-    ctx_s = sim_s.context
-    cells = rows * cols
-    n_region = max(40, min(400, int(0.08 * 3.5e11 / cells)))        # ~80 ms per region
-    n_region = min(n_region, max(1, (species.steps_done - 40) // 6))
-    sim_s.perform_steps(sp_s, n_region)                              # untimed: clocks, first touches
-    sp_s.steps_done += n_region
-    rates, launch_ms = [], []
-    for _ in range(5):
-        ctx_s.sync()
-        t0 = time.perf_counter()
-        ctx_s.timer_start()
-        sim_s.prepare_steps(sp_s, n_region)
-        ms = ctx_s.timer_stop()
-        ctx_s.sync()
-        wall = time.perf_counter() - t0
-        sp_s.steps_done += n_region
-        rates.append(cells * n_region / wall / 1e6)
-        launch_ms.append(ms / n_region)
-    rate = statistics.median(rates)
-    step_ms = statistics.median(launch_ms)
-    gbs = BYTES_PER_CELL_STEP * cells / (step_ms * 1e-3) / 1e9
-    label = ctx_s.info()[0]
-    pmc = measured_counters(label, rows, cols, (0, 0, 0))
-    single_step = {
-        "kernel": label,
-        "value": rate, "unit": "Mcells×steps/s", "values": [round(r) for r in rates], "steps_per_region": n_region,
-        "launch_ms": step_ms,                                    # HIP events on the library's stream, per launch
-        "hbm_GBps": gbs,                                         # algorithmic: 16 B per cell-step, one step per launch
-        "frac_of_8TBps": gbs / HBM_PEAK_GBS,
-        "frac_of_copy_ceiling": gbs / HBM_COPY_CEILING_GBS,
-        "traffic": pmc.get("traffic"),                           # HBM bytes per launch, PMC of the committed profile
-        "hbm_physical_GBps": pmc["traffic"] / (step_ms * 1e-3) / 1e9 if pmc.get("traffic") else None,
-        "profile_launch_ms": pmc.get("launch_ms"), "counters_source": pmc.get("source"),
-    }
-    # The same kernel on two more, separately allocated sets of planes: where four 1 GiB allocations land in HBM decides
-    # which of three levels (~330 / 350 / 375 k at 16384^2) this HBM-bound kernel reads, from box to box and from one
-    # Species to the next (profiles/r04_sweeps.md, section 8).  `value` above is the Species the replay uses.
-    placements = [cells / (step_ms * 1e-3) / 1e6]        # (HIP-event rates, like the two below)
-    for _ in range(2):
-        extra = sim_s.make_species([rows, cols])
-        sim_s.perform_steps(extra, n_region)
-        r3 = []
-        for _ in range(3):
-            ctx_s.timer_start()
-            sim_s.prepare_steps(extra, n_region)
-            r3.append(cells * n_region / (ctx_s.timer_stop() * 1e-3) / 1e6)
-        ctx_s.sync()
-        placements.append(statistics.median(r3))
-        for c in extra.u._pair + extra.v._pair:
-            c.destroy()
-    single_step["by_plane_placement"] = [round(x) for x in placements]
-    single_step["frac_of_8TBps_best_placement"] = max(placements) * 1e6 * BYTES_PER_CELL_STEP / 1e9 / HBM_PEAK_GBS
-    left = species.steps_done - sp_s.steps_done
-    if left < 0:
-        raise RuntimeError(f"the replay is ahead of the timed Species ({sp_s.steps_done} > {species.steps_done} steps)")
-    sim_s.perform_steps(sp_s, left)
-    sp_s.steps_done += left
-    species.context().sync()
-    a, b = species.in_out(), sp_s.in_out()
-    verified = {"against": f"single-step kernel {label} in a second context, same start", "timed_kernel": timed_kernel,
-                "steps": species.steps_done,
-                "equal": planes_equal(a[0], b[0]) and planes_equal(a[1], b[1])}
-    if sp_dev is not None and sp_dev_s is not None:
-        sim_s.perform_steps(sp_dev_s, sp_dev.steps_done)
-        a, b = sp_dev.in_out(), sp_dev_s.in_out()
-        verified["developed_pattern"] = {"steps": sp_dev.steps_done,
-                                         "equal": planes_equal(a[0], b[0]) and planes_equal(a[1], b[1])}
-    return single_step, verified
-
-
-def range_checksums(view, block: int = 2048):
-    """Two wrapping int64 sums (plain, position-weighted) of the bit patterns of every `block` rows of a plane
-    view: a checksum of checksums for planes that live on different GPUs."""
-    import torch
-
-    out = []
-    for k0 in range(0, view.shape[0], block):
-        x = view[k0:k0 + block].view(torch.int32).to(torch.int64)
-        w = (torch.arange(x.numel(), device=x.device, dtype=torch.int64) % 65521 + 1).reshape(x.shape)
-        out.append((int(x.sum()), int((x * w).sum())))
-    return out
-
-
-def fill_noise(species, ctx, block: int = 2048):
-    """Random U in [0, 1), V in [0, 0.5) in every cell, written on the device through the planes' pointers: a function
-    of the global row block alone, so that every rank of a chain and a single-GPU replay hold the same start."""
-    import torch
-
-    in_u, in_v, _, _ = species.in_out()
-    cols = in_u.shape()[1]
-    for si, conc in enumerate((in_u, in_v)):
-        for row0, rows, view in conc.torch_views():
-            for k in range(row0 // block, (row0 + rows + block - 1) // block):
-                g = torch.Generator(device=view.device)
-                g.manual_seed(1_000_003 * (k + 1) + si)
-                x = torch.rand((block, cols), generator=g, device=view.device, dtype=torch.float32)
-                lo, hi = max(k * block, row0), min((k + 1) * block, row0 + rows)
-                view[lo - row0:hi - row0].copy_((x if si == 0 else x * 0.5)[lo - k * block:hi - k * block])
-        torch.cuda.synchronize()
-        conc.mark_written(ctx)
-
-
-def verify_slab_chain(sim, species, rows, cols, rank, world, local_rank, rehearsal):
-    """N > 1: every rank checksums the rows it holds; rank 0 replays the WHOLE grid alone (a single slab on its
-    own GPU: 288 GB hold BASELINE config 5 several times over) for as many steps as the chain has taken and
-    checksums the same row ranges.  Equal sums = the exchanged ghost rows carried the right data on every seam.
-    Twice: the timed Species (the reference's input: signal on the seam under the seed only), and 203 steps (a
-    remainder pass, full passes) from random data everywhere, so that EVERY seam carries signal from step one."""
-    import torch.distributed as dist
-
-    from grayscott_amd import HipArgs, Parameters, Simulation
-
-    def local_sums(sp):
-        sp.context().sync()
-        out = []
-        for conc in sp.in_out()[:2]:
-            for row0, nrows, view in conc.torch_views():
-                out.append((row0, nrows, range_checksums(view)))
-        return out
-
-    noise_steps = 203
-    noisy = sim.make_species([rows, cols])
-    fill_noise(noisy, sim.context)
-    sim.perform_steps(noisy, noise_steps)
-    gathered = [None] * world
-    dist.all_gather_object(gathered, (local_sums(species), local_sums(noisy)))
-    result = None
-    if rank == 0:
-        solo = Simulation.new(Parameters(), HipArgs(devices=[local_rank]))
-
-        def compare(which, whole):
-            views = [conc.torch_views()[0][2] for conc in whole.in_out()[:2]]
-            bad, blocks = [], 0
-            for r, both in enumerate(gathered):
-                parts = both[which]
-                per_plane = len(parts) // 2
-                for i, (row0, nrows, sums) in enumerate(parts):
-                    ref = range_checksums(views[i // per_plane][row0:row0 + nrows])
-                    blocks += len(ref)
-                    if ref != sums and r not in bad:
-                        bad.append(r)
-            return bad, blocks
-
-        whole = solo.make_species([rows, cols])
-        solo.perform_steps(whole, species.steps_done)
-        bad, blocks = compare(0, whole)
-        fill_noise(whole, solo.context)
-        solo.perform_steps(whole, noise_steps)
-        bad_n, _ = compare(1, whole)
-        solo.context.close()
-        result = {"against": "single-GPU run of the whole grid on rank 0 (row-block checksums of U and V)",
-                  "steps": species.steps_done, "equal": not bad and not bad_n, "blocks": blocks, "mismatching_ranks": bad,
-                  "random_start": {"steps": noise_steps, "equal": not bad_n, "mismatching_ranks": bad_n}}
-    return result
-
-
-class Watchdog:
-    """Per-rank stage timer.  `with wd.stage(name, seconds):` arms a bound; a daemon thread that finds it
-    exceeded prints ONE JSON line {"error", "rank", "stage", "bound_s"} and ends the process with exit code 3
-    (os._exit: the main thread may sit in ncclCommInitRank or a stream wait that never returns).  No restart,
-    no re-exec: torchrun sees the non-zero exit and takes the other ranks down.
-    GS_BENCH_WATCHDOG_S caps every bound (tests use a few seconds)."""
-
-    EXIT_CODE = 3
-
-    def __init__(self, rank: int = 0, out=None):
-        import threading
-
-        self.rank = rank
-        self.out = out or sys.stdout
-        self._lock = threading.Lock()
-        self._stage = None          # (name, deadline, bound)
-        cap = os.environ.get("GS_BENCH_WATCHDOG_S", "")
-        self._cap = float(cap) if cap else None
-        self._thread = threading.Thread(target=self._watch, daemon=True)
-        self._thread.start()
-
-    def _watch(self):
-        while True:
-            time.sleep(0.25)
-            with self._lock:
-                st = self._stage
-            if st and time.monotonic() > st[1]:
-                line = json.dumps({"error": f"stage '{st[0]}' exceeded its bound of {st[2]:.0f} s",
-                                   "rank": self.rank, "stage": st[0], "bound_s": st[2]})
-                try:
-                    self.out.write(line + "\n")
-                    self.out.flush()
-                finally:
-                    os._exit(self.EXIT_CODE)
-
-    def stage(self, name: str, seconds: float):
-        wd = self
-        bound = min(seconds, self._cap) if self._cap else seconds
-
-        class _Stage:
-            def __enter__(self_inner):
-                with wd._lock:
-                    wd._stage = (name, time.monotonic() + bound, bound)
-                fault = os.environ.get("GS_BENCH_FAULT", "")       # "stall:RANK:STAGE" (tests)
-                if fault.startswith("stall:"):
-                    _, r, st = fault.split(":")
-                    if int(r) == wd.rank and st == name:
-                        time.sleep(1e6)
-
-            def __exit__(self_inner, *exc):
-                with wd._lock:
-                    wd._stage = None
-                return False
-
-        return _Stage()
-
-
-def self_launch(args) -> int:
-    """`python bench.py --gpus N` (N > 1) without a torchrun environment: start `torch.distributed.run` as a
-    CHILD process -- before this process has touched a GPU or loaded libgs_hip.so -- relay its output (the one
-    JSON line) and return its exit code.  Never an exec of this process."""
-    import socket
-    import subprocess
-
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if args.rehearsal and not env.get("GS_RCCL_LIBRARY"):
-        # all ranks share GPU 0: RCCL refuses that, the library binds the shared-memory transport double
-        import shutil
-
-        out_dir = os.path.join(ROOT, "gpurun_out", "rehearsal")
-        os.makedirs(out_dir, exist_ok=True)
-        lib = os.path.join(out_dir, "libshm_transport.so")
-        cc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        r = subprocess.run([cc, "-O2", "-fPIC", "-shared", "-std=c++17", "-x", "hip", "--offload-arch=gfx950",
-                            os.path.join(ROOT, "tests", "cpp", "shm_transport.cpp"), "-o", lib, "-lrt", "-lpthread"],
-                           capture_output=True, text=True)
-        if r.returncode != 0:
-            print("bench.py: building the rehearsal transport failed:\n" + r.stdout + r.stderr, file=sys.stderr)
-            return 2
-        env["GS_RCCL_LIBRARY"] = lib
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    limit = float(os.environ.get("GS_BENCH_CHILD_TIMEOUT_S", "1500"))
-    child = subprocess.Popen(cmd, env=env, start_new_session=True)       # inherits stdout / stderr
-    try:
-        return child.wait(timeout=limit)
-    except subprocess.TimeoutExpired:
-        import signal
-
-        print(json.dumps({"error": f"the torchrun child exceeded {limit:.0f} s", "rank": -1, "stage": "child"}))
-        try:
-            os.killpg(child.pid, signal.SIGKILL)     # the session this process started, nothing else
-        except OSError:
-            pass
-        child.wait()
-        return 3
+from benchkit.harness import (BYTES_PER_CELL_STEP, HBM_COPY_CEILING_GBS, HBM_PEAK_GBS, NOMINAL_SCLK_MHZ,  # noqa: E402,F401
+                              USEFUL_VALU_PER_CELL_STEP, VALU_PEAK_TLANEOPS, Watchdog, grid_for, self_launch, usable_cpus)
+from benchkit.legs import (cpu_baseline, developed_start, measured_counters, planes_equal,  # noqa: E402,F401
+                           sample_clock_and_power, scaled_valu_insts, upload_species, verify_single_gpu)
+from benchkit.multigpu import fill_noise, range_checksums, verify_slab_chain  # noqa: E402,F401
 
 
 def main() -> int:

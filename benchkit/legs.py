@@ -1,0 +1,292 @@
+"""The legs of bench.py's single-GPU line beside the timed regions: the CPU baseline (the only user of oracle/ outside
+tests and smoke()), the committed PMC counters, the developed-pattern input, clock / power / energy sampling, the
+single-step HBM leg with the in-run replay that proves the timed launches did the work."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from .harness import (BYTES_PER_CELL_STEP, HBM_COPY_CEILING_GBS, HBM_PEAK_GBS, usable_cpus)
+
+
+def cpu_baseline(target_seconds: float = 12.0):
+    """Times the CPU side on a bounded sample of the SAME workload (16384 x 16384, Species::new
+    init, a few steps) on every core this process may use: the port of the reference's
+    parallel(block(autovec)) backend (oracle/gs_cpu_parallel.c) -- the reported baseline -- and
+    the strict restatement of its naive backend (oracle/gs_oracle.c, OpenMP over rows) beside it."""
+    import numpy as np
+
+    import oracle
+    from oracle import cpu_parallel
+
+    rows, cols = 16384, 16384
+    threads = usable_cpus()
+    sim = cpu_parallel.ParallelSimulation(rows, cols, num_threads=threads, ftz=True)
+    sim.perform_steps(1)                                  # touch pages / warm the thread team
+    t0 = time.perf_counter()
+    sim.perform_steps(1)
+    one = time.perf_counter() - t0
+    n = max(2, min(200, int(target_seconds / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    sim.perform_steps(n)
+    dt = time.perf_counter() - t0
+    info = {
+        "value": rows * cols * n / dt / 1e6,
+        "unit": "Mcells×steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{rows}x{cols} f32, Species::new init, {n} steps of the parallel(block(autovec)) "
+                  f"port (oracle/gs_cpu_parallel.c), SIMD width {cpu_parallel.simd_width()}, FTZ on, "
+                  f"L1/L2 block {sim.l1_block_size}/{sim.l2_block_size} B, {dt:.1f} s",
+        "logical_cpus": os.cpu_count(),
+    }
+    sim.close()
+    # the strict naive restatement (the parity oracle) on the same cores, a few steps
+    u, v = oracle.init_species(rows, cols)
+    t0 = time.perf_counter()
+    u, v = oracle.run(u, v, 1, ftz=True, nthreads=threads)
+    one = time.perf_counter() - t0
+    m = max(1, min(20, int(6.0 / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    oracle.run(u, v, m, ftz=True, nthreads=threads)
+    dt = time.perf_counter() - t0
+    info["naive"] = {"value": rows * cols * m / dt / 1e6, "unit": "Mcells×steps/s", "cores": threads,
+                     "sample": f"{m} steps of the strict naive restatement (oracle/gs_oracle.c), {dt:.1f} s"}
+    del u, v, np
+    return info
+
+
+def measured_counters(kernel_name: str, rows: int, cols: int, tuned):
+    """Per-launch PMC figures of the committed rocprofv3 profile of this kernel on this grid
+    (profiles/counters.json, a list written by tools/summarize_profile.py from separate --pmc passes; every
+    entry names the layout it was measured with):
+    {"traffic": HBM bytes, "valu_insts": SQ_INSTS_VALU wave-instructions, "launch_ms": rocprofv3's average
+    launch duration, "rows_per_unit", "cols_per_lane", "steps_per_pass", "source"}; {} when no profile of
+    this kernel on this grid is committed."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    try:
+        with open(path) as f:
+            data = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    label = kernel_name.split("@")[0]
+    best = {}
+    for e in data if isinstance(data, list) else []:
+        if e.get("kernel") == label and e.get("rows") == rows and e.get("cols") == cols:
+            if not best or e.get("rows_per_unit") == tuned[0]:
+                best = e
+    return best
+
+
+def scaled_valu_insts(pmc, tuned):
+    """SQ_INSTS_VALU of the committed profile, re-scaled when this run's tuner picked another unit height of
+    the same lane layout: a unit of h rows computes 4 h + 12 level-rows for 4 h stored ones (the 2K apron rows
+    of the level pipeline), everything else is the same instruction stream.  Returns (instructions, how)."""
+    insts = pmc.get("valu_insts")
+    if not insts:
+        return None, None
+    h0, h = pmc.get("rows_per_unit"), tuned[0]
+    if not h:
+        return insts, f"profile of {h0}-row units; this run's layout is not known (nothing tuned or pinned)"
+    if not h0 or h0 == h:
+        return insts, "measured (profile of this layout)"
+    if pmc.get("cols_per_lane") != tuned[2] or pmc.get("steps_per_pass") != tuned[1]:
+        return None, f"profile is for {pmc.get('cols_per_lane')} col/lane, {pmc.get('steps_per_pass')} steps/pass"
+    k = tuned[1] or 4
+    return insts * ((k * h + k * (k - 1)) / (k * h)) / ((k * h0 + k * (k - 1)) / (k * h0)), \
+        f"scaled from the profile's {h0}-row units to this run's {h}-row units"
+
+
+def developed_start(rows, cols):
+    """Start of a pattern-forming run instead of the reference's benchmark input: U = 1, V = 0 with one
+    12 x 12 seed (U = 0.5, V = 0.25) per 40 000 cells and 1 % noise (tools/pattern_rate.py, profiles/r01_soak.md:
+    4000 steps later spots fill the grid).  Returns dense host arrays (u0, v0)."""
+    import numpy as np
+
+    rng = np.random.default_rng(2024)
+    u0 = np.ones((rows, cols), np.float32)
+    v0 = np.zeros((rows, cols), np.float32)
+    for _ in range(max(4, rows * cols // 40000)):
+        r, c = int(rng.integers(0, max(1, rows - 12))), int(rng.integers(0, max(1, cols - 12)))
+        u0[r:r + 12, c:c + 12] = 0.5
+        v0[r:r + 12, c:c + 12] = 0.25
+    u0 += rng.random(u0.shape, dtype=np.float32) * np.float32(0.01)
+    v0 += rng.random(v0.shape, dtype=np.float32) * np.float32(0.01)
+    return u0, v0
+
+
+def upload_species(sim, u0, v0):
+    """A Species of `sim`'s context whose input planes hold (u0, v0); `steps_done` counts what it has run."""
+    from grayscott_amd import Evolving, HipConcentration, Species
+
+    ctx = sim.context
+    u = Evolving([HipConcentration(ctx, u0.shape), HipConcentration(ctx, u0.shape)])
+    v = Evolving([HipConcentration(ctx, u0.shape), HipConcentration(ctx, u0.shape)])
+    u.in_out()[0].upload(ctx, u0)
+    v.in_out()[0].upload(ctx, v0)
+    species = Species(ctx, u, v)
+    species.steps_done = 0
+    return species
+
+
+def sample_clock_and_power(work, device: int, cell_steps: float = 0.0):
+    """Medians of rocm-smi's shader clock (MHz) and socket power (W) sampled while `work()` runs, the board's
+    power cap, and -- from the card's accumulated-energy counter, first and last sample taken while the kernel
+    ran -- the average power over that window and the energy per cell-step (`work` returns (wall seconds, ...)
+    for `cell_steps` cell-steps, so pJ per cell-step = watts x seconds / cell-steps).  None when rocm-smi is
+    missing or says nothing useful (informational fields, never part of `value`)."""
+    import re
+    import shutil
+    import statistics
+    import subprocess
+    import threading
+
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    sclk, power, energy, stop = [], [], [], threading.Event()
+    cap = [None]
+
+    def sampler():
+        try:
+            out = subprocess.run([smi, "-d", str(device), "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
+            m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", out)
+            if m:
+                cap[0] = float(m.group(1))
+        except Exception:
+            pass
+        while not stop.is_set():
+            t0 = time.monotonic()
+            try:
+                out = subprocess.run([smi, "-d", str(device), "--showclocks", "--showpower", "--showenergycounter"],
+                                     capture_output=True, text=True, timeout=10).stdout
+            except Exception:
+                return
+            t1 = time.monotonic()
+            busy = False
+            m = re.search(r"sclk clock level:[^(]*\((\d+)Mhz\)", out)
+            if m:
+                busy = float(m.group(1)) > 1000.0
+                sclk.append(float(m.group(1)))
+            m = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+            if m:
+                power.append(float(m.group(1)))
+            m = re.search(r"Accumulated Energy \(uJ\):\s*([0-9.]+)", out)
+            if m and busy:
+                energy.append((0.5 * (t0 + t1), float(m.group(1))))
+            stop.wait(0.2)
+
+    thread = threading.Thread(target=sampler, daemon=True)
+    thread.start()
+    try:
+        ret = work()
+    finally:
+        stop.set()
+        thread.join(timeout=15)
+    busy = [c for c in sclk if c > 1000.0]          # samples taken while the kernel ran
+    if not busy:
+        return None
+    out = {"sclk_MHz": statistics.median(busy), "power_W": statistics.median(power) if power else None,
+           "samples": len(busy), "power_cap_W": cap[0]}
+    # the last sample may have been taken after the kernel ended: leave it out when there are enough
+    win = energy[:-1] if len(energy) >= 4 else energy
+    if len(win) >= 2 and win[-1][0] - win[0][0] > 0.5 and cell_steps > 0 and ret:
+        watts = (win[-1][1] - win[0][1]) * 1e-6 / (win[-1][0] - win[0][0])
+        out["energy_W"] = watts
+        out["energy_window_s"] = win[-1][0] - win[0][0]
+        out["energy_pJ_per_cell_step"] = watts * ret[0] / cell_steps * 1e12
+    return out
+
+
+def planes_equal(a, b) -> bool:
+    """Bit-for-bit equality of two HipConcentrations of one shape, compared on the device (the planes are
+    1 GiB each at 16384^2): int32 views, so that NaNs and signed zeros count as what they are."""
+    import torch
+
+    ok = True
+    for (_, _, x), (_, _, y) in zip(a.torch_views(), b.torch_views()):
+        ok = ok and bool(torch.equal(x.view(torch.int32), y.view(torch.int32)))
+    return ok
+
+
+def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_kernel):
+    """In-run proof that the timed launches did the work, and the HBM-bound single-step leg north_star asks the
+    rocprof evidence for.  A second context pinned to the single-step stream kernel (one launch = one step =
+    one read and one write of U and V: 16 B per cell-step of HBM traffic) starts from the same Species::new,
+    is timed over 5 regions of steps (`single_step`), then runs on to exactly the number of steps the timed
+    Species has taken -- tuning passes, warm-ups and every timed region included -- and both planes must be
+    equal bit for bit; the same for the developed pattern (same upload, same step count)."""
+    import statistics
+
+    ctx_s = sim_s.context
+    cells = rows * cols
+    n_region = max(40, min(400, int(0.08 * 3.5e11 / cells)))        # ~80 ms per region
+    n_region = min(n_region, max(1, (species.steps_done - 40) // 6))
+    sim_s.perform_steps(sp_s, n_region)                              # untimed: clocks, first touches
+    sp_s.steps_done += n_region
+    rates, launch_ms = [], []
+    for _ in range(5):
+        ctx_s.sync()
+        t0 = time.perf_counter()
+        ctx_s.timer_start()
+        sim_s.prepare_steps(sp_s, n_region)
+        ms = ctx_s.timer_stop()
+        ctx_s.sync()
+        wall = time.perf_counter() - t0
+        sp_s.steps_done += n_region
+        rates.append(cells * n_region / wall / 1e6)
+        launch_ms.append(ms / n_region)
+    rate = statistics.median(rates)
+    step_ms = statistics.median(launch_ms)
+    gbs = BYTES_PER_CELL_STEP * cells / (step_ms * 1e-3) / 1e9
+    label = ctx_s.info()[0]
+    pmc = measured_counters(label, rows, cols, (0, 0, 0))
+    single_step = {
+        "kernel": label,
+        "value": rate, "unit": "Mcells×steps/s", "values": [round(r) for r in rates], "steps_per_region": n_region,
+        "launch_ms": step_ms,                                    # HIP events on the library's stream, per launch
+        "hbm_GBps": gbs,                                         # algorithmic: 16 B per cell-step, one step per launch
+        "frac_of_8TBps": gbs / HBM_PEAK_GBS,
+        "frac_of_copy_ceiling": gbs / HBM_COPY_CEILING_GBS,
+        "traffic": pmc.get("traffic"),                           # HBM bytes per launch, PMC of the committed profile
+        "hbm_physical_GBps": pmc["traffic"] / (step_ms * 1e-3) / 1e9 if pmc.get("traffic") else None,
+        "profile_launch_ms": pmc.get("launch_ms"), "counters_source": pmc.get("source"),
+    }
+    # The same kernel on two more, separately allocated sets of planes: where four 1 GiB allocations land in HBM decides
+    # which of three levels (~330 / 350 / 375 k at 16384^2) this HBM-bound kernel reads, from box to box and from one
+    # Species to the next (profiles/r04_sweeps.md, section 8).  `value` above is the Species the replay uses.
+    placements = [cells / (step_ms * 1e-3) / 1e6]        # (HIP-event rates, like the two below)
+    for _ in range(2):
+        extra = sim_s.make_species([rows, cols])
+        sim_s.perform_steps(extra, n_region)
+        r3 = []
+        for _ in range(3):
+            ctx_s.timer_start()
+            sim_s.prepare_steps(extra, n_region)
+            r3.append(cells * n_region / (ctx_s.timer_stop() * 1e-3) / 1e6)
+        ctx_s.sync()
+        placements.append(statistics.median(r3))
+        for c in extra.u._pair + extra.v._pair:
+            c.destroy()
+    single_step["by_plane_placement"] = [round(x) for x in placements]
+    single_step["frac_of_8TBps_best_placement"] = max(placements) * 1e6 * BYTES_PER_CELL_STEP / 1e9 / HBM_PEAK_GBS
+    left = species.steps_done - sp_s.steps_done
+    if left < 0:
+        raise RuntimeError(f"the replay is ahead of the timed Species ({sp_s.steps_done} > {species.steps_done} steps)")
+    sim_s.perform_steps(sp_s, left)
+    sp_s.steps_done += left
+    species.context().sync()
+    a, b = species.in_out(), sp_s.in_out()
+    verified = {"against": f"single-step kernel {label} in a second context, same start", "timed_kernel": timed_kernel,
+                "steps": species.steps_done,
+                "equal": planes_equal(a[0], b[0]) and planes_equal(a[1], b[1])}
+    if sp_dev is not None and sp_dev_s is not None:
+        sim_s.perform_steps(sp_dev_s, sp_dev.steps_done)
+        a, b = sp_dev.in_out(), sp_dev_s.in_out()
+        verified["developed_pattern"] = {"steps": sp_dev.steps_done,
+                                         "equal": planes_equal(a[0], b[0]) and planes_equal(a[1], b[1])}
+    return single_step, verified

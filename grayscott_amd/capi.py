@@ -38,7 +38,7 @@ EXPORTS = (
     "gs_host_alloc", "gs_host_free", "gs_field_download_async", "gs_download_wait",
     "gs_ctx_get_tuned", "gs_ctx_set_tuned", "gs_ctx_comm_info", "gs_field_colormap",
     "gs_ctx_stats", "gs_ctx_set_pass_timing", "gs_field_mark_written", "gs_rccl_selftest",
-    "gs_debug_dyn_lds_key", "gs_debug_window_plan",
+    "gs_runtime_info", "gs_debug_dyn_lds_key", "gs_debug_window_plan",
 )
 
 
@@ -78,7 +78,8 @@ class GsOptions(ctypes.Structure):
         ("boundary", ctypes.c_int32),
         ("no_tune", ctypes.c_int32),
         ("tile_shape", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 4),
+        ("share_taps", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 3),
     ]
 
 
@@ -95,6 +96,7 @@ class GsStats(ctypes.Structure):
         ("interior_ms", ctypes.c_float),
         ("halo_exposed_ms", ctypes.c_float),
         ("reserved", ctypes.c_float),
+        ("window_fallbacks", ctypes.c_uint64),
     ]
 
 
@@ -144,14 +146,15 @@ def load() -> ctypes.CDLL:
         "gs_host_free": (i32, [vp]),
         "gs_field_download_async": (i32, [vp, vp, vp]),
         "gs_download_wait": (i32, [vp]),
-        "gs_ctx_get_tuned": (i32, [vp, u64, u64, P(i32), P(i32), P(i32)]),
-        "gs_ctx_set_tuned": (i32, [vp, u64, u64, i32, i32, i32]),
+        "gs_ctx_get_tuned": (i32, [vp, u64, u64, P(i32), P(i32), P(i32), P(i32)]),
+        "gs_ctx_set_tuned": (i32, [vp, u64, u64, i32, i32, i32, i32]),
         "gs_ctx_comm_info": (i32, [vp, P(i32), P(i32), P(i32)]),
         "gs_field_colormap": (i32, [vp, vp, f32, vp, i32, vp]),
         "gs_ctx_stats": (i32, [vp, P(GsStats)]),
         "gs_ctx_set_pass_timing": (i32, [vp, i32]),
         "gs_field_mark_written": (i32, [vp, vp]),
         "gs_rccl_selftest": (i32, [i32, u64]),
+        "gs_runtime_info": (i32, [i32, ctypes.c_char_p, ctypes.c_size_t]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
@@ -188,6 +191,15 @@ def device_count() -> int:
 def rccl_selftest(device: int = 0, floats: int = 1 << 16) -> None:
     """``gs_rccl_selftest``: raises ``GsError`` when RCCL cannot be loaded or a one-rank send / receive fails."""
     check(load().gs_rccl_selftest(device, floats))
+
+
+def runtime_info(load_rccl: bool = False) -> dict:
+    """``gs_runtime_info``: the HIP runtime and the RCCL this process's libgs_hip.so is bound to (paths, versions)."""
+    import json
+
+    buf = ctypes.create_string_buffer(2048)
+    check(load().gs_runtime_info(1 if load_rccl else 0, buf, len(buf)))
+    return json.loads(buf.value.decode())
 
 
 def get_unique_id() -> bytes:

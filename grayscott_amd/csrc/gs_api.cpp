@@ -181,15 +181,16 @@ struct gs_ctx {
     uint64_t tuned_rows = 0, tuned_cols = 0;
     int tuned_fuse = 0, tuned_rpu = 0, tuned_split = 0, tuned_k = 0; // tuned_k: fused steps per pass chosen
     int tuned_cpl = 0;                                               // columns per lane chosen
+    int tuned_share = 1;                                             // full difference sharing chosen (0 / 1)
     // every finished choice (a context that alternates between grids does not re-tune)
-    struct Tuned { uint64_t rows, cols; int fuse, rpu, split, k, cpl; };
+    struct Tuned { uint64_t rows, cols; int fuse, rpu, split, k, cpl, share; };
     std::vector<Tuned> tuned_cache;
     // Tunings in progress, one per shape (each may span several gs_run calls; two grids driven
     // alternately advance independently).  `batch` / `nb`: timing windows enqueued but not read yet.
-    struct Trial { int rpu, V, k, cpl, reps; };
+    struct Trial { int rpu, V, k, cpl, reps, share; };
     struct Tuning {
         uint64_t rows = 0, cols = 0;
-        int fuse = 0, next = 0, best_rpu = 0, best_split = 0, best_k = 0, best_cpl = 0;
+        int fuse = 0, next = 0, best_rpu = 0, best_split = 0, best_k = 0, best_cpl = 0, best_share = 1;
         float best_ms = 0.f;
         Trial batch[16];
         int nb = 0;
@@ -223,12 +224,16 @@ struct gs_ctx {
         int32_t epoch = 0;
         bool pending = false;  // a launch has been enqueued since the abort word was last read
         bool disabled = false; // a launch gave up once: this context stays with the marching kernel
-        // the gs_run calls behind `pending`, in order: if a launch gave up, none of them took a step (the abort word is
-        // sticky) and they are run again with the marching kernel (resolve_window)
-        struct Run { gs_field *f[4]; uint64_t steps; int slot; };
-        std::vector<Run> runs;
+        // The launches behind `pending`, in order (planes in -> planes out, `steps` time steps, numbered `seq`).  A launch
+        // that gives up leaves its number in the abort word: the launches before it ran to their end and their results
+        // stand; that launch and every later one (they leave at once: the word is sticky) are run again with the
+        // marching kernel, from the input planes of the first of them, which no launch has written (resolve_window).
+        struct Launch { gs_field *in[2], *out[2]; int steps; int32_t seq; int passes; };
+        std::vector<Launch> launched;
+        int32_t seq = 0;
         uint64_t fallbacks = 0;
     } win;
+    int share_now = 1; // full difference sharing in force when gs_options.share_taps leaves the choice open (fast_of)
     int cu_count = 0; // compute units of the first slab's device
     int total_slabs() const { return world * (int)slabs.size(); }
     int global_index(int i) const { return rank * (int)slabs.size() + i; }
@@ -292,33 +297,42 @@ int32_t run_steps(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_fiel
 
 // Did a persistent window launch (gs_run_window_k) give up?  Its workgroups poll each other's flags with bounded
 // patience; they only run out of it when they are not all resident, i.e. when another long-running kernel holds CUs.
-// Then NONE of the launches enqueued since the last check took a step (the abort word is sticky, the input planes are
-// only read): they are run again, in order, with the marching kernel, their results put where gs_run said they would be,
-// and the context stays with the marching kernel.  Called by everything that waits for or reads results.
+// The abort word then holds the number of the launch that gave up.  Every launch before it ran to its end; that launch
+// may have stored some of its windows (workgroups far from the stalled one finish long before the patience runs out),
+// but only into its OUTPUT planes, and the launches behind it left at once.  So it and the later ones are run again, in
+// order, with the marching kernel -- each from its own input planes, which are intact -- their results put where gs_run
+// said they would be, and the context stays with the marching kernel.  Called by everything that waits for or reads
+// results.
 int32_t resolve_window(gs_ctx *ctx)
 {
     gs_ctx::WindowRt &w = ctx->win;
     if (!w.pending) return GS_OK;
-    w.pending = false;
     SlabRt &sl = ctx->slabs[0];
     GS_HIP(hipSetDevice(sl.device));
     GS_HIP(hipStreamSynchronize(sl.compute));
     int32_t gave_up = 0;
     GS_HIP(hipMemcpy(&gave_up, w.words + kWindowMaxTiles, sizeof gave_up, hipMemcpyDeviceToHost));
-    std::vector<gs_ctx::WindowRt::Run> runs;
-    runs.swap(w.runs);
+    // (only now: a failure above leaves the launches on record for the next call)
+    w.pending = false;
+    std::vector<gs_ctx::WindowRt::Launch> launched;
+    launched.swap(w.launched);
     if (!gave_up) return GS_OK;
     GS_HIP(hipMemsetAsync(w.words, 0, (kWindowMaxTiles + 1) * sizeof(int32_t), sl.compute));
     w.epoch = 0;
     w.disabled = true;
     w.fallbacks++;
-    for (const auto &run : runs) {
+    for (const auto &l : launched) {
+        if (l.seq < gave_up) continue; // ran to its end
+        // what the launch was counted as when it was enqueued (gs_ctx_stats): the replay counts its own passes
+        ctx->launches -= 1;
+        ctx->passes -= (uint64_t)l.passes;
+        ctx->steps_done -= (uint64_t)l.steps;
         int32_t slot = 0;
-        GS_TRY(run_steps(ctx, run.f[0], run.f[1], run.f[2], run.f[3], run.steps, &slot, false));
-        if (slot != run.slot) { // the marching kernel ends in the slot of the steps' parity: move the planes over
+        GS_TRY(run_steps(ctx, l.in[0], l.in[1], l.out[0], l.out[1], (uint64_t)l.steps, &slot, false));
+        if (slot != 1) { // the marching kernel ends in the slot of the steps' parity: move the planes over
             for (int sp = 0; sp < 2; ++sp) {
-                const gs_field *src = run.f[2 * slot + sp];
-                gs_field *dst = run.f[2 * run.slot + sp];
+                const gs_field *src = l.in[sp];
+                gs_field *dst = l.out[sp];
                 const size_t bytes = (size_t)src->s[0].rows * (size_t)src->pitch * sizeof(float);
                 GS_HIP(hipMemcpyAsync(dst->s[0].row0, src->s[0].row0, bytes, hipMemcpyDeviceToDevice, sl.compute));
                 dst->ghost_depth = src->ghost_depth;
@@ -439,7 +453,12 @@ long tb_strips(int32_t cols, int fuse, int cpl)
     return (cols + w - 1) / w;
 }
 
-// GsStepArgs::fast for this context's parameters: bit 0 = the four side weights are 0.5, bit 1 = dt == 1.
+// Is full difference sharing in force (when the parameters allow it)?  Pinned by gs_options.share_taps, else what the
+// on-line tuner last chose or is trying (gs_ctx::share_now), else on.
+bool share_on(const gs_ctx *ctx) { return ctx->o.share_taps == 1 || (ctx->o.share_taps == 0 && ctx->share_now != 0); }
+
+// GsStepArgs::fast for this context's parameters: bit 0 = the four side weights are 0.5, bit 1 = dt == 1, bit 2 = both
+// and the diagonal weights are pairwise equal and the context wants full difference sharing.
 int fast_of(const gs_ctx *ctx)
 {
     int fast = 0;
@@ -447,6 +466,8 @@ int fast_of(const gs_ctx *ctx)
         const float(*w)[3] = ctx->p.w;
         if (w[0][1] == 0.5f && w[1][0] == 0.5f && w[1][2] == 0.5f && w[2][1] == 0.5f) fast |= 1;
         if (ctx->p.dt == 1.0f) fast |= 2;
+        // full difference sharing (cells_vshare): the diagonal taps of a row pair are each other's negatives
+        if (fast == 3 && w[0][0] == w[2][2] && w[0][2] == w[2][0] && ctx->o.share_taps != 2 && share_on(ctx)) fast |= 4;
     }
     return fast;
 }
@@ -682,7 +703,8 @@ std::vector<GsWindowDesc> plan_windows(int cu_count, bool zero_halo, bool cheap,
                                        int *rpw_out, int *k_out);
 std::vector<GsWindowDesc> plan_windows(const gs_ctx *ctx, uint64_t rows, uint64_t cols, int want_rpw, int want_k, int *rpw_out, int *k_out)
 {
-    const bool cheap = fast_of(ctx) & 1 && ctx->o.math == GS_MATH_STRICT && gs_env_int("GS_HIP_EDGE_KINDS", 1, 0, 1) != 0;
+    // (the launcher builds the cheap kinds of edge window for the default side weights AND dt == 1 only: gs_launch_window)
+    const bool cheap = (fast_of(ctx) & 3) == 3 && ctx->o.math == GS_MATH_STRICT && gs_env_int("GS_HIP_EDGE_KINDS", 1, 0, 1) != 0;
     return plan_windows(ctx->cu_count, ctx->o.boundary == GS_BOUNDARY_ZERO_HALO, cheap, rows, cols, want_rpw, want_k, rpw_out, k_out);
 }
 // (the geometry alone: no device needed -- tests/test_capi_cpu.py checks it through gs_debug_window_plan)
@@ -1051,6 +1073,8 @@ void recall_tuned(gs_ctx *ctx, const gs_field *f, int fuse)
         if (same_slab_shape(ctx, t.rows, t.cols, rows, f->cols) && t.fuse == fuse) {
             ctx->tuned_rows = t.rows; ctx->tuned_cols = t.cols; ctx->tuned_fuse = t.fuse;
             ctx->tuned_rpu = t.rpu; ctx->tuned_split = t.split; ctx->tuned_k = t.k; ctx->tuned_cpl = t.cpl;
+            ctx->tuned_share = t.share;
+            ctx->share_now = t.share;
             return;
         }
 }
@@ -1075,9 +1099,10 @@ void remember_tuned(gs_ctx *ctx, const gs_ctx::Tuned &t)
 //   redundant rows per unit can cost more than the extra passes; phase D (columns per lane not
 //   pinned): 1 and 4 columns per lane -- more, narrower waves for small grids; fewer, wider ones
 //   with 16-byte accesses -- with a few unit heights each (large grids skip the candidates that
-//   would only multiply tiny units).  A-C run with the untuned layout (pick_cols_per_lane).  Every list
-//   of heights is a fixed ladder plus the heights that make a launch a whole number of rounds of the
-//   chip's wave slots (fit_heights).
+//   would only multiply tiny units); phase E (gs_options.share_taps = 0 and the parameters allow it): the
+//   chosen configuration without full difference sharing -- A-D run with it.  A-C run with the untuned layout
+//   (pick_cols_per_lane).  Every list of heights is a fixed ladder plus the heights that make a launch a whole
+//   number of rounds of the chip's wave slots (fit_heights).
 int32_t tune_online(Run &r, int fuse)
 {
     gs_ctx *ctx = r.ctx;
@@ -1136,6 +1161,13 @@ int32_t tune_online(Run &r, int fuse)
         for (int c : cpls)
             for (int h : heights(candn0, (int)(sizeof candn0 / sizeof candn0[0]), fuse, c)) { d_cpl.push_back(c); d_rpu.push_back(h); }
     const int nn = (int)d_cpl.size();
+    // phase E: one candidate, where the choice is open and a variant with full difference sharing exists at all
+    const bool share_open = ctx->o.share_taps == 0 && ctx->o.math == GS_MATH_STRICT && [&] {
+        gs_ctx probe = *ctx; // (fast_of reads options and parameters only)
+        probe.o.share_taps = 1;
+        return (fast_of(&probe) & 4) != 0;
+    }();
+    const int ne = share_open ? 1 : 0;
     // timed passes per candidate: short passes need more of them for a stable comparison
     const int reps = cells >= (1ull << 27) ? 2 : (cells >= (1ull << 24) ? 6 : 8);
     constexpr int kMaxBatch = (int)(sizeof(gs_ctx::Tuning::batch) / sizeof(gs_ctx::Trial));
@@ -1194,9 +1226,10 @@ int32_t tune_online(Run &r, int fuse)
             const float ms = (w0 < w1 ? w0 : w1) / (float)(t.reps * t.k); // per time step
             static const bool trace = gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1) != 0;
             if (trace)
-                std::fprintf(stderr, "gs_hip tuner %llux%llu: unit %3d rows, %d band(s), %d steps/pass, %d col/lane: "
+                std::fprintf(stderr, "gs_hip tuner %llux%llu: unit %3d rows, %d band(s), %d steps/pass, %d col/lane%s: "
                                      "%.4f ms/step (windows %.3f %.3f ms)\n",
-                             (unsigned long long)f->rows, (unsigned long long)f->cols, t.rpu, t.V, t.k, t.cpl, ms, w0, w1);
+                             (unsigned long long)f->rows, (unsigned long long)f->cols, t.rpu, t.V, t.k, t.cpl,
+                             t.share ? "" : ", taps not shared", ms, w0, w1);
             // prefer the incumbent unless the newcomer is clearly faster: by 1 %, or by 3 % when it
             // fuses fewer steps (more HBM traffic, slower remainder passes: a tie is not worth it)
             // ... and a taller unit of the same layout wins a near-tie: it recomputes fewer rows, and on large
@@ -1215,6 +1248,7 @@ int32_t tune_online(Run &r, int fuse)
                 tu->best_split = t.V;
                 tu->best_k = t.k;
                 tu->best_cpl = t.cpl;
+                tu->best_share = t.share;
             }
         }
         tu->nb = 0;
@@ -1226,8 +1260,9 @@ int32_t tune_online(Run &r, int fuse)
         if (q != hipSuccess) return fail(GS_ERR_HIP, "a tuning pass failed: %s", hipGetErrorString(q));
         GS_TRY(evaluate());
     }
-    const int phase_end[4] = {ncand, ncand + nalt, ncand + nalt + nk, ncand + nalt + nk + nn};
-    int warm_cpl = 0, warm_k = 0; // kernel of the newest pass enqueued by this call
+    const int phase_end[5] = {ncand, ncand + nalt, ncand + nalt + nk, ncand + nalt + nk + nn, ncand + nalt + nk + nn + ne};
+    constexpr int kLast = 4;
+    int warm_cpl = 0, warm_k = 0, warm_share = 1; // kernel of the newest pass enqueued by this call
     bool out_of_steps = false;
     // The first milliseconds of work on an idle chip run slow (the first windows of a 16384^2 context measured
     // 0.32 ms per step against 0.255 a few passes later: clocks, first touches), which used to cost whichever
@@ -1247,13 +1282,13 @@ int32_t tune_online(Run &r, int fuse)
         warm_cpl = base_cpl;
         warm_k = fuse;
     }
-    while (tu->next < phase_end[3] && !out_of_steps) {
+    while (tu->next < phase_end[kLast] && !out_of_steps) {
         int phase = 0;
         while (tu->next >= phase_end[phase]) ++phase;
         int nb = 0;
         int32_t st = GS_OK;
         for (; tu->next < phase_end[phase] && nb < kMaxBatch && st == GS_OK; ++tu->next) {
-            gs_ctx::Trial t{0, V0, fuse, base_cpl, reps};
+            gs_ctx::Trial t{0, V0, fuse, base_cpl, reps, 1};
             const int i = tu->next - (phase ? phase_end[phase - 1] : 0);
             if (phase == 0) {
                 t.rpu = cand[i];
@@ -1265,6 +1300,14 @@ int32_t tune_online(Run &r, int fuse)
                 t.V = tu->best_split;
                 t.k = altk[i];
                 if (t.rpu == 0 || t.k >= fuse) continue;
+            } else if (phase == 4) { // what phases A-D chose, without full difference sharing
+                t.rpu = tu->best_rpu;
+                t.V = tu->best_split;
+                t.k = tu->best_k;
+                t.cpl = tu->best_cpl;
+                t.share = 0;
+                // (only 2 columns per lane and 2 to 4 fused steps have a sharing variant: elsewhere nothing to compare)
+                if (t.rpu == 0 || t.cpl != 2 || t.k < 2) continue;
             } else { // phase 3 (phase 1 has no candidates)
                 t.cpl = d_cpl[i];
                 t.rpu = d_rpu[i];
@@ -1286,10 +1329,12 @@ int32_t tune_online(Run &r, int fuse)
             }
             ctx->o.rows_per_block = t.rpu;
             ctx->o.cols_per_lane = t.cpl;
-            if (t.cpl != warm_cpl || t.k != warm_k) { // another kernel: one untimed pass first
+            ctx->share_now = t.share;
+            if (t.cpl != warm_cpl || t.k != warm_k || t.share != warm_share) { // another kernel: one untimed pass first
                 st = r.advance(t.V, t.k);
                 warm_cpl = t.cpl;
                 warm_k = t.k;
+                warm_share = t.share;
             }
             for (int w = 0; w < 3 && st == GS_OK; ++w) {
                 st = mark(tu->events[3 * nb + w]);
@@ -1297,6 +1342,7 @@ int32_t tune_online(Run &r, int fuse)
             }
             ctx->o.rows_per_block = 0;
             ctx->o.cols_per_lane = user_cpl;
+            ctx->share_now = 1;
             tu->batch[nb++] = t;
         }
         if (st != GS_OK) return st;
@@ -1307,13 +1353,14 @@ int32_t tune_online(Run &r, int fuse)
             return fail(GS_ERR_HIP, "waiting for the tuning passes failed");
         GS_TRY(evaluate());
     }
-    if (tu->next >= phase_end[3] && tu->nb == 0 && tu->best_rpu > 0) {
-        const gs_ctx::Tuned done{f->rows, f->cols, fuse, tu->best_rpu, tu->best_split, tu->best_k, tu->best_cpl};
+    if (tu->next >= phase_end[kLast] && tu->nb == 0 && tu->best_rpu > 0) {
+        const gs_ctx::Tuned done{f->rows, f->cols, fuse, tu->best_rpu, tu->best_split, tu->best_k, tu->best_cpl, tu->best_share};
         remember_tuned(ctx, done);
         recall_tuned(ctx, f, fuse);
         if (gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1))
-            std::fprintf(stderr, "gs_hip tuner %llux%llu: chose unit %d rows, %d steps/pass, %d col/lane\n",
-                         (unsigned long long)f->rows, (unsigned long long)f->cols, done.rpu, done.k, done.cpl);
+            std::fprintf(stderr, "gs_hip tuner %llux%llu: chose unit %d rows, %d steps/pass, %d col/lane, taps %s\n",
+                         (unsigned long long)f->rows, (unsigned long long)f->cols, done.rpu, done.k, done.cpl,
+                         done.share ? "shared" : "not shared");
         for (auto e : tu->events)
             if (e) (void)hipEventDestroy(e);
         ctx->tunings.erase(ctx->tunings.begin() + (tu - ctx->tunings.data()));
@@ -1476,6 +1523,32 @@ int32_t gs_rccl_selftest(int32_t device, uint64_t floats)
     R->CommDestroy(comm);
     (void)hipGetLastError();
     return st;
+}
+
+// Which HIP runtime and which RCCL this process's libgs_hip.so is bound to (dladdr of an entry point of each), with
+// their versions.  A process that imported torch first resolves libamdhip64.so.7 and librccl.so.1 by SONAME to the
+// copies torch bundles -- the runtime that owns the device pointers the planes live at is then the one RCCL moves them
+// with; a torch-free process gets /opt/rocm's.
+int32_t gs_runtime_info(int32_t load_rccl, char *out, size_t cap)
+{
+    if (!out || cap == 0) return fail(GS_ERR_INVALID, "null output");
+    Dl_info hip_so{}, rccl_so{};
+    int hip_version = 0, rccl_version = 0;
+    (void)dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &hip_so);
+    if (hipRuntimeGetVersion(&hip_version) != hipSuccess) { hip_version = 0; (void)hipGetLastError(); }
+    Rccl *R = load_rccl ? rccl() : nullptr;
+    if (R) {
+        (void)dladdr(reinterpret_cast<const void *>(R->Send), &rccl_so);
+        auto get_version = reinterpret_cast<ncclResult_t (*)(int *)>(dlsym(R->handle, "ncclGetVersion"));
+        if (get_version) (void)get_version(&rccl_version);
+    }
+    const char *user = std::getenv("GS_RCCL_LIBRARY");
+    std::snprintf(out, cap, "{\"hip\": \"%s\", \"hip_runtime_version\": %d, \"rccl\": %s%s%s, \"rccl_version\": %d, "
+                            "\"rccl_named_by_GS_RCCL_LIBRARY\": %s}",
+                  hip_so.dli_fname ? hip_so.dli_fname : "", hip_version, rccl_so.dli_fname ? "\"" : "",
+                  rccl_so.dli_fname ? rccl_so.dli_fname : "null", rccl_so.dli_fname ? "\"" : "", rccl_version,
+                  user && *user ? "true" : "false");
+    return GS_OK;
 }
 
 int32_t gs_ctx_destroy(gs_ctx *ctx)
@@ -1875,7 +1948,7 @@ int32_t run_window(gs_ctx *ctx, Run &r, uint64_t steps, bool forced, int32_t *la
     // (kernel = auto only takes grids that 80-row windows cover: with 96-row windows -- 1200 x 2000: 450 k against the
     // marching kernel's 452 k -- nothing is gained, profiles/r04_window_kernel.md)
     const int want_rpw = forced ? (ctx->o.rows_per_block > 0 ? ctx->o.rows_per_block / 16 : 0) : 5;
-    const int key = ((ctx->o.boundary * 2 + (ctx->o.math == GS_MATH_FUSED)) * 4 + fast_of(ctx)) * 64 + want_rpw * 8 + ctx->o.fuse_steps;
+    const int key = ((ctx->o.boundary * 2 + (ctx->o.math == GS_MATH_FUSED)) * 4 + (fast_of(ctx) & 3)) * 64 + want_rpw * 8 + ctx->o.fuse_steps;
     if (w.plan_rows != u0->rows || w.plan_cols != u0->cols || w.plan_key != key) {
         int rpw = 0, wk = 0;
         const std::vector<GsWindowDesc> plan = plan_windows(ctx, u0->rows, u0->cols, want_rpw, ctx->o.fuse_steps, &rpw, &wk);
@@ -1900,6 +1973,13 @@ int32_t run_window(gs_ctx *ctx, Run &r, uint64_t steps, bool forced, int32_t *la
     GS_TRY(join_bands(ctx, sl.compute));
     ctx->bands_active = false;
     GS_TRY(ensure_window_rt(ctx, u0));
+    if (w.seq >= 0x7ffffff0) { // launch numbers only order the launches pending at one time: start over behind them
+        GS_TRY(sync_all(ctx));
+        w.seq = 0;
+    }
+    // the waits above may have found that an earlier launch gave up: the context then stays with the marching kernel
+    if (w.disabled) return forced ? fail(GS_ERR_UNSUPPORTED, "the persistent window kernel gave up on this context before (another "
+                                                             "kernel held compute units): it stays with GS_KERNEL_TB") : GS_OK;
     uint64_t left = steps;
     int slot = 0;
     while (left > 0) { // (the step count is an int in the kernel; a launch goes in-planes -> out-planes)
@@ -1917,6 +1997,7 @@ int32_t run_window(gs_ctx *ctx, Run &r, uint64_t steps, bool forced, int32_t *la
         x.k = w.plan_k;
         x.epoch = w.epoch;
         x.patience = gs_env_int("GS_HIP_WINDOW_PATIENCE", 1 << 21, 1, 1 << 30); // polls of ~1 us each: ~2 s
+        x.seq = ++w.seq;
         const char *name = nullptr;
         const hipError_t e = ctx->o.math == GS_MATH_FUSED ? gs_launch_window_fused(a, x, w.plan_rpw, sl.compute, &name)
                                                            : gs_launch_window_strict(a, x, w.plan_rpw, sl.compute, &name);
@@ -1924,6 +2005,7 @@ int32_t run_window(gs_ctx *ctx, Run &r, uint64_t steps, bool forced, int32_t *la
         const int supers = (n + w.plan_k - 1) / w.plan_k;
         w.epoch += supers;
         w.pending = true;
+        w.launched.push_back(gs_ctx::WindowRt::Launch{{r.u[slot], r.v[slot]}, {r.u[1 - slot], r.v[1 - slot]}, n, x.seq, supers});
         ctx->last_kernel = name;
         ctx->launches++;
         ctx->passes += (uint64_t)supers;
@@ -1932,7 +2014,6 @@ int32_t run_window(gs_ctx *ctx, Run &r, uint64_t steps, bool forced, int32_t *la
         slot ^= 1;
         left -= (uint64_t)n;
     }
-    w.runs.push_back(gs_ctx::WindowRt::Run{{r.u[0], r.v[0], r.u[1], r.v[1]}, steps, slot});
     if (result_slot) *result_slot = slot;
     *launched = 1;
     return GS_OK;
@@ -2221,30 +2302,31 @@ int32_t gs_timer_stop(gs_ctx *ctx, float *elapsed_ms)
 }
 
 int32_t gs_ctx_get_tuned(const gs_ctx *ctx, uint64_t slab_rows, uint64_t cols, int32_t *rows_per_block,
-                         int32_t *fuse_steps, int32_t *cols_per_lane)
+                         int32_t *fuse_steps, int32_t *cols_per_lane, int32_t *share_taps)
 {
     if (!ctx) return fail(GS_ERR_INVALID, "null context");
-    int rpu = 0, k = 0, cpl = 0;
+    int rpu = 0, k = 0, cpl = 0, share = 0;
     for (const gs_ctx::Tuned &t : ctx->tuned_cache)
-        if (t.rows == slab_rows && t.cols == cols) { rpu = t.rpu; k = t.k; cpl = t.cpl; } // the newest entry wins
+        if (t.rows == slab_rows && t.cols == cols) { rpu = t.rpu; k = t.k; cpl = t.cpl; share = t.share ? 1 : 2; } // the newest entry wins
     if (rows_per_block) *rows_per_block = rpu;
     if (fuse_steps) *fuse_steps = k;
     if (cols_per_lane) *cols_per_lane = cpl;
+    if (share_taps) *share_taps = share;
     return GS_OK;
 }
 
 int32_t gs_ctx_set_tuned(gs_ctx *ctx, uint64_t slab_rows, uint64_t cols, int32_t rows_per_block, int32_t fuse_steps,
-                         int32_t cols_per_lane)
+                         int32_t cols_per_lane, int32_t share_taps)
 {
     if (!ctx) return fail(GS_ERR_INVALID, "null context");
     if (rows_per_block < 1 || fuse_steps < 1 || fuse_steps > kGhostRows ||
-        (cols_per_lane != 1 && cols_per_lane != 2 && cols_per_lane != 4))
-        return fail(GS_ERR_INVALID, "bad configuration (unit %d rows, %d steps per pass, %d columns per lane)",
-                    rows_per_block, fuse_steps, cols_per_lane);
+        (cols_per_lane != 1 && cols_per_lane != 2 && cols_per_lane != 4) || share_taps < 0 || share_taps > 2)
+        return fail(GS_ERR_INVALID, "bad configuration (unit %d rows, %d steps per pass, %d columns per lane, share_taps %d)",
+                    rows_per_block, fuse_steps, cols_per_lane, share_taps);
     // keyed like gs_run's own choices: by the steps per pass it was asked to fuse
     const int fuse = ctx->o.fuse_steps > 0 ? (ctx->o.fuse_steps > kGhostRows ? kGhostRows : ctx->o.fuse_steps) : kGhostRows;
     if (fuse_steps > fuse) return fail(GS_ERR_INVALID, "%d steps per pass exceed fuse_steps = %d", fuse_steps, fuse);
-    remember_tuned(ctx, gs_ctx::Tuned{slab_rows, cols, fuse, rows_per_block, 1, fuse_steps, cols_per_lane});
+    remember_tuned(ctx, gs_ctx::Tuned{slab_rows, cols, fuse, rows_per_block, 1, fuse_steps, cols_per_lane, share_taps == 2 ? 0 : 1});
     return GS_OK;
 }
 
@@ -2283,6 +2365,7 @@ int32_t gs_ctx_stats(gs_ctx *ctx, gs_stats *out)
     out->steps = ctx->steps_done;
     out->launches = ctx->launches;
     out->ghost_refreshes = ctx->ghost_refreshes;
+    out->window_fallbacks = ctx->win.fallbacks;
     // timed passes (slab chains only): the slowest local slab's sums
     for (auto &sl : ctx->slabs) {
         if (sl.timed == 0) continue;

@@ -91,13 +91,15 @@ struct GsWindowDesc {
 struct GsWindowArgs {
     float *xu[2], *xv[2];      // exchange planes: local row 0, column 0; the field planes' pitch, at least the grid's rows
     int32_t *flags;            // one per workgroup; a workgroup that has finished exchange e holds epoch + e + 1
-    int32_t *abort;            // sticky: a poll ran out of patience (workgroups not co-resident); every workgroup then leaves
+    int32_t *abort;            // sticky, 0 or the `seq` of the launch in which a poll ran out of patience (workgroups not
+                               // co-resident): every workgroup of that launch and of every later one then leaves
     const GsWindowDesc *desc;  // one per workgroup (device memory)
     int32_t n_windows;
     int32_t steps;             // time steps of this launch (>= 1)
     int32_t k;                 // steps per exchange: even, 2 ... 8
     int32_t epoch;             // flags left by earlier launches are <= epoch
     int32_t patience;          // polls before a workgroup gives up
+    int32_t seq;               // this launch's number on its context (>= 1): what a workgroup that gives up leaves in *abort
 };
 
 // Launchers, one set per arithmetic flavour (see gs_math in include/gs_hip.h).  Each

@@ -97,6 +97,15 @@ __device__ __forceinline__ float half_diff(float s, float c)
 }
 #define GS_TAP_HALF(acc, s, c) (acc) = (acc) + half_diff((s), (c))
 
+// 0.0f - x as ONE instruction the compiler cannot touch: it folds `(0.0f - x) - y` into `(-x) - y` even without
+// fast-math flags, which is -0 instead of +0 for x == y == +0 (the accumulator of cells_vshare must never be -0).
+__device__ __forceinline__ float zero_minus(float x)
+{
+    float r;
+    asm("v_sub_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // m ? a : b for a per-lane all-ones / all-zeros mask: one v_bfi_b32, a full-rate VALU op
 // (v_cndmask_b32 measured ~8x slower on gfx950: tools/ubench/valu_rate.hip).
 __device__ __forceinline__ float blend(uint32_t m, float a, float b)
@@ -703,6 +712,56 @@ __device__ __forceinline__ void cells_interior(const GsStepArgs &a, const RowT<C
     }
 }
 
+// Full difference sharing (FAST & 4: side weights 0.5 AND w[0][0] == w[2][2], w[0][2] == w[2][0]; strict build).
+// The three taps a cell takes from the row BELOW it are, negated, the three taps the cells of that row take from the
+// row above them:  S(r, c) = (x[r+1][c] - x[r][c]) / 2 = -N(r+1, c),  SE(r, c) = w22 (x[r+1][c+1] - x[r][c]) =
+// -NW(r+1, c+1) when w00 == w22,  SW(r, c) = w20 (x[r+1][c-1] - x[r][c]) = -NE(r+1, c-1) when w02 == w20 -- bit for
+// bit: IEEE subtraction and multiplication are odd functions of their operands (round-to-nearest is symmetric), up to
+// the sign of an exact or flushed zero, which an accumulator that is never -0 cannot see (the argument of half_diff
+// and of the E / W pair in cells_interior).  So a march keeps, per level, the S / SE / SW taps of the row it has just
+// finished (TapCarry) and the next row's N / NW / NE taps are one subtraction each, in the reference's order:
+//   acc = 0 - SE'(k-1);  acc -= S'(k);  acc -= SW'(k+1);  acc -= E(k-1);  acc += E(k);  acc += SW(k);  acc += S(k);  acc += SE(k)
+// ("0.0f -" is kept like the fold's "0.0f +": it maps a -0 to +0.)  The row above is no longer needed at all: a level
+// is two widened rows and a carry instead of three rows.  Per lane-row and species 14 CPL + 5 arithmetic instructions
+// instead of 20 CPL - (CPL - 1): 46 per cell-step instead of 52 at 2 columns per lane (the SE tap of the column left of
+// the lane's and the SW tap of the column right of it are computed in-lane from the widened rows, no extra exchange).
+template <int CPL>
+struct TapCarry { // of the row a level has just finished, [i] for i = 0 .. CPL - 1: what own cell i + 1 of the next row needs
+    float s_u[CPL], s_v[CPL];   // S tap of cell i + 1  (-> N tap of cell i + 1)
+    float se_u[CPL], se_v[CPL]; // SE tap of cell i     (-> NW tap of cell i + 1; cell 0 = the column left of the lane's)
+    float sw_u[CPL], sw_v[CPL]; // SW tap of cell i + 2 (-> NE tap of cell i + 1; cell CPL + 1 = the column right of the lane's)
+};
+// One row of a level: z = the row, p = the row below it, c = the taps carried from the row above, replaced in place by
+// this row's (every old value is read before the new one of its slot exists, but for SE, which waits one cell).
+template <int FAST, int CPL>
+__device__ __forceinline__ void cells_vshare(const GsStepArgs &a, const RowT<CPL> &z, const RowT<CPL> &p, TapCarry<CPL> &c,
+                                             float (&nu)[CPL], float (&nv)[CPL])
+{
+    static_assert((FAST & 5) == 5 && !GS_MATH_FUSED, "full difference sharing is a specialisation of the strict build");
+    float eu = half_diff(z.u[1], z.u[0]), ev = half_diff(z.v[1], z.v[0]);                       // E tap of cell 0
+    float seu = a.w[2][2] * (p.u[1] - z.u[0]), sev = a.w[2][2] * (p.v[1] - z.v[0]);             // SE tap of cell 0
+#pragma unroll
+    for (int k = 1; k <= CPL; ++k) {
+        const float u = z.u[k], v = z.v[k];
+        float acc_u = zero_minus(c.se_u[k - 1]), acc_v = zero_minus(c.se_v[k - 1]);             // NW
+        c.se_u[k - 1] = seu;                                  c.se_v[k - 1] = sev;
+        acc_u = acc_u - c.s_u[k - 1];                         acc_v = acc_v - c.s_v[k - 1];     // N
+        acc_u = acc_u - c.sw_u[k - 1];                        acc_v = acc_v - c.sw_v[k - 1];    // NE
+        acc_u = acc_u - eu;                                   acc_v = acc_v - ev;               // W
+        eu = half_diff(z.u[k + 1], u);                        ev = half_diff(z.v[k + 1], v);
+        acc_u = acc_u + eu;                                   acc_v = acc_v + ev;               // E
+        const float swu = a.w[2][0] * (p.u[k - 1] - u), swv = a.w[2][0] * (p.v[k - 1] - v);
+        if (k >= 2) { c.sw_u[k - 2] = swu; c.sw_v[k - 2] = swv; }
+        acc_u = acc_u + swu;                                  acc_v = acc_v + swv;              // SW
+        c.s_u[k - 1] = half_diff(p.u[k], u);                  c.s_v[k - 1] = half_diff(p.v[k], v);
+        acc_u = acc_u + c.s_u[k - 1];                         acc_v = acc_v + c.s_v[k - 1];     // S
+        seu = a.w[2][2] * (p.u[k + 1] - u);                   sev = a.w[2][2] * (p.v[k + 1] - v);
+        acc_u = acc_u + seu;                                  acc_v = acc_v + sev;              // SE
+        react<(FAST & 2) != 0>(a, u, v, acc_u, acc_v, nu[k - 1], nv[k - 1]);
+    }
+    c.sw_u[CPL - 1] = a.w[2][0] * (p.u[CPL] - z.u[CPL + 1]);  c.sw_v[CPL - 1] = a.w[2][0] * (p.v[CPL] - z.v[CPL + 1]); // SW tap of cell CPL + 1
+}
+
 // Buffer-instruction forms of the plane accesses: address = 128-bit resource in SGPRs (base pointer of
 // the unit's first row) + per-lane byte offset (one VGPR for the whole march) + scalar byte offset of
 // the row: no 64-bit per-lane addresses to keep or to recompute per row.  The resource is raw (stride 0)
@@ -758,7 +817,21 @@ struct FairBoard {
     int *progress; // LDS: words 0..15 progress per wave (0 ... 256, INT_MAX once finished), 16..31 the SIMD it runs on
     int simd;      // this wave's SIMD (HW_REG_HW_ID bits 5:4)
     int wave;
+    float *halo;   // LDS: this wave's halo board (tb_halo_floats floats) in the variants with full difference sharing
 };
+
+// Halo board of the march with full difference sharing (2 columns per lane).  The columns next to a lane's two are
+// needed in TWO consecutive ticks there (a row is the lower row of one tick's differences and the upper row of the
+// next's); kept in registers they cost 4 per level on top of the carried taps, and the march needs 148: three waves per
+// SIMD, which issue at 0.80-0.85 of the rate of four (profiles/r05_energy.md).  So a wave hands its rows' columns
+// to its neighbouring lanes through LDS MEMORY instead of the crossbar: every new row is written once (two
+// ds_write2_b32) and its halo columns are read in the tick it appears and again in the next (one ds_read2_b32 per side
+// and tick): the same load on the LDS pipe as four ds_bpermute_b32 and 16 registers less.  Layout per level and slot
+// (tick & 1): four arrays of 66 floats -- U and V of the lanes' first and of their second column, element 1 + lane --
+// so that the left halo (second column of lane - 1) and the right halo (first column of lane + 1) are conflict-free
+// 4-byte accesses; elements 0 and 65 are only read by the sacrificial lanes (zeroed once).
+constexpr int kHaloArray = 66, kHaloRow = 4 * kHaloArray;
+__host__ __device__ constexpr int tb_halo_floats(int k) { return k * 2 * kHaloRow; }
 
 // EDGE: 0 = interior unit; 1 = general path; 2 / 3 = strip on the grid's left / right edge that touches neither its
 // top nor its bottom (cell<2> / cell<3>); 4 = interior strip that touches the top or bottom edge: interior code for
@@ -811,13 +884,116 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
         ra[k] = ((EDGE == 1 || EDGE == 3) && (c + k + 1 >= a.cols)) ? 0xffffffffu : 0u;
     }
 
-    RowT<CPL> w[K][3]; // w[j][slot]: level-j rows, newest in slot (tick % 3)
     RowQ<CPL> q[3];    // prefetch queue of level-0 rows, 3 ticks deep
     const int first = ur0 - K; // level-0 row of tick 0
     const int nticks = (ur1 - ur0) + 2 * K;
     const int fair_scale = FAIR ? (256 << 16) / nticks : 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) q[i] = fetch(first + i);
+    // The in-step form's progress board (FairBoard): publish this wave's progress, steer its priority.
+    auto fair_tick = [&](int tick) {
+        if constexpr (FAIR) {
+            const int mine = tick * fair_scale >> 16;       // 0 ... 256
+            if (lane == 0) fb.progress[fb.wave] = mine;
+            if (mine >= a.fair_from) { // (before: free-running, out of phase as the arbitration leaves them)
+                const int theirs = fb.progress[lane & 15], their_simd = fb.progress[16 + (lane & 15)];
+                const unsigned long long behind = __builtin_amdgcn_ballot_w64(their_simd == fb.simd && theirs < mine);
+                if (behind) __builtin_amdgcn_s_setprio(0);
+                else __builtin_amdgcn_s_setprio(3);
+            }
+        }
+    };
+
+    // Full difference sharing (cells_vshare) on interior units of the variant built for it.  A level keeps its two
+    // newest rows (slot = tick & 1) and the taps carried from the row before them, updated in place, instead of a
+    // window of three rows.  Level j's row l0 - j is computed in the tick in which row l0 - j + 1 of level j - 1
+    // appears, from tick 2 j - 1 on -- one row more at the top than the three-row form computes: the first row a level
+    // needs takes its N / NW / NE taps from the tick before it; what that extra row itself comes to is never used
+    // and never stored -- and every level runs until the last tick.  So the first 2 K ticks are peeled with the levels
+    // in use known at compile time, and the loop behind them (6 ticks per trip: the row slots' 2 x the queue's 3) has no
+    // test but "ticks left": every slot index is static, nothing is copied from register to register.
+    constexpr bool VS = EDGE == 0 && (FAST & 5) == 5 && !GS_MATH_FUSED && CPL == 2;
+    if constexpr (VS) {
+        RowQ<CPL> R[K][2]; // own columns of the two newest rows of level j
+        TapCarry<CPL> C[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) { R[j][sl].u[e] = 0.f; R[j][sl].v[e] = 0.f; }
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                C[j].s_u[e] = 0.f; C[j].s_v[e] = 0.f; C[j].se_u[e] = 0.f; C[j].se_v[e] = 0.f; C[j].sw_u[e] = 0.f; C[j].sw_v[e] = 0.f;
+            }
+        }
+        float *const mine = fb.halo + 1 + lane; // this lane's element of the first array of (level 0, slot 0)
+        if (lane < 2) // elements 0 and 65 of every array: read by the sacrificial lanes only
+#pragma unroll
+            for (int i = 0; i < K * 2 * 4; ++i) fb.halo[i * kHaloArray + lane * (kHaloArray - 1)] = 0.0f;
+        // a new row of level j: its columns go to the board, for the neighbouring lanes
+        auto put = [&](int j, int slot, const RowQ<CPL> &r) {
+            float *b = mine + (j * 2 + slot) * kHaloRow;
+            b[0] = r.u[0]; b[kHaloArray] = r.v[0]; b[2 * kHaloArray] = r.u[1]; b[3 * kHaloArray] = r.v[1];
+            // The elements a lane reads back are written by its NEIGHBOURS, in the same two instructions: to the
+            // compiler, which sees one lane, they are unrelated to the lane's own stores and could be read first.  The
+            // LDS executes a wave's instructions in order; the fence pair keeps the compiler from moving the reads up.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        // the row of (level j, slot) with the columns next to this lane's
+        auto widened = [&](int j, int slot) {
+            const float *b = mine + (j * 2 + slot) * kHaloRow;
+            RowT<CPL> w;
+            w.u[0] = b[2 * kHaloArray - 1]; w.v[0] = b[3 * kHaloArray - 1]; // second column of lane - 1
+            w.u[3] = b[1];                  w.v[3] = b[kHaloArray + 1];     // first column of lane + 1
+            w.u[1] = R[j][slot].u[0]; w.u[2] = R[j][slot].u[1]; w.v[1] = R[j][slot].v[0]; w.v[2] = R[j][slot].v[1];
+            return w;
+        };
+        // one tick; `par` = tick & 1, `qs` = tick % 3 and `levels` (levels 1 .. `levels` run) are constants after unrolling
+        auto vs_tick = [&](int tick, int par, int qs, int levels, bool store) {
+            const int l0 = first + tick;
+            GS_TRACE_AT(tick == 3, 1);
+            GS_TRACE_AT(tick == 2 * K, 2);
+            GS_TRACE_AT(tick == nticks - 2 * K, 3);
+            fair_tick(tick);
+            R[0][par] = q[qs];
+            put(0, par, R[0][par]);
+            if constexpr (!LATE) q[qs] = fetch(l0 + 3);
+#pragma unroll
+            for (int j = 1; j <= K; ++j) {
+                if (j > levels) break;
+                float nu[CPL], nv[CPL];
+                const RowT<CPL> z = widened(j - 1, par ^ 1), p = widened(j - 1, par);
+                cells_vshare<FAST, CPL>(a, z, p, C[j - 1], nu, nv);
+                if (j < K) {
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e) { R[j][par].u[e] = nu[e]; R[j][par].v[e] = nv[e]; }
+                    put(j, par, R[j][par]);
+                } else if (store && store_ok) {
+                    store_cols_buf<CPL>(wu, voff, (l0 - K - ur0) * pitch_bytes, nu);
+                    store_cols_buf<CPL>(wv, voff, (l0 - K - ur0) * pitch_bytes, nv);
+                }
+            }
+            if constexpr (LATE) q[qs] = fetch(l0 + 3); // two rows in flight while the levels are computed
+        };
+#pragma unroll
+        for (int tick = 0; tick < 2 * K; ++tick) vs_tick(tick, tick & 1, tick % 3, (tick + 1) / 2, false); // level j from tick 2 j - 1
+        // (whole trips without a test inside: a tick that may be skipped is a block of its own, and every value carried
+        // from tick to tick -- 16 per level -- then meets its successor in a register copy at the block's end)
+        int t = 2 * K;
+        for (; t + 6 <= nticks; t += 6) {
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) vs_tick(t + s6, s6 & 1, (2 * K + s6) % 3, K, true);
+        }
+#pragma unroll
+        for (int s6 = 0; s6 < 5; ++s6)
+            if (t + s6 < nticks) vs_tick(t + s6, s6 & 1, (2 * K + s6) % 3, K, true);
+        return;
+    }
+
+    RowT<CPL> w[K][3]; // w[j][slot]: level-j rows, newest in slot (tick % 3)
 #pragma unroll
     for (int j = 0; j < K; ++j)
 #pragma unroll
@@ -834,16 +1010,7 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                 GS_TRACE_AT(tick == 3, 1);
                 GS_TRACE_AT(tick == 2 * K, 2);
                 GS_TRACE_AT(tick == nticks - 2 * K, 3);
-                if constexpr (FAIR) {
-                    const int mine = tick * fair_scale >> 16;       // 0 ... 256
-                    if (lane == 0) fb.progress[fb.wave] = mine;
-                    if (mine >= a.fair_from) { // (before: free-running, out of phase as the arbitration leaves them)
-                        const int theirs = fb.progress[lane & 15], their_simd = fb.progress[16 + (lane & 15)];
-                        const unsigned long long behind = __builtin_amdgcn_ballot_w64(their_simd == fb.simd && theirs < mine);
-                        if (behind) __builtin_amdgcn_s_setprio(0);
-                        else __builtin_amdgcn_s_setprio(3);
-                    }
-                }
+                fair_tick(tick);
                 w[0][s3] = widen_tb<CPL>(q[s3].u, q[s3].v);
                 if constexpr (!LATE) q[s3] = fetch(l0 + 3);
 #pragma unroll
@@ -888,8 +1055,8 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
 }
 
 // WG: waves per workgroup.  4 independent waves, or all 16 of a CU with the progress board of tb_march<FAIR>.
-template <int K, int FAST, int CPL, int WG = 4>
-__global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
+template <int K, int FAST, int CPL, int WG>
+__device__ __forceinline__ void tb_unit(const GsStepArgs &a)
 {
     // half_diff needs MODE.IEEE = 0: hwreg(HW_REG_MODE, offset 9, width 1).  The bit only governs
     // the quieting of signalling NaNs otherwise, which parity does not cover.
@@ -898,7 +1065,11 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
     constexpr bool FAIR = WG == 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, see above
-    FairBoard fb{nullptr, 0, wave};
+    FairBoard fb{nullptr, 0, wave, nullptr};
+    if constexpr ((FAST & 5) == 5 && !GS_MATH_FUSED && CPL == 2) { // the variant with full difference sharing: halo boards
+        __shared__ float halo_boards[WG * tb_halo_floats(K)];
+        fb.halo = halo_boards + wave * tb_halo_floats(K);
+    }
     if constexpr (FAIR) {
         // The board.  No barrier: a wave starts marching as soon as it is dispatched (a barrier here held every
         // wave until the 16th of its workgroup had arrived: -2 ... -7 % on a whole pass).  What a wave reads of a
@@ -1035,6 +1206,19 @@ __global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
         rec[7] = (cycles << 32) | (unsigned)strip;
     }
 #endif
+}
+
+template <int K, int FAST, int CPL, int WG = 4>
+__global__ __launch_bounds__(WG * 64) void GS_SUFFIX(gs_step_tb_k)(GsStepArgs a)
+{
+    tb_unit<K, FAST, CPL, WG>(a);
+}
+// The variants with full difference sharing (FAST = 7, 2 columns per lane) are kernels of their own: built for four
+// waves per SIMD (the register allocator is told so; left to itself it settles a few registers above 128).
+template <int K, int WG = 4>
+__global__ __launch_bounds__(WG * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void GS_SUFFIX(gs_step_tb_ds_k)(GsStepArgs a)
+{
+    tb_unit<K, 7, 2, WG>(a);
 }
 
 #if !GS_TB_OP_ONLY
@@ -1411,7 +1595,9 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
                 __builtin_amdgcn_s_sleep(2);
             }
             if (lane == 0) {
-                if (!ok) __builtin_amdgcn_raw_buffer_store_b32(1, win_rsrc(x.abort), 0, 0, SC1);
+                // (the number of THIS launch: the launches before it ran to their end, what the host needs to know --
+                // a launch that finds the word set leaves at once, so only workgroups of one launch ever write it)
+                if (!ok) __builtin_amdgcn_raw_buffer_store_b32(x.seq, win_rsrc(x.abort), 0, 0, SC1);
                 *go = ok;
             }
         }
@@ -1786,7 +1972,7 @@ hipError_t GS_SUFFIX(gs_launch_window)(const GsStepArgs &a, const GsWindowArgs &
     if (a.rows <= 0 || a.cols <= 0 || a.top_present || a.bottom_present || (rpw != 5 && rpw != 6) || x.steps < 1 || x.k < 2 ||
         x.k > 8 || (x.k & 1) || 2 * x.k >= win_rows(rpw) || 2 * x.k + 2 > kWinCols || !x.flags || !x.abort || !x.xu[0] || !x.xu[1] || !x.xv[0] || !x.xv[1])
         return hipErrorInvalidValue;
-    if (!x.desc || x.n_windows < 1) return hipErrorInvalidValue;
+    if (!x.desc || x.n_windows < 1 || x.seq < 1) return hipErrorInvalidValue;
     // byte offsets inside a plane are 32-bit in the kernel
     if ((long)(a.rows + 8) * a.pitch * 4 > 0x7fffffffL) return hipErrorInvalidValue;
     int fast = a.fast & (GS_MATH_FUSED ? 0 : 3);
@@ -1837,7 +2023,7 @@ static const void *tb_entry(int k, int fast, int cpl, int wg = 4)
     const void *fn = nullptr;
 #define GS_TB_CASE(KK, CC)                                                                      \
     case (KK) * 8 + (CC): fn = reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<KK, 0, CC>); break;
-    if (wg == 16) { // the fair-progress form: 4 fused steps, 1 or 2 columns per lane (128 registers at most)
+    if (wg == 16) { // the fair-progress form: 4 fused steps, 1 or 2 columns per lane
         if (k != 4 || (cpl != 1 && cpl != 2)) return nullptr;
         if (fast) {
 #if !GS_MATH_FUSED
@@ -1887,13 +2073,23 @@ static int tb_waves_of(const void *f)
     return w;
 }
 
-static int tb_reduce_fast(int fast)
+// The variant that runs for GsStepArgs::fast = `fast` with k fused steps, cpl columns per lane and wg waves per
+// workgroup: 0 (general), 1 (side weights 0.5), 3 (and dt == 1) or 7 (and full difference sharing: built for 2 columns
+// per lane, 2 to 4 fused steps).
+static int tb_reduce_fast(int fast, int k = 0, int cpl = 0, int wg = 4)
 {
     // The fused build has no use for bit 0 (its taps are sub + fma already) and measured slower
     // with bit 1 (profiles/r01_sweeps.md, runs 48/49): it always runs the general variant.  dt == 1
-    // alone (fast == 2) is not worth a variant either.
-    fast &= GS_MATH_FUSED ? 0 : 3;
-    return fast == 2 ? 0 : fast;
+    // alone (fast == 2) is not worth a variant either, and bit 2 means nothing without the other two.
+    fast &= GS_MATH_FUSED ? 0 : 7;
+    if (!(fast & 1)) return 0;
+    if (fast == 7) {
+#if !GS_MATH_FUSED
+        if (gs_tb_op_kernel_strict(k, 7, cpl, wg)) return 7;
+#endif
+        return 3;
+    }
+    return fast & 3;
 }
 
 // Wave slots of the chip for the kernel entry a launch with these parameters would use (the tuner's
@@ -1901,7 +2097,7 @@ static int tb_reduce_fast(int fast)
 int GS_SUFFIX(gs_tb_wave_slots)(int k, int fast, int cpl)
 {
     if (k < 1 || k > 4 || (cpl != 1 && cpl != 2 && cpl != 4)) return 0;
-    const void *fn = tb_entry(k, tb_reduce_fast(fast), cpl);
+    const void *fn = tb_entry(k, tb_reduce_fast(fast, k, cpl), cpl);
     return fn ? 1024 * tb_waves_of(fn) : 0;
 }
 
@@ -1909,20 +2105,23 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
 {
     // "cN": N columns per lane (4 = the wide layout); ".op": the variant specialised for the
     // default (Oono-Puri) side weights, with or without dt == 1
+    // ".op.ds": ... and with full difference sharing (cells_vshare)
 #define GS_TB_NAMES(C)                                                                          \
     {{"tb-k1" C "/" GS_MATH_NAME, "tb-k2" C "/" GS_MATH_NAME, "tb-k3" C "/" GS_MATH_NAME, "tb-k4" C "/" GS_MATH_NAME}, \
      {"tb-k1" C "/" GS_MATH_NAME ".op", "tb-k2" C "/" GS_MATH_NAME ".op", "tb-k3" C "/" GS_MATH_NAME ".op",            \
-      "tb-k4" C "/" GS_MATH_NAME ".op"}}
-    static const char *const names[3][2][4] = {GS_TB_NAMES("c1"), GS_TB_NAMES("c2"), GS_TB_NAMES("")};
+      "tb-k4" C "/" GS_MATH_NAME ".op"},                                                        \
+     {"tb-k1" C "/" GS_MATH_NAME ".op.ds", "tb-k2" C "/" GS_MATH_NAME ".op.ds", "tb-k3" C "/" GS_MATH_NAME ".op.ds",   \
+      "tb-k4" C "/" GS_MATH_NAME ".op.ds"}}
+    static const char *const names[3][3][4] = {GS_TB_NAMES("c1"), GS_TB_NAMES("c2"), GS_TB_NAMES("")};
 #undef GS_TB_NAMES
     // "f": the fair-progress form (16-wave workgroups) of one-round launches
-    static const char *const names16[2][2] = {{"tb-k4c1f/" GS_MATH_NAME, "tb-k4c1f/" GS_MATH_NAME ".op"},
-                                              {"tb-k4c2f/" GS_MATH_NAME, "tb-k4c2f/" GS_MATH_NAME ".op"}};
+    static const char *const names16[2][3] = {{"tb-k4c1f/" GS_MATH_NAME, "tb-k4c1f/" GS_MATH_NAME ".op", "tb-k4c1f/" GS_MATH_NAME ".op.ds"},
+                                              {"tb-k4c2f/" GS_MATH_NAME, "tb-k4c2f/" GS_MATH_NAME ".op", "tb-k4c2f/" GS_MATH_NAME ".op.ds"}};
     if (k < 1 || k > 4 || a.cols <= 0 || a.rows_per_unit <= 0) return hipErrorInvalidValue;
     const int cpl = a.cpl == 0 ? 4 : a.cpl;
     if (cpl != 1 && cpl != 2 && cpl != 4) return hipErrorInvalidValue;
-    const int fast = tb_reduce_fast(a.fast);
-    if (name) *name = names[cpl == 1 ? 0 : (cpl == 2 ? 1 : 2)][fast ? 1 : 0][k - 1];
+    const int fast = tb_reduce_fast(a.fast, k, cpl);
+    if (name) *name = names[cpl == 1 ? 0 : (cpl == 2 ? 1 : 2)][fast == 7 ? 2 : (fast ? 1 : 0)][k - 1];
     const long rpu = a.rows_per_unit;
     const long rows_a = (long)a.ra1 - a.ra0;
     const long W = tb_cols_per_wave(k, cpl);
@@ -2011,12 +2210,13 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // GS_HIP_FAIR = 0 / 1 forces it off / on.
     static const int fair_env = gs_env_int("GS_HIP_FAIR", -1, 0, 1);
     const bool fair = a.allow_fair && units <= 4096 && units > 1024 && (fair_env < 0 ? (cpl == 2 || rpu >= 20) : fair_env != 0);
-    const void *fair_fn = fair ? tb_entry(k, fast, cpl, 16) : nullptr;
+    const int fast16 = fair ? tb_reduce_fast(a.fast, k, cpl, 16) : 0;
+    const void *fair_fn = fair ? tb_entry(k, fast16, cpl, 16) : nullptr;
     static const int fair_from_env = gs_env_int("GS_HIP_FAIR_FROM", -1, 0, 256);
     args.fair_from = fair_from_env >= 0 ? fair_from_env : 0;
     void *kargs[] = {&args};
     if (fair_fn) {
-        if (name) *name = names16[cpl == 1 ? 0 : 1][fast ? 1 : 0];
+        if (name) *name = names16[cpl == 1 ? 0 : 1][fast16 == 7 ? 2 : (fast16 ? 1 : 0)];
         return hipLaunchKernel(fair_fn, dim3((unsigned)((units + 15) / 16)), dim3(1024), kargs, 0, s);
     }
     const long blocks = (units + 3) / 4;
@@ -2084,6 +2284,16 @@ extern "C" int32_t GS_SUFFIX(gs_debug_trace_read)(unsigned long long *dst, int32
 // and `cpl` columns per lane.
 const void *gs_tb_op_kernel_strict(int k, int fast, int cpl, int wg)
 {
+    if (fast == 7) { // full difference sharing: 2 columns per lane
+        if (cpl != 2) return nullptr;
+        if (wg == 16) return k == 4 ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_ds_k)<4, 16>) : nullptr;
+        switch (k) {
+        case 2: return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_ds_k)<2>);
+        case 3: return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_ds_k)<3>);
+        case 4: return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_ds_k)<4>);
+        default: return nullptr;
+        }
+    }
     if (wg == 16) {
         if (k != 4 || (cpl != 1 && cpl != 2) || (fast != 1 && fast != 3)) return nullptr;
         if (fast == 1)

@@ -96,18 +96,18 @@ def share_tuning(sim, slab_rows: int, cols: int, rank: int, world: int, device: 
 
     Multi-process contexts do not tune on line (a timing window would have to be collective).
     Rank 0 lets a throw-away single-slab context of the slab's shape run ``tune_steps`` steps, reads
-    what ``gs_run`` chose (``gs_ctx_get_tuned``) and broadcasts the three integers; every rank hands them
+    what ``gs_run`` chose (``gs_ctx_get_tuned``) and broadcasts the four integers; every rank hands them
     to its own context (``gs_ctx_set_tuned``).  They must agree: the exchange is ``fuse_steps`` rows deep.
-    Returns (rows per unit, steps per pass, columns per lane); zeros mean "nothing chosen, defaults".
+    Returns (rows per unit, steps per pass, columns per lane, share_taps); zeros mean "nothing chosen, defaults".
     """
     from .simulation import HipArgs, Parameters, Simulation
 
-    choice = [0, 0, 0]
+    choice = [0, 0, 0, 0]
     if rank == 0:
         args = sim.context.args
         scratch = Simulation.new(sim.params, HipArgs(devices=[local_device], math=args.math, kernel=args.kernel,
                                                      fuse_steps=args.fuse_steps, boundary=args.boundary,
-                                                     general_kernels=args.general_kernels))
+                                                     general_kernels=args.general_kernels, share_taps=args.share_taps))
         species = scratch.make_species([slab_rows, cols])
         for _ in range(8):                       # long calls wait for their tuning phases
             scratch.perform_steps(species, tune_steps)

@@ -94,6 +94,7 @@ class HipArgs:
     boundary: int = field(default_factory=lambda: _env_int("GS_HIP_BOUNDARY", capi.GS_BOUNDARY_CLIPPED))
     no_tune: int = field(default_factory=lambda: _env_int("GS_HIP_NO_TUNE", 0))
     tile_shape: int = field(default_factory=lambda: _env_int("GS_HIP_TILE_SHAPE", 0))
+    share_taps: int = field(default_factory=lambda: _env_int("GS_HIP_SHARE_TAPS", 0))
     rank: int = 0
     world: int = 1
     unique_id: Optional[bytes] = None
@@ -109,6 +110,7 @@ class HipArgs:
         o.boundary = self.boundary
         o.no_tune = self.no_tune
         o.tile_shape = self.tile_shape
+        o.share_taps = self.share_taps
         return o
 
 
@@ -154,17 +156,18 @@ class HipContext:
         capi.check(self._lib.gs_timer_stop(self.handle, ctypes.byref(ms)))
         return float(ms.value)
 
-    def get_tuned(self, slab_rows: int, cols: int) -> Tuple[int, int, int]:
-        """(rows per unit, steps fused per pass, columns per lane) chosen for slabs of this shape;
-        zeros when nothing was chosen yet (``gs_ctx_get_tuned``)."""
-        a, b, c = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+    def get_tuned(self, slab_rows: int, cols: int) -> Tuple[int, int, int, int]:
+        """(rows per unit, steps fused per pass, columns per lane, share_taps: 1 = on, 2 = off) chosen for slabs of
+        this shape; zeros when nothing was chosen yet (``gs_ctx_get_tuned``)."""
+        a, b, c, d = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
         capi.check(self._lib.gs_ctx_get_tuned(self.handle, slab_rows, cols, ctypes.byref(a), ctypes.byref(b),
-                                              ctypes.byref(c)))
-        return int(a.value), int(b.value), int(c.value)
+                                              ctypes.byref(c), ctypes.byref(d)))
+        return int(a.value), int(b.value), int(c.value), int(d.value)
 
-    def set_tuned(self, slab_rows: int, cols: int, rows_per_block: int, fuse_steps: int, cols_per_lane: int) -> None:
+    def set_tuned(self, slab_rows: int, cols: int, rows_per_block: int, fuse_steps: int, cols_per_lane: int,
+                  share_taps: int = 0) -> None:
         capi.check(self._lib.gs_ctx_set_tuned(self.handle, slab_rows, cols, rows_per_block, fuse_steps,
-                                              cols_per_lane))
+                                              cols_per_lane, share_taps))
 
     def comm_info(self) -> Tuple[int, int, int]:
         """(ranks, rank, device) as RCCL reports them for this context's communicator; (0, -1, -1)

@@ -71,7 +71,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 3
+#define GS_ABI_VERSION 4
 
 typedef enum gs_status {
     GS_OK = 0,
@@ -169,7 +169,13 @@ typedef struct gs_options {
     int32_t tile_shape;      /* GS_KERNEL_TILE: window of a workgroup, 1 = 32 rows x 64 columns, 2 = 16 x 64,       *
                               * 3 = 64 x 64; 0 = 32 x 64.  With kernel = TILE, fuse_steps (1..8, and less than  *
                               * half the window's rows) sets the steps per launch                          */
-    int32_t reserved[4];
+    int32_t share_taps;      /* full difference sharing in the temporally blocked kernel (the S / SE / SW taps of a  *
+                              * row are, negated, the N / NW / NE taps of the next: 46 instead of 52 arithmetic    *
+                              * instructions per cell-step, bit-identical; needs side weights 0.5, dt == 1 and      *
+                              * w[0][0] == w[2][2], w[0][2] == w[2][0] -- true of every stencil of the reference -- *
+                              * and runs at 3 instead of 4 waves per SIMD): 0 = chosen on line by gs_run like the  *
+                              * unit height (slab chains and untuned runs: on), 1 = on, 2 = off                    */
+    int32_t reserved[3];
 } gs_options;
 
 typedef struct gs_ctx gs_ctx;     /* devices, streams, row partition, RCCL communicator    */
@@ -192,6 +198,17 @@ int32_t gs_get_unique_id(void *out128);
  * call pattern of the ghost-row exchange (one group: ncclSend + ncclRecv, on a high-priority stream), then compares
  * it.  For a maintainer's first multi-GPU run; no context is needed. */
 int32_t gs_rccl_selftest(int32_t device, uint64_t floats);
+
+/* Which libraries this process's libgs_hip.so is bound to, as one JSON object: {"hip": path of the HIP runtime,
+ * "hip_runtime_version", "rccl": path or null, "rccl_version", "rccl_named_by_GS_RCCL_LIBRARY"}.  libgs_hip.so links
+ * the HIP runtime by SONAME (libamdhip64.so.7) and dlopens RCCL by SONAME (librccl.so.1) on first use, so it binds
+ * WHATEVER COPY THE PROCESS HAS MAPPED FIRST: in a process that imported torch before creating a context -- bench.py,
+ * smoke(), the tests -- both are the copies the torch wheel bundles (one HIP runtime in the process, the one that owns
+ * the planes' device pointers, and the RCCL built against it, which the library's communicator then shares with
+ * torch's ProcessGroupNCCL if that exists); in a torch-free process -- the Rust binary -- they are /opt/rocm's.  Both
+ * pairings run the one-rank exchange of gs_rccl_selftest in the GPU suite (tests/test_gpu_multiprocess.py).
+ * load_rccl = 0 reports RCCL only if this process has loaded it already (nothing is loaded for the answer). */
+int32_t gs_runtime_info(int32_t load_rccl, char *out, size_t cap);
 
 /* SimulateCreate::new(params, args) (compute/shared/src/lib.rs:42-45).
  *   device_ids / n_local : local slabs, top to bottom (NULL / 0 = one slab on device 0)
@@ -287,15 +304,16 @@ int32_t gs_timer_start(gs_ctx *ctx);
 int32_t gs_timer_stop(gs_ctx *ctx, float *elapsed_ms);
 
 /* The configuration gs_run uses for slabs of `slab_rows` x `cols` cells: unit height, steps fused per
- * pass, columns per lane (zeros from _get_ when nothing was chosen yet).  Single-slab contexts find it
+ * pass, columns per lane, full difference sharing (1 = on, 2 = off, as gs_options.share_taps; _set_ takes 0 as "on")
+ * (zeros from _get_ when nothing was chosen yet).  Single-slab contexts find it
  * themselves (on-line tuning inside gs_run); a slab chain takes what it is given: one process tunes on a
  * single slab of the slab's shape, reads the result with _get_ and every process of the chain sets it
  * with _set_ -- all of them the same values, since the ghost-row exchange is fuse_steps rows deep
  * (grayscott_amd/dist.py: share_tuning). */
 int32_t gs_ctx_get_tuned(const gs_ctx *ctx, uint64_t slab_rows, uint64_t cols, int32_t *rows_per_block,
-                         int32_t *fuse_steps, int32_t *cols_per_lane);
+                         int32_t *fuse_steps, int32_t *cols_per_lane, int32_t *share_taps);
 int32_t gs_ctx_set_tuned(gs_ctx *ctx, uint64_t slab_rows, uint64_t cols, int32_t rows_per_block,
-                         int32_t fuse_steps, int32_t cols_per_lane);
+                         int32_t fuse_steps, int32_t cols_per_lane, int32_t share_taps);
 
 /* What RCCL itself reports for this context's communicator (ncclCommCount / ncclCommUserRank /
  * ncclCommCuDevice): the number of ranks, this rank and its device; 0, -1, -1 for a single process. */
@@ -316,6 +334,9 @@ typedef struct gs_stats {
     float halo_exposed_ms;    /* sum over passes of max(0, end of the halo stream's work - end of the      *
                                * interior kernel): what the exchange did NOT hide behind the interior      */
     float reserved;
+    uint64_t window_fallbacks; /* persistent window launches that gave up (another kernel held compute units) and were  *
+                                * run again by the marching kernel: 0 or 1, the context stays with the marching kernel  *
+                                * afterwards; a timing that contains one measured the stall, not a rate               */
 } gs_stats;
 int32_t gs_ctx_stats(gs_ctx *ctx, gs_stats *out);
 /* Time the next `passes` passes (0..4096; 0 = off) of every local slab of a slab chain with HIP events on

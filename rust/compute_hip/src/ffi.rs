@@ -1,4 +1,4 @@
-//! `extern "C"` view of include/gs_hip.h (ABI version 3).  Field order and widths must match
+//! `extern "C"` view of include/gs_hip.h (ABI version 4).  Field order and widths must match
 //! the header exactly; `tests/test_capi_cpu.py::test_struct_layouts` pins the C side.
 #![allow(non_camel_case_types)]
 
@@ -33,7 +33,8 @@ pub struct gs_options {
     pub boundary: i32,
     pub no_tune: i32,
     pub tile_shape: i32,
-    pub reserved: [i32; 4],
+    pub share_taps: i32,
+    pub reserved: [i32; 3],
 }
 
 #[repr(C)]

@@ -70,9 +70,46 @@ pub struct HipArgs {
     pub hip_cols_per_lane: i32,
 
     /// 1 = never time candidate configurations inside perform_steps (untuned defaults, or the
-    /// three pinned values above)
+    /// pinned values above)
     #[arg(long, env = "GS_HIP_NO_TUNE", default_value_t = 0)]
     pub hip_no_tune: i32,
+
+    /// Step kernel (`gs_kernel` in gs_hip.h): 0 = chosen by grid size and call length, 1 = one thread
+    /// per cell, 2 = single-step streaming, 3 = temporally blocked, 4 = LDS-staged, 5 = LDS-resident
+    /// windows, 6 = one persistent launch per call on register-resident windows
+    #[arg(long, env = "GS_HIP_KERNEL", default_value_t = 0)]
+    pub hip_kernel: i32,
+
+    /// Rule on the edges of the grid (`gs_boundary`): 0 = compute_naive's clipped window, 1 = zero halo
+    /// (what the SIMD and Vulkan backends compute: data/src/concentration/simd/mod.rs:281-326)
+    #[arg(long, env = "GS_HIP_BOUNDARY", default_value_t = 0)]
+    pub hip_boundary: i32,
+
+    /// 1 = never run the kernel variants specialised for the default stencil and time step (A/B timing;
+    /// results are bit-identical either way)
+    #[arg(long, env = "GS_HIP_GENERAL_KERNELS", default_value_t = 0)]
+    pub hip_general_kernels: i32,
+
+    /// Full difference sharing in the temporally blocked kernel: 0 = chosen on line, 1 = on, 2 = off
+    /// (bit-identical either way)
+    #[arg(long, env = "GS_HIP_SHARE_TAPS", default_value_t = 0)]
+    pub hip_share_taps: i32,
+
+    /// Row bands a single slab is scheduled as (0 or 1 = off)
+    #[arg(long, env = "GS_HIP_SPLIT", default_value_t = 0)]
+    pub hip_split: i32,
+
+    /// 1 = replay batches of 16 passes through a hipGraph (single slab)
+    #[arg(long, env = "GS_HIP_USE_GRAPH", default_value_t = 0)]
+    pub hip_use_graph: i32,
+
+    /// Window of the LDS-resident-window kernel: 1 = 32 x 64, 2 = 16 x 64, 3 = 64 x 64 (0 = 32 x 64)
+    #[arg(long, env = "GS_HIP_TILE_SHAPE", default_value_t = 0)]
+    pub hip_tile_shape: i32,
+
+    /// Extra f32 of row pitch beyond the round-up to 64
+    #[arg(long, env = "GS_HIP_PITCH_PAD", default_value_t = 0)]
+    pub hip_pitch_pad: i32,
 }
 
 /// Owner of the `gs_ctx` (devices, streams); shared by the simulation and its species
@@ -216,6 +253,14 @@ impl SimulateCreate for Simulation {
         opts.fuse_steps = args.hip_fuse_steps;
         opts.cols_per_lane = args.hip_cols_per_lane;
         opts.no_tune = args.hip_no_tune;
+        opts.kernel = args.hip_kernel;
+        opts.boundary = args.hip_boundary;
+        opts.general_kernels = args.hip_general_kernels;
+        opts.share_taps = args.hip_share_taps;
+        opts.split = args.hip_split;
+        opts.use_graph = args.hip_use_graph;
+        opts.tile_shape = args.hip_tile_shape;
+        opts.pitch_pad = args.hip_pitch_pad;
         let mut ctx = ptr::null_mut();
         // one process, `hip_devices.len()` row slabs with ghost-row exchange by peer copies
         check(unsafe {

@@ -27,7 +27,7 @@ def test_header_symbols_all_exported(built):
     assert set(names) == set(capi.EXPORTS)
     for n in names:
         assert hasattr(lib, n), f"libgs_hip.so does not export {n}"
-    assert lib.gs_abi_version() == 3
+    assert lib.gs_abi_version() == 4
 
 
 def test_library_has_gfx950_code_object_and_no_oracle(built):
@@ -60,7 +60,7 @@ def test_struct_layouts(built):
 
     assert ctypes.sizeof(capi.GsParams) == 14 * 4
     assert ctypes.sizeof(capi.GsOptions) == 16 * 4
-    assert ctypes.sizeof(capi.GsStats) == 5 * 8 + 4 * 4      # gs_stats: 5 x uint64 + 4 x float
+    assert ctypes.sizeof(capi.GsStats) == 5 * 8 + 4 * 4 + 8  # gs_stats: 5 x uint64 + 4 x float + uint64
 
 
 def test_dynamic_lds_opt_in_is_keyed_by_device_and_function(built):

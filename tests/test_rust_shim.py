@@ -43,8 +43,19 @@ def test_manifest_and_bench_entry():
     bench = _read(RUST, "benches", "compute_hip.rs")
     assert "compute::cpu_benchmark!(compute_hip);" in bench
     lib = _read(RUST, "src", "lib.rs")
-    for flag in ("hip_devices", "hip_math", "hip_rows_per_block", "hip_fuse_steps", "hip_cols_per_lane", "hip_no_tune"):
-        assert re.search(r"#\[arg\(long, env = \"GS_HIP_\w+\"[^\]]*\)\]\s*\n\s*pub %s:" % flag, lib), flag
+    # every field of gs_options is a flag of HipArgs -- `--hip-<field>`, env GS_HIP_<FIELD>, defaulted
+    # (compute/shared/src/lib.rs:20-25) -- reaches the C struct, and is the variable grayscott_amd.HipArgs reads
+    header = _read(ROOT, "include", "gs_hip.h")
+    c_body = header[header.index("typedef struct gs_options {"):header.index("} gs_options;")]
+    fields = [f for f in re.findall(r"int32_t (\w+)(?:\[\d+\])?;", c_body) if f != "reserved"]
+    assert len(fields) == 13
+    py = _read(ROOT, "grayscott_amd", "simulation.py")
+    for f in ["devices"] + fields:
+        m = re.search(r"#\[arg\(long, env = \"(GS_HIP_\w+)\"[^\]]*default_value(?:_t)? = [^\]]*\)\]\s*\n\s*pub hip_%s:" % f, lib)
+        assert m and m.group(1) == "GS_HIP_" + f.upper(), f
+        assert '"%s"' % m.group(1) in py, f
+        if f != "devices":
+            assert "opts.%s = args.hip_%s;" % (f, f) in lib, f
 
 
 def test_perform_steps_waits_and_prepare_steps_does_not():

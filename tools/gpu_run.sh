@@ -17,6 +17,7 @@
 #   criterion       tools/criterion_grid.py
 #   rehearsal       tools/rehearsal.sh
 #   py:SCRIPT[:args]  any python tool of this repository
+#   pytest:FILE[,FILE...][:K-EXPRESSION]   some GPU test files (fast failure before a long run)
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
@@ -67,7 +68,7 @@ for stage in "$@"; do
       # per-flavour PMC counters of tools/energy_table.py (--profile: 40 steps per flavour), one pass per input
       rc=0
       for data in new developed; do
-        ( cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU \
+        ( cd /tmp && TMPDIR=/tmp timeout -k 10 1100 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU \
             --output-format csv -d "$OUT/energy_$data" -o energy -- python3 "$ROOT/tools/energy_table.py" --profile --data $data \
             > "$OUT/energyprof_$data.log" 2>&1 ) || rc=$?
         tail -3 "$OUT/energyprof_$data.log"
@@ -82,6 +83,9 @@ for stage in "$@"; do
       fi ;;
     rehearsal)
       timeout -k 10 1100 bash tools/rehearsal.sh > "$OUT/rehearsal.log" 2>&1; rc=$?; tail -12 "$OUT/rehearsal.log" ;;
+    pytest)
+      IFS=: read -r files kexpr <<< "$rest"
+      timeout -k 10 1100 python -m pytest ${files//,/ } -m gpu -x -q ${kexpr:+-k "$kexpr"} > "$OUT/pytest_some.log" 2>&1; rc=$?; tail -15 "$OUT/pytest_some.log" ;;
     py)
       IFS=: read -r script pyargs <<< "$rest"
       timeout -k 10 900 python "$script" ${pyargs//,/ } > "$OUT/$(basename "$script" .py).log" 2>&1; rc=$?; tail -40 "$OUT/$(basename "$script" .py).log" ;;
