@@ -34,12 +34,14 @@ sys.path.insert(0, ROOT)
 
 from benchkit.harness import (BYTES_PER_CELL_STEP, HBM_COPY_CEILING_GBS, HBM_PEAK_GBS, NOMINAL_SCLK_MHZ,  # noqa: E402,F401
                               USEFUL_VALU_PER_CELL_STEP, VALU_PEAK_TLANEOPS, Watchdog, grid_for, self_launch, usable_cpus)
-from benchkit.legs import (cpu_baseline, developed_start, measured_counters, planes_equal,  # noqa: E402,F401
-                           sample_clock_and_power, scaled_valu_insts, upload_species, verify_single_gpu)
-from benchkit.multigpu import fill_noise, range_checksums, verify_slab_chain  # noqa: E402,F401
+from benchkit.legs import (add_clocks, cpu_baseline, developed_start, fused_flavour_leg, measured_counters,  # noqa: E402,F401
+                           planes_equal, roofline_object, sample_clock_and_power, scaled_valu_insts, upload_species,
+                           verify_single_gpu)
+from benchkit.multigpu import (fill_noise, peer_chain_leg, per_rank_report, range_checksums,  # noqa: E402,F401
+                               verify_slab_chain)
 
 
-def main() -> int:
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -51,11 +53,20 @@ def main() -> int:
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions of --steps steps each, back to back; `value` is their median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra", action="store_true",
+                    help="N = 1: also the fused-tap flavour and the single-step kernel on two more sets of planes")
     ap.add_argument("--no-extra", action="store_true",
-                    help="skip the informational legs (fused flavour, developed pattern, clock / energy samples)")
+                    help="N = 1: skip the developed-pattern co-headline and the clock / power / energy samples")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the replay that compares the timed planes with an independent run (and, on one GPU, "
                          "the single-step HBM leg that is part of it)")
+    ap.add_argument("--no-peer-chain", action="store_true",
+                    help="N > 1: skip rank 0's in-process chain over all GPUs (hipMemcpyPeerAsync, no RCCL) after the timed job")
+    ap.add_argument("--bootstrap", choices=("nccl", "gloo"), default="nccl",
+                    help="N > 1: backend of the torch.distributed group that carries the unique id, barriers and timing "
+                         "reductions (the ghost rows always travel through the library's own RCCL communicator).  nccl: "
+                         "barriers on the GPU, and torch's communicator shares the RCCL instance the library binds; gloo: "
+                         "the library's communicator is the only one in the process")
     ap.add_argument("--kernel", choices=("auto", "stream"), default="auto",
                     help="diagnostics / profiles: `stream` pins the single-step HBM-bound kernel for the whole protocol")
     ap.add_argument("--rehearsal", action="store_true",
@@ -63,8 +74,11 @@ def main() -> int:
                          "binds a transport that accepts several ranks per device (tests/cpp/shm_transport.cpp, "
                          "built on the fly unless GS_RCCL_LIBRARY names one).  Checks the code path, the numbers "
                          "mean nothing")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def main() -> int:
+    args = parse_args()
     # N > 1 without a torchrun environment: this process is only the launcher of the torchrun CHILD -- decided
     # before torch.cuda, the process group or libgs_hip.so exist in this process.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -74,16 +88,29 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     wd = Watchdog(rank)
+    stage_s = {}                                     # seconds per stage of this rank (rank 0's go into the line)
 
-    with wd.stage("import", 600):
+    class stage:                                     # a watchdog stage that also keeps its wall time
+        def __init__(self, name, bound):
+            self.name, self.inner = name, wd.stage(name, bound)
+
+        def __enter__(self):
+            self.t0 = time.perf_counter()
+            return self.inner.__enter__()
+
+        def __exit__(self, *exc):
+            stage_s[self.name] = round(stage_s.get(self.name, 0.0) + time.perf_counter() - self.t0, 2)
+            return self.inner.__exit__(*exc)
+
+    # ---- the libraries, in the order that decides which copies libgs_hip.so binds (gs_hip.h: gs_runtime_info) ----
+    with stage("import", 600):
         import torch
         import torch.distributed as dist
 
         from grayscott_amd import HipArgs, Parameters, Simulation, capi
         from grayscott_amd import dist as gsd
 
-    if world != args.gpus:
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         return 2
@@ -93,20 +120,26 @@ def main() -> int:
             return 2
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    red_dev = "cpu" if args.rehearsal else "cuda"   # where the bootstrap / reduction tensors live
+    gloo = args.rehearsal or args.bootstrap == "gloo"
+    red_dev = "cpu" if gloo else "cuda"              # where the bootstrap / reduction tensors live
 
     rows, cols = grid_for(args.gpus, args.scaling)
     if args.grid:
         rows, cols = (int(x) for x in args.grid.lower().split("x"))
     if args.rows and args.cols:
         rows, cols = args.rows, args.cols
+    cells = rows * cols
+    cells_per_gpu = cells / world
+    single = world == 1
+    with_extra = single and not args.no_extra
+    verify = not args.no_verify
 
-    # communicator creation: the process group, rank 0's RCCL unique id, ncclCommInitRank inside gs_ctx_create
-    with wd.stage("init", 300):
+    # ---- N > 1: the process group, rank 0's RCCL unique id, ncclCommInitRank inside gs_ctx_create ----------------
+    with stage("init", 300):
         unique_id = None
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if args.rehearsal:
+            if gloo:
                 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
             else:
                 dist.init_process_group(backend="nccl", rank=rank, world_size=world,
@@ -118,33 +151,32 @@ def main() -> int:
             unique_id = bytes(buf.cpu().numpy().tobytes())
         # The library's defaults, nothing pinned: one kernel launch per pass, so "launch" in the roofline
         # object is unambiguous and comparable with rocprofv3's per-kernel average.
-        hip_args = HipArgs(devices=[local_rank], rank=rank, world=world, unique_id=unique_id,
-                           kernel=capi.GS_KERNEL_STREAM if args.kernel == "stream" else capi.GS_KERNEL_AUTO)
-        sim = Simulation.new(Parameters(), hip_args)
+        sim = Simulation.new(Parameters(), HipArgs(devices=[local_rank], rank=rank, world=world, unique_id=unique_id,
+                                                   kernel=capi.GS_KERNEL_STREAM if args.kernel == "stream" else capi.GS_KERNEL_AUTO))
+        runtime = capi.runtime_info(load_rccl=world > 1)
+        runtime["bootstrap"] = ("gloo" if gloo else "nccl") if world > 1 else None
+        runtime["torch"] = torch.__version__
     ctx = sim.context
-    cells = rows * cols
-    cells_per_gpu = cells / args.gpus
-    single = args.gpus == 1
-    with_extra = single and not args.no_extra
-    verify = not args.no_verify
 
     def run(sp, steps):
         """perform_steps, counted: the replay at the end repeats exactly the steps a Species has taken."""
         sim.perform_steps(sp, steps)
         sp.steps_done += steps
 
-    # Everything the timed regions touch exists BEFORE the first of them: the timed Species (Species::new on
-    # the device, HBM-resident) and, for the co-headline, the developed pattern.  Nothing is allocated, freed
-    # or filled between tuning and timing -- round 2's line read 8 % low because 4 GiB of planes were created
-    # in that gap and the first launches after it ran on an idle chip's clocks.  The same holds for the planes
-    # of the replay (single GPU: a second context pinned to the single-step stream kernel).
-    with wd.stage("setup", 900):
+    # ---- everything the timed regions touch exists BEFORE the first of them -------------------------------------
+    # The timed Species (Species::new on the device, HBM-resident) and, for the co-headline, the developed pattern.
+    # Nothing is allocated, freed or filled between tuning and timing -- round 2's line read 8 % low because 4 GiB of
+    # planes were created in that gap and the first launches after it ran on an idle chip's clocks.  The same holds for
+    # the planes of the replay (single GPU: a second context pinned to the single-step stream kernel).
+    with stage("setup", 900):
         species = sim.make_species([rows, cols])
         species.steps_done = 0
         sp_dev, sim_s, sp_s, sp_dev_s = None, None, None, None
         if single and verify:
             sim_s = Simulation.new(Parameters(), HipArgs(devices=[local_rank], kernel=capi.GS_KERNEL_STREAM))
-            sp_s = sim_s.make_species([rows, cols])
+            # placement by measurement (gs_fields_place): the HBM-bound single-step kernel reads at one of three levels
+            # depending on where its four planes land; the replay's Species takes the best four of eight blocks
+            sp_s = sim_s.make_species([rows, cols], place_candidates=0 if cells < (1 << 26) else 4)
             sp_s.steps_done = 0
         if with_extra:
             u0, v0 = developed_start(rows, cols)
@@ -153,10 +185,10 @@ def main() -> int:
                 sp_dev_s = upload_species(sim_s, u0, v0)
             del u0, v0
             run(sp_dev, 4000)                            # develops the pattern; also tunes the context
-        tuned = (0, 0, 0)
-        if world == 1:
-            # gs_run chooses unit height / fused steps / columns per lane on line, from timed passes of the
-            # simulation itself (per context and shape).  It finishes here, on passes of the timed Species, so
+        tuned = (0, 0, 0, 0)
+        if single:
+            # gs_run chooses unit height / fused steps / columns per lane / tap sharing on line, from timed passes of
+            # the simulation itself (per context and shape).  It finishes here, on passes of the timed Species, so
             # that neither the W warm-up steps nor the K timed ones contain tuning passes whatever W and K are.
             for _ in range(8):
                 tuned = ctx.get_tuned(rows, cols)
@@ -217,6 +249,7 @@ def main() -> int:
         run(sp, n)                                      # whole passes only, whatever the tuner fuses (2, 3 or 4 steps)
         return n
 
+    # ---- the timed regions -------------------------------------------------------------------------------------
     # A rehearsal of the timed region first: the first torch.cuda.synchronize() / barrier / HIP-event calls of a
     # process may initialise things lazily, and a chip that idles for 2 ms runs its next ~10 ms at lower clocks
     # (tools/region_startup.py: a 5-pass region after 2 ms of idle reads 5 % low).
@@ -224,7 +257,7 @@ def main() -> int:
     # that is not a whole number of passes (the driver's 5) ends in a single-step launch of another kernel, and the
     # chip, which sits on its power limit, answers that 0.7 ms change of load with a 20 ms dip -- the first four
     # 5-ms regions read 1-5 % low with W = 5 and not with W = 0, 4 or 8 (profiles/r03_sweeps.md, section 6).
-    with wd.stage("timed", 600):
+    with stage("timed", 600):
         timed_run(species, args.steps)
         run(species, args.warmup)
         extra_warm_steps = warm(species)
@@ -233,92 +266,24 @@ def main() -> int:
     wall, event_ms, passes = median_run(runs)
     walls = [r[0] for r in runs]
 
-    per_rank, comm = [], []
+    per_rank, rccl_ranks = [], None
     if world > 1:
-        # Per rank: its own launch time, and -- in an untimed repeat with HIP events on the halo and compute
-        # streams (gs_ctx_set_pass_timing) -- whether the boundary band + ghost-row exchange hid behind the
-        # interior kernel.  Then what RCCL itself says about the communicator, and where every rank runs.
-        with wd.stage("per-rank", 600):
-            _, my_ms, my_passes = median_run([timed_run(species, args.steps) for _ in range(3)])
-            n_timed = min(64, max(1, my_passes))
-            ctx.set_pass_timing(n_timed)
-            timed_run(species, args.steps)
-            st = ctx.stats()
-            ctx.set_pass_timing(0)
-            tp = max(1, st["timed_passes"])
-            mine = torch.tensor([my_ms / max(1, my_passes), st["halo_ms"] / tp, st["interior_ms"] / tp,
-                                 st["halo_exposed_ms"] / tp, float(st["timed_passes"])] +
-                                [float(x) for x in ctx.comm_info()] + [float(local_rank)],
-                                dtype=torch.float64, device=red_dev)
-            allr = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allr, mine)
-        for r in allr:
-            x = [float(v) for v in r.cpu()]
-            per_rank.append({"launch_ms": x[0], "halo_stream_ms_per_pass": x[1], "interior_ms_per_pass": x[2],
-                             "halo_exposed_ms_per_pass": x[3], "timed_passes": int(x[4]),
-                             "rccl_rank": int(x[6]), "rccl_device": int(x[7]), "local_rank": int(x[8])})
-            comm.append(int(x[5]))
+        with stage("per-rank", 600):
+            per_rank, rccl_ranks = per_rank_report(sim, species, args.steps, timed_run, world, local_rank, red_dev)
 
     kernel_name, _ = ctx.info()
     value = cells * args.steps / wall / 1e6
     steps_per_launch = args.steps / passes
-    pmc = measured_counters(kernel_name, int(rows // args.gpus), cols, tuned)
+    pmc = measured_counters(kernel_name, int(rows // world), cols, tuned)
     valu_insts, valu_how = scaled_valu_insts(pmc, tuned)
 
-    def roofline_of(event_ms, passes):
-        """The roofline object of one timed region (its own launch time; the committed profile's counters)."""
-        launch_s = event_ms * 1e-3 / passes
-        algo_bytes = BYTES_PER_CELL_STEP * cells_per_gpu * steps_per_launch
-        algo_gbs = algo_bytes / launch_s / 1e9
-        traffic = pmc.get("traffic")
-        hbm_physical = traffic / launch_s / 1e9 / HBM_PEAK_GBS if traffic else None
-        valu_rate = valu_insts * 64 / launch_s / 1e12 if valu_insts else None
-        useful_rate = USEFUL_VALU_PER_CELL_STEP * cells_per_gpu * steps_per_launch / launch_s / 1e12
-        # Which roof binds: with K >= 3 steps fused per HBM pass the kernel moves ~16 B per cell for K
-        # steps and is bound by VALU issue; a single-step pass is bound by HBM.
-        valu_bound = steps_per_launch >= 3
-        if valu_bound:
-            # issued VALU lane-instructions (PMC SQ_INSTS_VALU x 64, committed profile of this layout) per
-            # launch time against the chip's plain-f32 issue rate; without a matching profile, the useful
-            # instructions alone (computed from this run: a lower bound of what was issued)
-            achieved = valu_rate if valu_rate else useful_rate
-            frac = achieved / VALU_PEAK_TLANEOPS
-        else:
-            achieved = traffic / launch_s / 1e9 if traffic else algo_gbs
-            frac = hbm_physical if hbm_physical else algo_gbs / HBM_PEAK_GBS
-        return {
-            "bound": "valu-issue" if valu_bound else "hbm",
-            "achieved": achieved,
-            "peak": VALU_PEAK_TLANEOPS if valu_bound else HBM_PEAK_GBS,
-            "unit": "T lane-ops/s" if valu_bound else "GB/s",
-            "frac": frac,
-            "frac_source": (valu_how if valu_rate else "useful instructions only (no profile of this layout committed)")
-                           if valu_bound else ("PMC traffic" if traffic else "algorithmic bytes"),
-            "valu": valu_rate / VALU_PEAK_TLANEOPS if valu_rate else None,
-            "useful_valu": useful_rate / VALU_PEAK_TLANEOPS,
-            "hbm_physical": hbm_physical,
-            # SURVEY section 8(d)'s algorithmic figure (16 B per cell-step): a throughput in GB/s-equivalents,
-            # NOT a fraction of the HBM roof once K steps share one HBM pass (it exceeds the peak by design)
-            "algorithmic_GBps": algo_gbs,
-            "algorithmic_frac": algo_gbs / HBM_PEAK_GBS,
-            "algorithmic_frac_of_copy_ceiling": algo_gbs / HBM_COPY_CEILING_GBS,
-            "launch_ms": launch_s * 1e3,
-            # rocprofv3's average duration of the same kernel in the committed profile (profiling lowers clocks)
-            "profile_launch_ms": pmc.get("launch_ms"),
-            "launches": passes,
-            "steps_per_launch": steps_per_launch,
-            "algorithmic_bytes_per_launch": algo_bytes,
-            "traffic": traffic,                      # HBM bytes per launch, PMC (null: not profiled)
-            "valu_insts_per_launch": valu_insts,     # SQ_INSTS_VALU per launch, PMC (null: not profiled)
-            "counters_source": pmc.get("source"),
-            "counters_layout": ({"rows_per_unit": pmc.get("rows_per_unit"), "steps_per_pass": pmc.get("steps_per_pass"),
-                                 "cols_per_lane": pmc.get("cols_per_lane")} if pmc else None),
-        }
+    def roofline_of(ms, n_passes):
+        return roofline_object(ms, n_passes, steps_per_launch, cells_per_gpu, pmc, valu_insts, valu_how, kernel_name)
 
     roofline = roofline_of(event_ms, passes)
-    extra, developed, clocks, clocks_dev = None, None, None, None
+    fused, developed, clocks, clocks_dev = None, None, None, None
     if with_extra:
-        with wd.stage("extras", 900):
+        with stage("developed", 900):
             # co-headline: the same kernel, same context, same launches on a developed spot pattern (the chip
             # sustains a lower clock on non-trivial operands; BASELINE.md asks for "random/real data not zeros")
             run(sp_dev, args.warmup)
@@ -332,41 +297,45 @@ def main() -> int:
                          "roofline": {k: v for k, v in roofline_of(ms_dev, p_dev).items()
                                       if k in ("bound", "achieved", "peak", "unit", "frac", "frac_source", "valu", "useful_valu",
                                                "hbm_physical", "algorithmic_GBps", "launch_ms")}}
+        with stage("energy", 900):
             # informational: shader clock, socket power and energy per cell-step while the same kernel runs
             # (rocm-smi samples next to an untimed repeat of >= 3 s; the VALU roof is priced at the nominal
             # 2.4 GHz, the chip sustains less on its power limit), on both inputs
             long_steps = max(args.steps, int(3.2 * value * 1e6 / cells) // 12 * 12)
             clocks = sample_clock_and_power(lambda: timed_run(species, long_steps), local_rank, cells * long_steps)
             clocks_dev = sample_clock_and_power(lambda: timed_run(sp_dev, long_steps), local_rank, cells * long_steps)
-            # informational: the fused-tap flavour (GS_MATH_FUSED: bit-identical wherever no sub-normal
-            # intermediate occurs, |diff| <= 1e-37 elsewhere -- inside north_star's 1e-5 tolerance)
-            sim_c = Simulation.new(Parameters(), HipArgs(devices=[local_rank], math=capi.GS_MATH_FUSED))
-            species_c = sim_c.make_species([rows, cols])
-            sim_c.perform_steps(species_c, max(args.warmup, 400))
-            tc = time.perf_counter()
-            sim_c.perform_steps(species_c, args.steps)
-            tc = time.perf_counter() - tc
-            extra = {"kernel": sim_c.context.info()[0], "value": rows * cols * args.steps / tc / 1e6}
-            sim_c.context.close()
-            del species_c, sim_c
+    if single and args.extra:
+        with stage("fused", 600):
+            fused = fused_flavour_leg(rows, cols, args.steps, args.warmup, local_rank)
 
-    verified, single_step = None, None
+    verified, single_step, peer_chain = None, None, None
     if verify:
-        with wd.stage("verify", 900):
+        with stage("verify", 900):
             try:
                 if single:
-                    single_step, verified = verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, kernel_name)
+                    single_step, verified = verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, kernel_name,
+                                                              extra_placements=2 if args.extra else 0)
                 else:
                     verified = verify_slab_chain(sim, species, rows, cols, rank, world, local_rank, args.rehearsal)
             except Exception as e:                      # the line is still worth printing
                 verified = {"error": f"{type(e).__name__}: {e}"}
+    if world > 1 and not args.no_peer_chain:
+        # the other ranks wait at the barrier (their GPUs idle but for rank 0's slabs)
+        with stage("peer-chain", 900):
+            if rank == 0:
+                try:
+                    peer_chain = peer_chain_leg(rows, cols, world, args.steps, tuned, args.rehearsal)
+                except Exception as e:                  # a second figure, never the line's fate
+                    peer_chain = {"error": f"{type(e).__name__}: {e}"}
+            barrier()
+
     result = {
         # BASELINE.json's metric, verbatim; `value` is its first quantity, the `roofline` object
         # carries the second
         "metric": "Mcells×steps/s and achieved HBM GB/s (% of roofline), 16384² f32 grid",
         "value": value,                                   # the median of `repeats` timed regions
         "unit": "Mcells×steps/s",
-        "n_gpus": args.gpus,
+        "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": wall * 1e3 / args.steps,
@@ -390,31 +359,23 @@ def main() -> int:
             "workload": f"{rows}x{cols} f32 (rows x cols), Species::new init, default feed/kill, "
                         f"double-buffered U/V in HBM",
             "grid": [rows, cols],
-            "cells_per_gpu": cells // args.gpus,
+            "cells_per_gpu": cells // world,
             "kernel": kernel_name,
-            "tuned": {"rows_per_unit": tuned[0], "steps_per_pass": tuned[1], "cols_per_lane": tuned[2]},
+            "tuned": {"rows_per_unit": tuned[0], "steps_per_pass": tuned[1], "cols_per_lane": tuned[2],
+                      "share_taps": tuned[3] == 1 if tuned[3] else None},
             "launches_per_pass": 1 if single else 2,
-            "partition": "single GPU" if single else
-                         f"{args.gpus} row slabs, RCCL send/recv ghost rows",
+            "partition": "single GPU" if single else f"{world} row slabs, RCCL send/recv ghost rows",
         },
         "roofline": roofline,
+        # which HIP runtime and RCCL the library is bound to in this process (gs_runtime_info), and what carried the
+        # barriers: torch is imported first, so both are the copies the torch wheel bundles
+        "runtime": runtime,
     }
     if per_rank:
-        result["rccl_ranks"] = comm[0]
+        result["rccl_ranks"] = rccl_ranks
         result["ranks"] = per_rank
     if clocks:
-        roofline["sclk_MHz_under_load"] = clocks["sclk_MHz"]
-        roofline["socket_power_W_under_load"] = clocks["power_W"]
-        roofline["power_cap_W"] = clocks.get("power_cap_W")
-        if roofline["valu"] and roofline["bound"] == "valu-issue":
-            roofline["valu_at_sustained_clock"] = roofline["valu"] / (clocks["sclk_MHz"] / NOMINAL_SCLK_MHZ)
-        if clocks.get("energy_pJ_per_cell_step"):
-            result["energy_pJ_per_cell_step"] = clocks["energy_pJ_per_cell_step"]
-            roofline["energy_W_from_counter"] = clocks.get("energy_W")
-        cap, pw = clocks.get("power_cap_W"), clocks.get("energy_W") or clocks["power_W"]
-        if cap and pw and pw >= 0.96 * cap and roofline["bound"] == "valu-issue":
-            # the package sits on its power limit: what a faster instruction stream gains, the clock gives back
-            roofline["bound"] = "power-capped valu"
+        add_clocks(roofline, result, clocks)
     if developed is not None:
         result["value_developed_pattern"] = developed["value"]
         result["developed_pattern"] = developed
@@ -422,15 +383,15 @@ def main() -> int:
             developed["sclk_MHz_under_load"] = clocks_dev["sclk_MHz"]
             developed["socket_power_W_under_load"] = clocks_dev["power_W"]
             developed["energy_pJ_per_cell_step"] = clocks_dev.get("energy_pJ_per_cell_step")
-    if extra is not None:
-        result["fused_flavour"] = extra
-    if single_step is not None:
-        result["single_step"] = single_step
-    if verified is not None:
-        result["verified"] = verified
+    for key, leg in (("fused_flavour", fused), ("single_step", single_step), ("verified", verified), ("peer_chain", peer_chain)):
+        if leg is not None:
+            result[key] = leg
+    if ctx.stats().get("window_fallbacks"):
+        result["window_fallbacks"] = ctx.stats()["window_fallbacks"]     # a timing that contains one measured a stall
     if rank == 0 and single and not args.no_cpu_baseline:
-        with wd.stage("cpu_baseline", 600):
+        with stage("cpu_baseline", 600):
             result["cpu_baseline"] = cpu_baseline()
+    result["stage_seconds"] = stage_s
     if rank == 0:
         print(json.dumps(result, ensure_ascii=False), flush=True)
     with wd.stage("teardown", 120):

@@ -10,7 +10,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-from .harness import (BYTES_PER_CELL_STEP, HBM_COPY_CEILING_GBS, HBM_PEAK_GBS, usable_cpus)
+from .harness import (BYTES_PER_CELL_STEP, HBM_COPY_CEILING_GBS, HBM_PEAK_GBS, NOMINAL_SCLK_MHZ, USEFUL_VALU_PER_CELL_STEP,
+                      USEFUL_VALU_PER_CELL_STEP_SHARED, VALU_PEAK_TLANEOPS, usable_cpus)
 
 
 def cpu_baseline(target_seconds: float = 12.0):
@@ -213,7 +214,7 @@ def planes_equal(a, b) -> bool:
     return ok
 
 
-def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_kernel):
+def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_kernel, extra_placements=0):
     """In-run proof that the timed launches did the work, and the HBM-bound single-step leg north_star asks the
     rocprof evidence for.  A second context pinned to the single-step stream kernel (one launch = one step =
     one read and one write of U and V: 16 B per cell-step of HBM traffic) starts from the same Species::new,
@@ -260,7 +261,7 @@ def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_
     # which of three levels (~330 / 350 / 375 k at 16384^2) this HBM-bound kernel reads, from box to box and from one
     # Species to the next (profiles/r04_sweeps.md, section 8).  `value` above is the Species the replay uses.
     placements = [cells / (step_ms * 1e-3) / 1e6]        # (HIP-event rates, like the two below)
-    for _ in range(2):
+    for _ in range(extra_placements):
         extra = sim_s.make_species([rows, cols])
         sim_s.perform_steps(extra, n_region)
         r3 = []
@@ -272,6 +273,12 @@ def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_
         placements.append(statistics.median(r3))
         for c in extra.u._pair + extra.v._pair:
             c.destroy()
+    if getattr(sp_s, "placement", None):
+        first, best = sp_s.placement
+        single_step["placement"] = {"how": "gs_fields_place: best four of 4 + 4 candidate blocks, single-step probes",
+                                    "first_blocks_ms_per_step": first, "chosen_blocks_ms_per_step": best,
+                                    "first_blocks_frac_of_8TBps": BYTES_PER_CELL_STEP * cells / (first * 1e-3) / 1e9 / HBM_PEAK_GBS if first else None,
+                                    "chosen_blocks_frac_of_8TBps": BYTES_PER_CELL_STEP * cells / (best * 1e-3) / 1e9 / HBM_PEAK_GBS if best else None}
     single_step["by_plane_placement"] = [round(x) for x in placements]
     single_step["frac_of_8TBps_best_placement"] = max(placements) * 1e6 * BYTES_PER_CELL_STEP / 1e9 / HBM_PEAK_GBS
     left = species.steps_done - sp_s.steps_done
@@ -290,3 +297,96 @@ def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_
         verified["developed_pattern"] = {"steps": sp_dev.steps_done,
                                          "equal": planes_equal(a[0], b[0]) and planes_equal(a[1], b[1])}
     return single_step, verified
+
+
+def useful_valu_per_cell_step(kernel_name: str) -> int:
+    """Arithmetic instructions per cell-step of the kernel's form of the reference's update, each operation one
+    instruction: 53 as the reference writes it (compute/naive/src/lib.rs:63-79), 46 with full difference sharing at 2
+    columns per lane (the `.ds` variants: the N / NW / NE taps are the negated S / SE / SW taps of the row above)."""
+    return USEFUL_VALU_PER_CELL_STEP_SHARED if ".ds" in kernel_name else USEFUL_VALU_PER_CELL_STEP
+
+
+def roofline_object(event_ms, passes, steps_per_launch, cells_per_gpu, pmc, valu_insts, valu_how, kernel_name):
+    """The roofline object of one timed region: its own launch time (HIP events on the library's stream), the committed
+    profile's counters (`pmc`: measured_counters(); `valu_insts`, `valu_how`: scaled_valu_insts())."""
+    launch_s = event_ms * 1e-3 / passes
+    algo_bytes = BYTES_PER_CELL_STEP * cells_per_gpu * steps_per_launch
+    algo_gbs = algo_bytes / launch_s / 1e9
+    traffic = pmc.get("traffic")
+    hbm_physical = traffic / launch_s / 1e9 / HBM_PEAK_GBS if traffic else None
+    valu_rate = valu_insts * 64 / launch_s / 1e12 if valu_insts else None
+    useful = useful_valu_per_cell_step(kernel_name)
+    useful_rate = useful * cells_per_gpu * steps_per_launch / launch_s / 1e12
+    # Which roof binds: with K >= 3 steps fused per HBM pass the kernel moves ~16 B per cell for K
+    # steps and is bound by VALU issue; a single-step pass is bound by HBM.
+    valu_bound = steps_per_launch >= 3
+    if valu_bound:
+        # issued VALU lane-instructions (PMC SQ_INSTS_VALU x 64, committed profile of this layout) per
+        # launch time against the chip's plain-f32 issue rate; without a matching profile, the useful
+        # instructions alone (computed from this run: a lower bound of what was issued)
+        achieved = valu_rate if valu_rate else useful_rate
+        frac = achieved / VALU_PEAK_TLANEOPS
+    else:
+        achieved = traffic / launch_s / 1e9 if traffic else algo_gbs
+        frac = hbm_physical if hbm_physical else algo_gbs / HBM_PEAK_GBS
+    return {
+        "bound": "valu-issue" if valu_bound else "hbm",
+        "achieved": achieved,
+        "peak": VALU_PEAK_TLANEOPS if valu_bound else HBM_PEAK_GBS,
+        "unit": "T lane-ops/s" if valu_bound else "GB/s",
+        "frac": frac,
+        "frac_source": (valu_how if valu_rate else "useful instructions only (no profile of this layout committed)")
+                       if valu_bound else ("PMC traffic" if traffic else "algorithmic bytes"),
+        "valu": valu_rate / VALU_PEAK_TLANEOPS if valu_rate else None,
+        "useful_valu": useful_rate / VALU_PEAK_TLANEOPS,
+        "useful_valu_per_cell_step": useful,
+        "hbm_physical": hbm_physical,
+        # SURVEY section 8(d)'s algorithmic figure (16 B per cell-step): a throughput in GB/s-equivalents,
+        # NOT a fraction of the HBM roof once K steps share one HBM pass (it exceeds the peak by design)
+        "algorithmic_GBps": algo_gbs,
+        "algorithmic_frac": algo_gbs / HBM_PEAK_GBS,
+        "algorithmic_frac_of_copy_ceiling": algo_gbs / HBM_COPY_CEILING_GBS,
+        "launch_ms": launch_s * 1e3,
+        # rocprofv3's average duration of the same kernel in the committed profile (profiling lowers clocks)
+        "profile_launch_ms": pmc.get("launch_ms"),
+        "launches": passes,
+        "steps_per_launch": steps_per_launch,
+        "algorithmic_bytes_per_launch": algo_bytes,
+        "traffic": traffic,                      # HBM bytes per launch, PMC (null: not profiled)
+        "valu_insts_per_launch": valu_insts,     # SQ_INSTS_VALU per launch, PMC (null: not profiled)
+        "counters_source": pmc.get("source"),
+        "counters_layout": ({"rows_per_unit": pmc.get("rows_per_unit"), "steps_per_pass": pmc.get("steps_per_pass"),
+                             "cols_per_lane": pmc.get("cols_per_lane")} if pmc else None),
+    }
+
+
+def add_clocks(roofline, result, clocks):
+    """Fold a sample_clock_and_power() result into the roofline object (and name the bound from it)."""
+    roofline["sclk_MHz_under_load"] = clocks["sclk_MHz"]
+    roofline["socket_power_W_under_load"] = clocks["power_W"]
+    roofline["power_cap_W"] = clocks.get("power_cap_W")
+    if roofline["valu"] and roofline["bound"] == "valu-issue":
+        roofline["valu_at_sustained_clock"] = roofline["valu"] / (clocks["sclk_MHz"] / NOMINAL_SCLK_MHZ)
+    if clocks.get("energy_pJ_per_cell_step"):
+        result["energy_pJ_per_cell_step"] = clocks["energy_pJ_per_cell_step"]
+        roofline["energy_W_from_counter"] = clocks.get("energy_W")
+    cap, pw = clocks.get("power_cap_W"), clocks.get("energy_W") or clocks["power_W"]
+    if cap and pw and pw >= 0.96 * cap and roofline["bound"] == "valu-issue":
+        # the package sits on its power limit: what a faster instruction stream gains, the clock gives back
+        roofline["bound"] = "power-capped valu"
+
+
+def fused_flavour_leg(rows, cols, steps, warmup, device):
+    """Informational: the fused-tap flavour (GS_MATH_FUSED: bit-identical wherever no sub-normal intermediate
+    occurs, |diff| <= 1e-37 elsewhere -- inside north_star's 1e-5 tolerance) on the same grid."""
+    from grayscott_amd import HipArgs, Parameters, Simulation, capi
+
+    sim_c = Simulation.new(Parameters(), HipArgs(devices=[device], math=capi.GS_MATH_FUSED))
+    species_c = sim_c.make_species([rows, cols])
+    sim_c.perform_steps(species_c, max(warmup, 400))
+    tc = time.perf_counter()
+    sim_c.perform_steps(species_c, steps)
+    tc = time.perf_counter() - tc
+    out = {"kernel": sim_c.context.info()[0], "value": rows * cols * steps / tc / 1e6}
+    sim_c.context.close()
+    return out

@@ -38,7 +38,7 @@ EXPORTS = (
     "gs_host_alloc", "gs_host_free", "gs_field_download_async", "gs_download_wait",
     "gs_ctx_get_tuned", "gs_ctx_set_tuned", "gs_ctx_comm_info", "gs_field_colormap",
     "gs_ctx_stats", "gs_ctx_set_pass_timing", "gs_field_mark_written", "gs_rccl_selftest",
-    "gs_runtime_info", "gs_debug_dyn_lds_key", "gs_debug_window_plan",
+    "gs_runtime_info", "gs_fields_place", "gs_debug_dyn_lds_key", "gs_debug_window_plan",
 )
 
 
@@ -155,6 +155,7 @@ def load() -> ctypes.CDLL:
         "gs_field_mark_written": (i32, [vp, vp]),
         "gs_rccl_selftest": (i32, [i32, u64]),
         "gs_runtime_info": (i32, [i32, ctypes.c_char_p, ctypes.c_size_t]),
+        "gs_fields_place": (i32, [vp, P(vp), i32, P(f32), P(f32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -719,7 +719,7 @@ std::vector<GsWindowDesc> plan_windows(int cu_count, bool zero_halo, bool cheap,
     const long tiles_c = (long)((cols + wo - 1) / wo);
     int forced[3] = {0, 0, 0};
     if (const char *e = std::getenv("GS_HIP_WINDOW_WAVES")) (void)std::sscanf(e, "%d,%d,%d", &forced[0], &forced[1], &forced[2]);
-    for (int rpw : {5, 6}) {
+    for (int rpw : {5}) { // rows per wave: 80-row windows (gs_launch_window)
         if (want_rpw > 0 && want_rpw != rpw) continue;
         const int min_waves = (2 * k + rpw) / rpw; // at least one owned row
         plan.clear();
@@ -1794,6 +1794,120 @@ int32_t gs_field_create(gs_ctx *ctx, gs_field **out, uint64_t rows, uint64_t col
     if (st != GS_OK) { gs_field_destroy(ctx, f); return st; }
     f->ghost_depth = kGhostRows; // all zeros, ghosts included
     *out = f;
+    return GS_OK;
+}
+
+// Placement by measurement (gs_hip.h).  Where an allocation lands in HBM is below what a process controls (physical
+// frames, the channel hash over high address bits), and four 1 GiB planes land on one of three levels for the HBM-bound
+// single-step kernel -- 0.66 / 0.70 / 0.75 of 8 TB/s at 16384^2, from one context to the next (profiles/r04_sweeps.md,
+// section 8).  What a process CAN do is draw more blocks than it needs and keep the four that read best together.
+int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidates, float *first_ms, float *best_ms)
+{
+    if (!ctx || !planes) return fail(GS_ERR_INVALID, "null argument");
+    if (candidates < 1 || candidates > 12) return fail(GS_ERR_INVALID, "1 to 12 extra candidate blocks, not %d", candidates);
+    if (ctx->total_slabs() != 1) return fail(GS_ERR_UNSUPPORTED, "placement by measurement is for single-slab contexts");
+    for (int i = 0; i < 4; ++i) {
+        if (!planes[i] || planes[i]->ctx != ctx) return fail(GS_ERR_INVALID, "bad plane %d", i);
+        GS_TRY(same_shape(planes[0], planes[i]));
+        for (int j = 0; j < i; ++j)
+            if (planes[i] == planes[j]) return fail(GS_ERR_INVALID, "the four planes must be distinct");
+    }
+    if (first_ms) *first_ms = 0.0f;
+    if (best_ms) *best_ms = 0.0f;
+    const gs_field *f0 = planes[0];
+    if (f0->rows == 0 || f0->cols == 0) return GS_OK;
+    GS_TRY(sync_all(ctx));
+    SlabRt &sl = ctx->slabs[0];
+    GS_HIP(hipSetDevice(sl.device));
+    const size_t pitch = (size_t)f0->pitch;
+    const size_t n = (size_t)(f0->s[0].rows + 2 * kGhostRows) * pitch + 2 * kGuardFloats;
+    const int total = 4 + candidates;
+    std::vector<float *> blocks;
+    for (int i = 0; i < 4; ++i) blocks.push_back(planes[i]->s[0].alloc);
+    auto release = [&](int keep_from) { // frees the blocks from index keep_from on
+        for (size_t i = (size_t)keep_from; i < blocks.size(); ++i)
+            if (blocks[i]) (void)hipFree(blocks[i]);
+        blocks.resize((size_t)keep_from);
+    };
+    for (int i = 4; i < total; ++i) {
+        float *b = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&b), n * sizeof(float)) != hipSuccess) { // fewer candidates: fine
+            (void)hipGetLastError();
+            break;
+        }
+        blocks.push_back(b);
+    }
+    const int have = (int)blocks.size();
+    // zeros everywhere (what gs_field_create leaves; the four planes come out zero-filled whichever blocks they get)
+    for (float *b : blocks) {
+        const hipError_t e = hipMemsetAsync(b, 0, n * sizeof(float), sl.compute);
+        if (e != hipSuccess) { release(4); return fail(GS_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e)); }
+    }
+    auto row0_of = [&](float *b) { return b + kGuardFloats + (size_t)kGhostRows * pitch; };
+    // a probe: four single steps ping-ponging between (a, b) and (c, d), timed with the context's events
+    GsStepArgs base = make_args(ctx, planes[0], planes[1], planes[2], planes[3], 0, 1);
+    base.ra0 = 0;
+    base.ra1 = base.rows;
+    const bool fused = ctx->o.math == GS_MATH_FUSED;
+    auto probe = [&](const int (&pick)[4], float *ms) -> int32_t {
+        float *p[4];
+        for (int i = 0; i < 4; ++i) p[i] = row0_of(blocks[(size_t)pick[i]]);
+        for (int rep = 0; rep < 5; ++rep) { // the first step is not timed
+            if (rep == 1) GS_HIP(hipEventRecord(sl.t0, sl.compute));
+            GsStepArgs a = base;
+            const int in = (rep & 1) * 2, out = 2 - in;
+            a.in_u = p[in]; a.in_v = p[in + 1]; a.out_u = p[out]; a.out_v = p[out + 1];
+            const char *name = nullptr;
+            const hipError_t e = fused ? gs_launch_stream_fused(a, sl.compute, &name) : gs_launch_stream_strict(a, sl.compute, &name);
+            if (e != hipSuccess) return fail(GS_ERR_HIP, "probe launch failed: %s", hipGetErrorString(e));
+        }
+        GS_HIP(hipEventRecord(sl.t1, sl.compute));
+        GS_HIP(hipEventSynchronize(sl.t1));
+        GS_HIP(hipEventElapsedTime(ms, sl.t0, sl.t1));
+        return GS_OK;
+    };
+    int best[4] = {0, 1, 2, 3};
+    float best_t = 0.0f, first_t = 0.0f;
+    // the four that are there, then pseudo-random 4-subsets of the pool (a fixed sequence: the same candidates every time)
+    uint32_t rng = 0x9e3779b9u;
+    const int trials = have > 4 ? 3 * have : 1;
+    for (int t = 0; t < trials; ++t) {
+        int pick[4] = {0, 1, 2, 3};
+        if (t > 0) {
+            int order[16];
+            for (int i = 0; i < have; ++i) order[i] = i;
+            for (int i = 0; i < 4; ++i) { // partial Fisher-Yates
+                rng = rng * 1664525u + 1013904223u;
+                const int j = i + (int)((rng >> 8) % (uint32_t)(have - i));
+                std::swap(order[i], order[j]);
+                pick[i] = order[i];
+            }
+        }
+        float ms = 0.0f;
+        const int32_t st = probe(pick, &ms);
+        if (st != GS_OK) { release(4); return st; }
+        if (t == 0) first_t = ms;
+        if (t == 0 || ms < 0.995f * best_t) { best_t = ms; std::memcpy(best, pick, sizeof best); }
+    }
+    // hand the chosen blocks to the planes; the probes have written into every block: zeros again
+    std::vector<float *> chosen(4);
+    for (int i = 0; i < 4; ++i) chosen[(size_t)i] = blocks[(size_t)best[i]];
+    for (int i = 0; i < 4; ++i) {
+        FieldSlab &fs = planes[i]->s[0];
+        fs.alloc = chosen[(size_t)i];
+        fs.row0 = row0_of(fs.alloc);
+        planes[i]->ghost_depth = kGhostRows;
+        GS_HIP(hipMemsetAsync(fs.alloc, 0, n * sizeof(float), sl.compute));
+    }
+    GS_HIP(hipStreamSynchronize(sl.compute));
+    for (float *b : blocks) {
+        bool used = false;
+        for (float *c : chosen) used = used || c == b;
+        if (!used) (void)hipFree(b);
+    }
+    (void)hipGetLastError();
+    if (first_ms) *first_ms = first_t / 4.0f;
+    if (best_ms) *best_ms = best_t / 4.0f;
     return GS_OK;
 }
 

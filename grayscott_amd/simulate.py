@@ -49,6 +49,14 @@ def parse(argv=None):
     be.add_argument("--hip-fuse-steps", type=int, default=None, help="time steps fused per pass over HBM, 1..4, 0 = chosen on line [GS_HIP_FUSE_STEPS]")
     be.add_argument("--hip-cols-per-lane", type=int, default=None, help="columns per lane: 4, 2 or 1, 0 = chosen on line [GS_HIP_COLS_PER_LANE]")
     be.add_argument("--hip-no-tune", type=int, default=None, help="1 = never time candidate configurations inside perform_steps [GS_HIP_NO_TUNE]")
+    be.add_argument("--hip-kernel", type=int, default=None, help="step kernel (gs_kernel in gs_hip.h), 0 = by grid size and call length [GS_HIP_KERNEL]")
+    be.add_argument("--hip-boundary", type=int, default=None, help="0 = compute_naive's clipped window, 1 = zero halo (the SIMD / Vulkan backends' rule) [GS_HIP_BOUNDARY]")
+    be.add_argument("--hip-general-kernels", type=int, default=None, help="1 = never run the variants specialised for the default stencil and time step [GS_HIP_GENERAL_KERNELS]")
+    be.add_argument("--hip-share-taps", type=int, default=None, help="full difference sharing: 0 = chosen on line, 1 = on, 2 = off [GS_HIP_SHARE_TAPS]")
+    be.add_argument("--hip-split", type=int, default=None, help="row bands a single slab is scheduled as [GS_HIP_SPLIT]")
+    be.add_argument("--hip-use-graph", type=int, default=None, help="1 = replay batches of 16 passes through a hipGraph [GS_HIP_USE_GRAPH]")
+    be.add_argument("--hip-tile-shape", type=int, default=None, help="window of the LDS-window kernel: 1 = 32x64, 2 = 16x64, 3 = 64x64 [GS_HIP_TILE_SHAPE]")
+    be.add_argument("--hip-pitch-pad", type=int, default=None, help="extra f32 of row pitch [GS_HIP_PITCH_PAD]")
     return ap.parse_args(argv)
 
 
@@ -57,8 +65,9 @@ def backend_args(args) -> HipArgs:
     h = HipArgs()
     if getattr(args, "hip_devices", None):
         h.devices = [int(x) for x in str(args.hip_devices).split(",") if x != ""]
-    for flag, name in (("hip_math", "math"), ("hip_rows_per_block", "rows_per_block"), ("hip_fuse_steps", "fuse_steps"),
-                       ("hip_cols_per_lane", "cols_per_lane"), ("hip_no_tune", "no_tune")):
+    for name in ("math", "rows_per_block", "fuse_steps", "cols_per_lane", "no_tune", "kernel", "boundary", "general_kernels",
+                 "share_taps", "split", "use_graph", "tile_shape", "pitch_pad"):
+        flag = "hip_" + name
         value = getattr(args, flag, None)
         if value is not None:
             setattr(h, name, value)

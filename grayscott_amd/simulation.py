@@ -406,10 +406,25 @@ class Species:
         self._context, self.u, self.v = context, u, v
 
     @classmethod
-    def new(cls, context: HipContext, shape: Sequence[int]) -> "Species":
+    def new(cls, context: HipContext, shape: Sequence[int], place_candidates: int = 0) -> "Species":
+        """``Species::new`` (data/src/concentration/mod.rs:36-59).  ``place_candidates`` > 0 (not in the reference): the
+        four planes are first given the best of 4 + n candidate allocations as the single-step kernel measures them
+        (``gs_fields_place``); ``placement`` then holds (ms per step of the first four blocks, of the chosen four)."""
         shape = (int(shape[0]), int(shape[1]))
-        u = Evolving.ones_out(context, shape)
-        v = Evolving.zeros_out(context, shape)
+        placement = None
+        if place_candidates > 0:
+            planes = [HipConcentration(context, shape) for _ in range(4)]
+            arr = (ctypes.c_void_p * 4)(*[p.handle for p in planes])
+            first, best = ctypes.c_float(0), ctypes.c_float(0)
+            capi.check(context._lib.gs_fields_place(context.handle, arr, int(place_candidates), ctypes.byref(first),
+                                                    ctypes.byref(best)))
+            placement = (float(first.value), float(best.value))
+            u, v = Evolving([planes[0], planes[2]]), Evolving([planes[1], planes[3]])
+            # as Evolving.ones_out / zeros_out: the OUTPUT slot is what Species::new fills (U = 1, V = 0)
+            capi.check(context._lib.gs_field_fill(context.handle, u.out().handle, 1.0))
+        else:
+            u = Evolving.ones_out(context, shape)
+            v = Evolving.zeros_out(context, shape)
         num_range, frac, row_shift = (7, 8), 16, 4
         sl = []
         for i in (0, 1):
@@ -420,6 +435,7 @@ class Species:
         v.out().fill_slice(context, sl, 1.0)
         s = cls(context, u, v)
         s.flip()
+        s.placement = placement
         return s
 
     def context(self) -> HipContext:
@@ -470,9 +486,9 @@ class Simulation:
         """``SimulateCreate::new(params, args)`` (compute/shared/src/lib.rs:42-45)."""
         return cls(params, args)
 
-    def make_species(self, shape: Sequence[int]) -> Species:
+    def make_species(self, shape: Sequence[int], place_candidates: int = 0) -> Species:
         """``SimulateBase::make_species`` (lib.rs:33-34)."""
-        return Species.new(self.context, shape)
+        return Species.new(self.context, shape, place_candidates)
 
     def perform_steps(self, species: Species, steps: int) -> None:
         """``Simulate::perform_steps`` (lib.rs:48-58): ``steps`` steps; on return they are DONE and

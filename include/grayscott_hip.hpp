@@ -72,7 +72,7 @@ struct Parameters {
 struct HipArgs {
     std::vector<int32_t> devices{0};
     int32_t math = GS_MATH_STRICT, kernel = GS_KERNEL_AUTO, rows_per_block = 0, fuse_steps = 0, cols_per_lane = 0;
-    int32_t boundary = GS_BOUNDARY_CLIPPED, no_tune = 0;
+    int32_t boundary = GS_BOUNDARY_CLIPPED, no_tune = 0, share_taps = 0, general_kernels = 0;
 };
 
 // Concentration::Context: owner of the gs_ctx.
@@ -90,6 +90,8 @@ class HipContext {
         o.cols_per_lane = args.cols_per_lane;
         o.boundary = args.boundary;
         o.no_tune = args.no_tune;
+        o.share_taps = args.share_taps;
+        o.general_kernels = args.general_kernels;
         check(gs_ctx_create(&ctx_, &p, &o, args.devices.data(), (int32_t)args.devices.size(), 0, 1, nullptr));
     }
     ~HipContext() { gs_ctx_destroy(ctx_); }

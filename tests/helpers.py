@@ -63,3 +63,29 @@ def assert_bits_equal(got: np.ndarray, ref: np.ndarray, what: str):
         raise AssertionError(
             f"{what}: {bad.size} of {got.size} cells differ; first at ({r},{c}): "
             f"got {got[r, c]!r} ref {ref[r, c]!r}; max|d|={float(np.max(np.abs(got - ref)))}")
+
+
+_handed_out = set()
+
+
+def free_port() -> int:
+    """A port nobody listens on and that this test process has not handed out before: the kernel gives a closed
+    ephemeral port out again at once, and the rendezvous store of the previous test may still hold it (EADDRINUSE in
+    the next test's TCPStore, seen once on the GPU box)."""
+    import os
+    import random
+    import socket
+
+    rng = random.Random(os.getpid() * 7919 + len(_handed_out))
+    for _ in range(200):
+        port = rng.randrange(20000, 45000)
+        if port in _handed_out:
+            continue
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+        _handed_out.add(port)
+        return port
+    raise RuntimeError("no free port found")

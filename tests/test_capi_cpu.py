@@ -133,6 +133,7 @@ def test_named_stencils_match_the_reference_constants():
 def test_simulate_driver_flattens_the_backend_flags(monkeypatch):
     """ui/src/lib.rs:43-45 flattens the backend's CliArgs into the command line; the Python driver mirrors the Rust
     shim's names (rust/compute_hip/src/lib.rs) and keeps the environment defaults for what is not given."""
+    from grayscott_amd import capi
     from grayscott_amd import simulate as driver
 
     monkeypatch.setenv("GS_HIP_FUSE_STEPS", "3")
@@ -142,7 +143,11 @@ def test_simulate_driver_flattens_the_backend_flags(monkeypatch):
     h = driver.backend_args(driver.parse(["--hip-devices", "0,0", "--hip-fuse-steps", "2", "--hip-math", "1", "--hip-no-tune", "1"]))
     assert list(h.devices) == [0, 0] and (h.fuse_steps, h.math, h.no_tune) == (2, 1, 1)
     shim = open(os.path.join(ROOT, "rust", "compute_hip", "src", "lib.rs")).read()
-    for flag in ("hip_devices", "hip_math", "hip_rows_per_block", "hip_fuse_steps", "hip_cols_per_lane", "hip_no_tune"):
+    h = driver.backend_args(driver.parse(["--hip-boundary", "1", "--hip-share-taps", "2", "--hip-kernel", "3"]))
+    assert (h.boundary, h.share_taps, h.kernel) == (1, 2, 3)
+    flags = ["hip_devices"] + ["hip_" + f for f, _ in capi.GsOptions._fields_ if f != "reserved"]
+    assert len(flags) == 14
+    for flag in flags:
         assert f"pub {flag}:" in shim, flag
         assert hasattr(driver.parse([]), flag), flag
 

@@ -294,9 +294,9 @@ def test_two_slab_chain_2000_steps_of_a_developing_pattern(built):
 # ---- N processes over the transport double -------------------------------------------------------------
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from tests.helpers import free_port
+
+    return free_port()
 
 
 def _worker(rank, world, port, rows, cols, local_slabs, out_dir, transport_lib):

@@ -154,17 +154,15 @@ def test_species_new_and_a_developing_pattern_at_a_few_megacells():
     v0 += rng.random(v0.shape, dtype=np.float32) * np.float32(0.01)
     outs = []
     for share in (1, 2):
-        # (6-row units: more than one round of wave slots, or the launch would take the in-step 16-wave form, which has
-        # no sharing variant -- 148 registers do not fit 16 waves per CU)
-        sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_TB, cols_per_lane=2, share_taps=share, no_tune=1,
-                                                rows_per_block=6))
+        # (a launch of one round of wave slots: the in-step form, 16-wave workgroups with 132 KB of halo boards)
+        sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_TB, cols_per_lane=2, share_taps=share, no_tune=1))
         sp_new = sim.make_species([rows, cols])
         sp_dev = species_from_arrays(sim, u0, v0)
         for n in (197, 3, 400):
             sim.perform_steps(sp_new, n)
         sim.perform_steps(sp_dev, 400)
         label = sim.context.info()[0]
-        assert (".op.ds" in label) == (share == 1), label
+        assert (".op.ds" in label) == (share == 1) and label.startswith("tb-k4c2f/"), label
         outs.append([x.make_scalar_view(sim.context) for x in sp_new.in_out()[:2] + sp_dev.in_out()[:2]])
         sim.context.close()
     for a, b, what in zip(outs[0], outs[1], ("new U", "new V", "pattern U", "pattern V")):

@@ -74,8 +74,8 @@ def _seeded(rows, cols):
 
 
 def _assert_production(label):
-    # the default schedule, tuned: "tb-k<K>[c<cpl>]/strict.op@<rows>x<bands>"
-    assert label.startswith("tb-k") and "/strict.op@" in label, label
+    # the default schedule, tuned: "tb-k<K>[c<cpl>]/strict.op[.ds]@<rows>x<bands>" (.ds: full difference sharing)
+    assert label.startswith("tb-k") and ("/strict.op@" in label or "/strict.op.ds@" in label), label
 
 
 def test_default_schedule_16384_403_steps_vs_stream_kernel():

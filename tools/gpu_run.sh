@@ -17,7 +17,7 @@
 #   criterion       tools/criterion_grid.py
 #   rehearsal       tools/rehearsal.sh
 #   py:SCRIPT[:args]  any python tool of this repository
-#   pytest:FILE[,FILE...][:K-EXPRESSION]   some GPU test files (fast failure before a long run)
+#   pytest:FILE[,FILE...][:K+EXPRESSION]   some GPU test files (fast failure before a long run; + stands for a blank in -k)
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
@@ -85,7 +85,7 @@ for stage in "$@"; do
       timeout -k 10 1100 bash tools/rehearsal.sh > "$OUT/rehearsal.log" 2>&1; rc=$?; tail -12 "$OUT/rehearsal.log" ;;
     pytest)
       IFS=: read -r files kexpr <<< "$rest"
-      timeout -k 10 1100 python -m pytest ${files//,/ } -m gpu -x -q ${kexpr:+-k "$kexpr"} > "$OUT/pytest_some.log" 2>&1; rc=$?; tail -15 "$OUT/pytest_some.log" ;;
+      timeout -k 10 1100 python -m pytest ${files//,/ } -m gpu -x -q ${kexpr:+-k "${kexpr//+/ }"} > "$OUT/pytest_some.log" 2>&1; rc=$?; tail -15 "$OUT/pytest_some.log" ;;
     py)
       IFS=: read -r script pyargs <<< "$rest"
       timeout -k 10 900 python "$script" ${pyargs//,/ } > "$OUT/$(basename "$script" .py).log" 2>&1; rc=$?; tail -40 "$OUT/$(basename "$script" .py).log" ;;
