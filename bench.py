@@ -175,8 +175,8 @@ def main() -> int:
         if single and verify:
             sim_s = Simulation.new(Parameters(), HipArgs(devices=[local_rank], kernel=capi.GS_KERNEL_STREAM))
             # placement by measurement (gs_fields_place): the HBM-bound single-step kernel reads at one of three levels
-            # depending on where its four planes land; the replay's Species takes the best four of eight blocks
-            sp_s = sim_s.make_species([rows, cols], place_candidates=0 if cells < (1 << 26) else 4)
+            # depending on where its four planes land; the replay's Species takes the best four of sixteen blocks
+            sp_s = sim_s.make_species([rows, cols], place_candidates=0 if cells < (1 << 26) else 12)
             sp_s.steps_done = 0
         if with_extra:
             u0, v0 = developed_start(rows, cols)

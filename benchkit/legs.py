@@ -275,7 +275,7 @@ def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_
             c.destroy()
     if getattr(sp_s, "placement", None):
         first, best = sp_s.placement
-        single_step["placement"] = {"how": "gs_fields_place: best four of 4 + 4 candidate blocks, single-step probes",
+        single_step["placement"] = {"how": "gs_fields_place: best four of 4 + 12 candidate blocks, single-step probes",
                                     "first_blocks_ms_per_step": first, "chosen_blocks_ms_per_step": best,
                                     "first_blocks_frac_of_8TBps": BYTES_PER_CELL_STEP * cells / (first * 1e-3) / 1e9 / HBM_PEAK_GBS if first else None,
                                     "chosen_blocks_frac_of_8TBps": BYTES_PER_CELL_STEP * cells / (best * 1e-3) / 1e9 / HBM_PEAK_GBS if best else None}

@@ -1887,7 +1887,28 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
         const int32_t st = probe(pick, &ms);
         if (st != GS_OK) { release(4); return st; }
         if (t == 0) first_t = ms;
+        static const bool trace = gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1) != 0;
+        if (trace)
+            std::fprintf(stderr, "gs_hip placement: blocks %2d %2d %2d %2d (%p %p %p %p): %.4f ms per step\n", pick[0], pick[1], pick[2],
+                         pick[3], (void *)blocks[(size_t)pick[0]], (void *)blocks[(size_t)pick[1]], (void *)blocks[(size_t)pick[2]],
+                         (void *)blocks[(size_t)pick[3]], ms / 4.0f);
         if (t == 0 || ms < 0.995f * best_t) { best_t = ms; std::memcpy(best, pick, sizeof best); }
+    }
+    // one sweep of single-block exchanges around the best set found: every member against every block outside it
+    if (have > 4) {
+        for (int i = 0; i < 4; ++i)
+            for (int b = 0; b < have; ++b) {
+                bool member = false;
+                for (int j = 0; j < 4; ++j) member = member || best[j] == b;
+                if (member) continue;
+                int pick[4];
+                std::memcpy(pick, best, sizeof pick);
+                pick[i] = b;
+                float ms = 0.0f;
+                const int32_t st = probe(pick, &ms);
+                if (st != GS_OK) { release(4); return st; }
+                if (ms < 0.995f * best_t) { best_t = ms; std::memcpy(best, pick, sizeof best); }
+            }
     }
     // hand the chosen blocks to the planes; the probes have written into every block: zeros again
     std::vector<float *> chosen(4);

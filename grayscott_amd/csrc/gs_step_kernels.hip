@@ -1396,7 +1396,12 @@ __global__ __launch_bounds__(kTileWaves * 64) void GS_SUFFIX(gs_run_tile_k)(GsSt
 // grid's first and last row) under the clipped rule and interior code over zeros under the zero-halo rule.
 // ------------------------------------------------------------------------------------
 constexpr int kWinCols = 128;              // window columns: 64 lanes x 2
-constexpr int kWinPitch = 132;             // floats per published row: window column c at index 2 + c, c = -1 ... 129
+// floats per published row: two arrays of 66 -- the lanes' first columns (window column 2 l at element 1 + l), then their
+// second columns (2 l + 1 at 66 + 1 + l) -- so that a lane's own columns and the two next to them are two conflict-free
+// ds_read2_b32 (first columns of lanes l, l + 1; second columns of lanes l - 1, l).  (Round 4 kept a row in column order
+// and read a float2 and two odd-offset scalars: 37 % of the LDS pipe's active cycles were bank conflicts.)
+constexpr int kWinHalf = 66;
+constexpr int kWinPitch = 2 * kWinHalf;
 constexpr int kWinWaves = 16;
 __host__ __device__ constexpr int win_rows(int rpw) { return kWinWaves * rpw; }
 // 2 buffers x 2 species x 16 waves x (first row, last row) x pitch
@@ -1416,7 +1421,8 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
     constexpr bool ROWS = EDGE == 1 || EDGE == 4 || EDGE == 5 || EDGE == 6;
     constexpr int SIDE = (EDGE == 2 || EDGE == 5) ? 2 : ((EDGE == 3 || EDGE == 6) ? 3 : 0);
     // row `which` (0 = first, 1 = last row of a wave's band) of wave w, species sp, buffer buf
-    auto row_of = [&](int buf, int sp, int w, int which) { return lds + ((((buf * 2 + sp) * kWinWaves + w) * 2 + which) * P) + 2 + 2 * lane; };
+    // (element of this lane's FIRST column; its second column is kWinHalf further on)
+    auto row_of = [&](int buf, int sp, int w, int which) { return lds + ((((buf * 2 + sp) * kWinWaves + w) * 2 + which) * P) + 1 + lane; };
     // cells outside the grid are zeros and stay zeros: rows are wave-uniform (scalar tests), columns per lane
     bool col_in[2];
     uint32_t la[2], ra[2];
@@ -1472,10 +1478,11 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
     };
     // the first and the last row of this wave's band, for the waves above and below
     auto publish = [&](int buf) {
-        *reinterpret_cast<float2 *>(row_of(buf, 0, wave, 0)) = make_float2(u[0][0], u[0][1]);
-        *reinterpret_cast<float2 *>(row_of(buf, 1, wave, 0)) = make_float2(v[0][0], v[0][1]);
-        *reinterpret_cast<float2 *>(row_of(buf, 0, wave, 1)) = make_float2(u[RPW - 1][0], u[RPW - 1][1]);
-        *reinterpret_cast<float2 *>(row_of(buf, 1, wave, 1)) = make_float2(v[RPW - 1][0], v[RPW - 1][1]);
+        auto put = [](float *p, float c0, float c1) { p[0] = c0; p[kWinHalf] = c1; }; // one ds_write2_b32
+        put(row_of(buf, 0, wave, 0), u[0][0], u[0][1]);
+        put(row_of(buf, 1, wave, 0), v[0][0], v[0][1]);
+        put(row_of(buf, 0, wave, 1), u[RPW - 1][0], u[RPW - 1][1]);
+        put(row_of(buf, 1, wave, 1), v[RPW - 1][0], v[RPW - 1][1]);
     };
     // A step: publish, the rows that need nothing from other waves (the other waves' rows arrive meanwhile), barrier, the
     // rows above and below from LDS, the band's first and last row.  (Reads first and the publish for the next step
@@ -1501,14 +1508,12 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
         __syncthreads();
         RowT<2> above, below;
         {
-            const float *pu = row_of(buf, 0, wa, 1), *pv = row_of(buf, 1, wa, 1);
-            const float2 cu = *reinterpret_cast<const float2 *>(pu), cv = *reinterpret_cast<const float2 *>(pv);
-            above.u[0] = pu[-1]; above.u[1] = cu.x; above.u[2] = cu.y; above.u[3] = pu[2];
-            above.v[0] = pv[-1]; above.v[1] = cv.x; above.v[2] = cv.y; above.v[3] = pv[2];
-            const float *qu = row_of(buf, 0, wb, 0), *qv = row_of(buf, 1, wb, 0);
-            const float2 du = *reinterpret_cast<const float2 *>(qu), dv = *reinterpret_cast<const float2 *>(qv);
-            below.u[0] = qu[-1]; below.u[1] = du.x; below.u[2] = du.y; below.u[3] = qu[2];
-            below.v[0] = qv[-1]; below.v[1] = dv.x; below.v[2] = dv.y; below.v[3] = qv[2];
+            // [0] = second column of lane - 1, [1] [2] = own columns, [3] = first column of lane + 1
+            auto get = [](const float *p, float (&w)[4]) { w[1] = p[0]; w[3] = p[1]; w[0] = p[kWinHalf - 1]; w[2] = p[kWinHalf]; };
+            get(row_of(buf, 0, wa, 1), above.u);
+            get(row_of(buf, 1, wa, 1), above.v);
+            get(row_of(buf, 0, wb, 0), below.u);
+            get(row_of(buf, 1, wb, 0), below.v);
         }
         if (RPW == 1) {
             update(0, above, first, below);
@@ -1664,18 +1669,19 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
     if (wave == 0 && lane == 0) go = __builtin_amdgcn_raw_buffer_load_b32(win_rsrc(x.abort), 0, 0, SC1) == 0;
     __syncthreads();
     if (!go) return; // (workgroup-uniform)
-    // columns -1 and 128 .. 129 of this wave's published rows are never written by a step; they are read into cells
-    // that are discarded, and zeroed once so that nothing depends on earlier contents of the LDS
-    if (lane < 3)
+    // elements 0 and 65 of both arrays of this wave's published rows (window columns -2, -1, 128, 129) are never written by
+    // a step; they are read into cells that are discarded, and zeroed once so that nothing depends on earlier contents of
+    // the LDS
+    if (lane < 4)
 #pragma unroll
         for (int b = 0; b < 8; ++b)
-            lds[(((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + (lane == 0 ? 1 : 129 + lane)] = 0.0f;
+            lds[(((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + (lane & 1) * kWinHalf + (lane >> 1) * (kWinHalf - 1)] = 0.0f;
     if (wave * RPW >= H) {
         // A wave beyond the window's rows in use publishes zeros once (the last wave in use reads them as its row below)
         // and then only keeps the workgroup's barrier count: one per step, two per exchange.
 #pragma unroll
         for (int b = 0; b < 8; ++b)
-            *reinterpret_cast<float2 *>(lds + (((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + 2 + 2 * lane) = make_float2(0.0f, 0.0f);
+            { float *p = lds + (((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + 1 + lane; p[0] = 0.0f; p[kWinHalf] = 0.0f; }
         const int supers = (x.steps + K - 1) / K;
         for (int s = 0; s < supers; ++s) {
             const int n = (s == 0 && x.steps % K) ? x.steps % K : K;

@@ -274,8 +274,10 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
  * single-step kernel gains up to 14 %, the temporally blocked kernel of gs_run does not care).  Where a hipMalloc lands
  * in HBM is below what a process controls, and four 1 GiB planes read at one of three levels (0.66 / 0.70 / 0.75 of
  * 8 TB/s at 16384^2) depending on it.  This call draws `candidates` (1..12) more blocks of the planes' size, times the
- * single-step kernel over 4-subsets of the pool (3 x pool-size probes of four steps each: ~50 ms at 16384^2), gives the
- * four planes the blocks that read best together and frees the rest.  Call it on FRESHLY CREATED planes, before they
+ * single-step kernel over 4-subsets of the pool (3 x pool-size random subsets, then one sweep of single-block exchanges
+ * around the best: ~100 probes of four steps each, 0.4 s at 16384^2 with 12 candidates), gives the four planes the blocks
+ * that read best together and frees the rest.  Measured (profiles/r05_placement.md): first four blocks 0.63-0.66 of
+ * 8 TB/s, best of 4 + 4 blocks 0.67-0.68, best of 4 + 12 blocks 0.70-0.75.  Call it on FRESHLY CREATED planes, before they
  * are filled: their contents are not kept -- all four are zero-filled on return, as gs_field_create leaves them.
  * first_ms / best_ms (optional): time per step of the planes' original blocks and of the chosen ones. */
 int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidates, float *first_ms, float *best_ms);

@@ -39,6 +39,14 @@ def test_gpus_2_rehearsal_without_torchrun_prints_a_verified_line(built):
     assert v["equal"] is True and v["mismatching_ranks"] == [] and v["blocks"] >= 4 and v["steps"] > 24, v
     assert v["random_start"] == {"steps": 203, "equal": True, "mismatching_ranks": []}, v     # signal on every seam
     assert "closing barrier outside" in line["timing"]
+    # the second route to several GPUs, run by rank 0 alone after the chain: one process, the slabs' ghost rows by
+    # device-to-device copies (here: both slabs on GPU 0), checked against a single-slab run
+    pc = line["peer_chain"]
+    assert "error" not in pc and pc["value"] > 0 and pc["verified"]["equal"] is True and len(pc["values"]) == 5, pc
+    # ... and which libraries the ranks were bound to
+    rt = line["runtime"]
+    assert rt["hip"] and rt["hip_runtime_version"] > 0 and rt["bootstrap"] == "gloo" and rt["rccl_named_by_GS_RCCL_LIBRARY"] is True, rt
+    assert line["stage_seconds"]["timed"] > 0
     assert line["value"] > 0 and line["value_first_region"] > 0 and line["untimed_steps_before_first_region"] >= 24 + 5
 
 

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""The reference's real call pattern at its default size: `simulate` calls perform_steps(32) per image and copies the V
+plane out after each (simulate/src/main.rs:52, 113-115; grid: ui/src/lib.rs:32-37).  Which kernel should `kernel = auto`
+run for calls of that length?  Per call length: Mcells x steps / s of (a) perform_steps alone, back to back, (b)
+perform_steps + a blocking V download per call (the reference's default build), (c) prepare_steps + an overlapped
+download (its `async-gpu` build), for the marching kernel (GS_KERNEL_TB), the persistent window kernel
+(GS_KERNEL_WINDOW) and whatever `auto` picks.
+
+    python tools/call_pattern.py [--rows 1080 --cols 1920 --calls 200]
+"""
+import argparse
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from grayscott_amd import HipArgs, Parameters, Simulation, capi  # noqa: E402
+from grayscott_amd.simulation import pinned_empty  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1080)
+    ap.add_argument("--cols", type=int, default=1920)
+    ap.add_argument("--calls", type=int, default=200)
+    ap.add_argument("--lengths", default="8,16,32,64,128,1000")
+    a = ap.parse_args()
+    cells = a.rows * a.cols
+    kinds = (("auto", {}), ("marching", {"kernel": capi.GS_KERNEL_TB}), ("window", {"kernel": capi.GS_KERNEL_WINDOW}))
+    sims = {}
+    for name, kw in kinds:
+        sim = Simulation.new(Parameters(), HipArgs(devices=[0], **kw))
+        sp = sim.make_species([a.rows, a.cols])
+        sim.perform_steps(sp, 4000)                       # on-line tuning done
+        sims[name] = (sim, sp)
+    image = np.empty((a.rows, a.cols), np.float32)
+    pinned = [pinned_empty((a.rows, a.cols)) for _ in range(2)]
+    print(f"grid {a.rows} x {a.cols}, {a.calls} calls per figure, median of 3; Mcells x steps / s")
+    print("| steps per call | kernel (label) | steps only | + blocking V download | + overlapped V download |")
+    print("|---|---|---|---|---|")
+    for n in (int(x) for x in a.lengths.split(",")):
+        calls = max(20, min(a.calls, 40000 // n))
+        for name, (sim, sp) in sims.items():
+            ctx = sim.context
+
+            def steps_only():
+                for _ in range(calls):
+                    sim.perform_steps(sp, n)
+
+            def blocking():
+                for _ in range(calls):
+                    sim.perform_steps(sp, n)
+                    sp.write_result_view(image)
+
+            def overlapped():
+                for i in range(calls):
+                    sim.prepare_steps(sp, n)
+                    if i:
+                        ctx.download_wait()
+                    sp.write_result_view_after(pinned[i & 1])
+                ctx.download_wait()
+                ctx.sync()
+
+            row = []
+            for fn in (steps_only, blocking, overlapped):
+                fn()
+                rates = []
+                for _ in range(3):
+                    ctx.sync()
+                    t0 = time.perf_counter()
+                    fn()
+                    ctx.sync()
+                    rates.append(cells * n * calls / (time.perf_counter() - t0) / 1e6)
+                row.append(statistics.median(rates))
+            print(f"| {n} | {name} (`{ctx.info()[0]}`) | {row[0]:,.0f} | {row[1]:,.0f} | {row[2]:,.0f} |", flush=True)
+    for sim, _ in sims.values():
+        sim.context.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
