@@ -323,10 +323,22 @@ def main() -> int:
         # the other ranks wait at the barrier (their GPUs idle but for rank 0's slabs)
         with stage("peer-chain", 900):
             if rank == 0:
-                try:
-                    peer_chain = peer_chain_leg(rows, cols, world, args.steps, tuned, args.rehearsal)
-                except Exception as e:                  # a second figure, never the line's fate
-                    peer_chain = {"error": f"{type(e).__name__}: {e}"}
+                # in a thread of its own with a bound of its own: a second figure, never the line's fate -- if it does
+                # not come back, the line says so and the other ranks are released all the same
+                import threading
+
+                box = {}
+
+                def leg():
+                    try:
+                        box["out"] = peer_chain_leg(rows, cols, world, args.steps, tuned, args.rehearsal)
+                    except Exception as e:
+                        box["out"] = {"error": f"{type(e).__name__}: {e}"}
+
+                th = threading.Thread(target=leg, daemon=True)
+                th.start()
+                th.join(float(os.environ.get("GS_BENCH_PEER_CHAIN_S", "300")))
+                peer_chain = box.get("out", {"error": "the in-process chain did not finish within its bound"})
             barrier()
 
     result = {

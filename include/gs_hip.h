@@ -125,12 +125,13 @@ typedef enum gs_kernel {
                               cells + a k-cell apron; lower windows on the grid's left and right edge, whose cells cost
                               more) in registers and trades its apron with its neighbours every k steps through
                               exchange planes, flags and sc1 accesses (fuse_steps = k: 2, 4, 6 or 8; rows_per_block =
-                              full window rows, 80 or 96).  What AUTO runs for calls of >= 64 steps where 80-row windows
-                              cover the grid: 456-461 k against TB's 435 k Mcells x steps / s at 1080 x 1920, both rules.
+                              full window rows: 80).  What AUTO runs for calls of >= 64 steps where such windows cover the
+                              grid: 496 k against TB's 395 k Mcells x steps / s at 1080 x 1920 in 1000-step calls; in
+                              32-step calls the two tie (profiles/r05_window_summary.md).
                               A launch whose workgroups are not all resident (another long-running kernel holds CUs)
-                              gives up after a bounded wait without having written anything but its exchange planes:
-                              the next call that waits for or reads results runs the steps again with TB, and the
-                              context stays with TB  */
+                              gives up after a bounded wait: the launches before it stand, it and the later ones are run
+                              again with TB by the next call that waits for or reads results (each from its own input
+                              planes, which no launch writes), and the context stays with TB  */
 } gs_kernel;
 
 /* Rule on the edges of the global grid.  The reference has two:

@@ -23,10 +23,12 @@ def built():
 
 @pytest.fixture(scope="session", autouse=True)
 def torch_runtime_first():
-    """A GPU test process holds TWO HIP runtimes: libgs_hip.so links /opt/rocm's, torch brings its own copy.
-    bench.py and smoke() always bring torch's up first (torch.cuda.is_available / set_device before the first
-    gs_ctx_create); the tests that compare planes on the device through torch views do the same here, once per
-    session, so that the order never depends on which test happens to run first.  No-op without a GPU.
+    """torch first.  libgs_hip.so links the HIP runtime by SONAME (libamdhip64.so.7) and torch bundles a copy under the
+    same SONAME: with torch imported first -- what bench.py and smoke() do -- the library binds torch's copy and the
+    process holds ONE runtime (and, for RCCL, torch's librccl); with the library first the process holds /opt/rocm's
+    runtime and torch's own copy then finds no GPU ("No HIP GPUs are available": tests/test_gpu_multiprocess.py pins all
+    three orders in fresh interpreters).  The tests that compare planes on the device through torch views need torch's
+    CUDA side, so torch's runtime comes up here, once per session, whichever test runs first.  No-op without a GPU.
     GS_TEST_TORCH_FIRST=0 switches it off (diagnostics)."""
     if os.environ.get("GS_TEST_TORCH_FIRST", "1") != "0":
         try:

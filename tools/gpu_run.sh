@@ -12,6 +12,7 @@
 #   sweep:RxC:STEPS:VARIANT;VARIANT...   tools/sweep.py (VARIANT = key=value,key=value)
 #   libsweep:NAME:RxC:STEPS:VARIANT;...  the same against grayscott_amd/variants/libgs_hip_NAME.so
 #   profile:TAG[:bench extra args]       tools/profile_gpu.sh
+#   kprofile:TAG:TOOL,ARG,ARG...         tools/profile_kernel.sh (rocprofv3 passes over a python tool, e.g. tools/run_steps.py)
 #   energyprof      rocprofv3 PMC passes of tools/energy_table.py --profile (tools/summarize_energy.py reads them)
 #   configs         tools/baseline_configs.py
 #   criterion       tools/criterion_grid.py
@@ -64,6 +65,10 @@ for stage in "$@"; do
     profile)
       IFS=: read -r ptag extra <<< "$rest"
       GS_BENCH_EXTRA="$extra" timeout -k 10 1100 bash tools/profile_gpu.sh "$ptag" 400 > "$OUT/profile_$ptag.log" 2>&1; rc=$?; tail -5 "$OUT/profile_$ptag.log" ;;
+    kprofile)
+      # kprofile:TAG:tools/run_steps.py,--rows,1080,...   rocprofv3 passes over a python tool (tools/profile_kernel.sh)
+      IFS=: read -r ptag prog <<< "$rest"
+      timeout -k 10 1100 bash tools/profile_kernel.sh "$ptag" ${prog//,/ } > "$OUT/kprofile_$ptag.log" 2>&1; rc=$?; tail -6 "$OUT/kprofile_$ptag.log" ;;
     energyprof)
       # per-flavour PMC counters of tools/energy_table.py (--profile: 40 steps per flavour), one pass per input
       rc=0

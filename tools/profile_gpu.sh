@@ -20,7 +20,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 EXTRA=${GS_BENCH_EXTRA:-}
-python3 "$ROOT/bench.py" --steps "$STEPS" --warmup 20 --no-cpu-baseline --no-extra $EXTRA > "$OUT/bench_unprofiled.json" 2> "$OUT/unprofiled.log"
+python3 "$ROOT/bench.py" --steps "$STEPS" --warmup 20 --no-cpu-baseline --no-extra --no-verify $EXTRA > "$OUT/bench_unprofiled.json" 2> "$OUT/unprofiled.log"
 tail -1 "$OUT/bench_unprofiled.json"
 python3 - "$OUT" <<'PY'
 import json, sys
@@ -36,13 +36,13 @@ PY
 source "$OUT/layout.env"
 cat "$OUT/layout.json"; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
-    python3 "$ROOT/bench.py" --steps "$STEPS" --warmup 20 --no-cpu-baseline --no-extra $EXTRA > "$OUT/bench_stats.json" 2> "$OUT/stats.log"
+    python3 "$ROOT/bench.py" --steps "$STEPS" --warmup 20 --no-cpu-baseline --no-extra --no-verify $EXTRA > "$OUT/bench_stats.json" 2> "$OUT/stats.log"
 tail -1 "$OUT/bench_stats.json"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o bench -- \
-    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-extra $EXTRA > "$OUT/bench_fetch.json" 2> "$OUT/fetch.log"
+    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-extra --no-verify $EXTRA > "$OUT/bench_fetch.json" 2> "$OUT/fetch.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o bench -- \
-    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-extra $EXTRA > "$OUT/bench_write.json" 2> "$OUT/write.log"
+    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-extra --no-verify $EXTRA > "$OUT/bench_write.json" 2> "$OUT/write.log"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES \
     --output-format csv -d "$OUT/sq" -o bench -- \
-    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-extra $EXTRA > "$OUT/bench_sq.json" 2> "$OUT/sq.log"
+    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-extra --no-verify $EXTRA > "$OUT/bench_sq.json" 2> "$OUT/sq.log"
 find "$OUT" -name '*.csv' | head -20
