@@ -34,6 +34,12 @@
 #ifndef GS_TB_AUX_STORE
 #define GS_TB_AUX_STORE 0
 #endif
+// GS_WIN_LATE_ROW  1 = the persistent window kernel computes the last of a wave's middle rows behind the step's barrier,
+//                  after issuing the reads of the neighbouring waves' rows (hides the LDS read burst of 16 waves in
+//                  lock-step); 0 = all middle rows before the barrier (round 4's order).
+#ifndef GS_WIN_LATE_ROW
+#define GS_WIN_LATE_ROW 0
+#endif
 // GS_WIN_TRACE     (defined = on; tools/window_timeline.py) wave 0 of every workgroup of the persistent window kernel
 //                  stamps the 100 MHz real-time counter at seven points of each of its last 8 super-steps.
 // GS_TB_TRACE      (defined = on; tools/wave_timeline.py) every wave of gs_step_tb_k leaves five stamps of the

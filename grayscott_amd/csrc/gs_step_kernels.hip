@@ -1497,14 +1497,18 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
         RowT<2> first = widen(u[0], v[0]);                 // old row 0
         RowT<2> second = widen(u[RPW > 1 ? 1 : 0], v[RPW > 1 ? 1 : 0]); // old row 1: needed again for row 0
         RowT<2> prev = first, cur = second;
+        // GS_WIN_LATE_ROW (gs_experiments.h): the last of the rows that need nothing from other waves is computed BEHIND
+        // the barrier, after the reads of the neighbouring waves' rows have been issued -- all 16 waves of the workgroup
+        // issue those reads at the same moment, and the LDS pipe serves them one after the other
+        constexpr int kLate = (GS_WIN_LATE_ROW && RPW >= 4) ? 1 : 0;
 #pragma unroll
-        for (int r = 1; r < RPW - 1; ++r) {
+        for (int r = 1; r < RPW - 1 - kLate; ++r) {
             const RowT<2> next = widen(u[r + 1], v[r + 1]); // old row r + 1 (not overwritten yet)
             update(r, prev, cur, next);
             prev = cur;
             cur = next;
         }
-        // now: prev = old row RPW - 2, cur = old row RPW - 1 (RPW >= 3); RPW == 2: prev = old row 0, cur = old row 1
+        // now (kLate = 0): prev = old row RPW - 2, cur = old row RPW - 1 (RPW >= 3); RPW == 2: prev = old row 0, cur = old row 1
         __syncthreads();
         RowT<2> above, below;
         {
@@ -1514,6 +1518,12 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
             get(row_of(buf, 1, wa, 1), above.v);
             get(row_of(buf, 0, wb, 0), below.u);
             get(row_of(buf, 1, wb, 0), below.v);
+        }
+        if constexpr (kLate) {
+            const RowT<2> next = widen(u[RPW - 1], v[RPW - 1]);
+            update(RPW - 2, prev, cur, next);
+            prev = cur;
+            cur = next;
         }
         if (RPW == 1) {
             update(0, above, first, below);

@@ -127,7 +127,7 @@ typedef enum gs_kernel {
                               exchange planes, flags and sc1 accesses (fuse_steps = k: 2, 4, 6 or 8; rows_per_block =
                               full window rows: 80).  What AUTO runs for calls of >= 64 steps where such windows cover the
                               grid: 496 k against TB's 395 k Mcells x steps / s at 1080 x 1920 in 1000-step calls; in
-                              32-step calls the two tie (profiles/r05_window_summary.md).
+                              32-step calls the two tie (profiles/r05_window_kernel.md).
                               A launch whose workgroups are not all resident (another long-running kernel holds CUs)
                               gives up after a bounded wait: the launches before it stand, it and the later ones are run
                               again with TB by the next call that waits for or reads results (each from its own input

@@ -91,6 +91,10 @@ for stage in "$@"; do
     pytest)
       IFS=: read -r files kexpr <<< "$rest"
       timeout -k 10 1100 python -m pytest ${files//,/ } -m gpu -x -q ${kexpr:+-k "${kexpr//+/ }"} > "$OUT/pytest_some.log" 2>&1; rc=$?; tail -15 "$OUT/pytest_some.log" ;;
+    libpytest)
+      # libpytest:NAME:FILE[,FILE...][:K+EXPRESSION]   GPU tests against grayscott_amd/variants/libgs_hip_NAME.so
+      IFS=: read -r lib files kexpr <<< "$rest"
+      GS_HIP_LIBRARY=$ROOT/grayscott_amd/variants/libgs_hip_$lib.so timeout -k 10 1100 python -m pytest ${files//,/ } -m gpu -x -q ${kexpr:+-k "${kexpr//+/ }"} > "$OUT/pytest_$lib.log" 2>&1; rc=$?; tail -8 "$OUT/pytest_$lib.log" ;;
     py)
       IFS=: read -r script pyargs <<< "$rest"
       timeout -k 10 900 python "$script" ${pyargs//,/ } > "$OUT/$(basename "$script" .py).log" 2>&1; rc=$?; tail -40 "$OUT/$(basename "$script" .py).log" ;;
