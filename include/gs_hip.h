@@ -204,7 +204,7 @@ int32_t gs_rccl_selftest(int32_t device, uint64_t floats);
  * "hip_runtime_version", "rccl": path or null, "rccl_version", "rccl_named_by_GS_RCCL_LIBRARY"}.  libgs_hip.so links
  * the HIP runtime by SONAME (libamdhip64.so.7) and dlopens RCCL by SONAME (librccl.so.1) on first use, so it binds
  * WHATEVER COPY THE PROCESS HAS MAPPED FIRST: in a process that imported torch before creating a context -- bench.py,
- * smoke(), the tests -- both are the copies the torch wheel bundles (one HIP runtime in the process, the one that owns
+ * the tests -- both are the copies the torch wheel bundles (one HIP runtime in the process, the one that owns
  * the planes' device pointers, and the RCCL built against it, which the library's communicator then shares with
  * torch's ProcessGroupNCCL if that exists); in a torch-free process -- the Rust binary -- they are /opt/rocm's.  Both
  * pairings run the one-rank exchange of gs_rccl_selftest in the GPU suite (tests/test_gpu_multiprocess.py).

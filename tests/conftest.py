@@ -24,7 +24,7 @@ def built():
 @pytest.fixture(scope="session", autouse=True)
 def torch_runtime_first():
     """torch first.  libgs_hip.so links the HIP runtime by SONAME (libamdhip64.so.7) and torch bundles a copy under the
-    same SONAME: with torch imported first -- what bench.py and smoke() do -- the library binds torch's copy and the
+    same SONAME: with torch imported first -- what bench.py does -- the library binds torch's copy and the
     process holds ONE runtime (and, for RCCL, torch's librccl); with the library first the process holds /opt/rocm's
     runtime and torch's own copy then finds no GPU ("No HIP GPUs are available": tests/test_gpu_multiprocess.py pins all
     three orders in fresh interpreters).  The tests that compare planes on the device through torch views need torch's

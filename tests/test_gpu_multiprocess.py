@@ -173,7 +173,7 @@ def _ranks_match_oracle(tmp_path, world, rows, cols, steps, transport_lib, seed,
 @pytest.mark.parametrize("order", ["torch+library", "library", "library+torch"])
 def test_library_pairing_of_a_bench_rank_runs_on_one_gpu(tmp_path, built, order):
     """What `bench.py --gpus N` binds, run at world size 1 (VERDICT round 4, weak point 2).  torch first -- bench.py,
-    smoke() and this suite's conftest -- means libgs_hip.so's libamdhip64.so.7 and librccl.so.1 resolve, by SONAME, to
+    and this suite's conftest -- means libgs_hip.so's libamdhip64.so.7 and librccl.so.1 resolve, by SONAME, to
     the copies the torch wheel bundles: ONE HIP runtime in the process, and the library's communicator on the RCCL
     instance torch's ProcessGroupNCCL uses.  A torch-free process ("library": the reference's Rust binaries) binds
     /opt/rocm's runtime and RCCL.  Both must move the ghost-row messages and step bit-exactly.  The third order is the one
