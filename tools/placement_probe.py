@@ -21,10 +21,23 @@ def main():
     ap.add_argument("--cols", type=int, default=16384)
     ap.add_argument("--contexts", type=int, default=3)
     ap.add_argument("--candidates", type=int, default=12)
+    ap.add_argument("--generations", type=int, default=1, help="species placed (and freed) per context before the one that is kept")
+    ap.add_argument("--hold", type=int, default=0, help="1 = a Species of another context is allocated first (as in bench.py)")
     a = ap.parse_args()
     cells = a.rows * a.cols
+    hold = None
+    if a.hold:   # as in bench.py: another context's Species (4 planes) is allocated before the placed one
+        other = Simulation.new(Parameters(), HipArgs(devices=[0]))
+        hold = (other, other.make_species([a.rows, a.cols]))
     for c in range(a.contexts):
         sim = Simulation.new(Parameters(), HipArgs(devices=[0], kernel=capi.GS_KERNEL_STREAM))
+        for g in range(a.generations - 1):    # throw-away generations: place, step a little, free
+            tmp = sim.make_species([a.rows, a.cols], place_candidates=a.candidates)
+            print(f"context {c} generation {g}: first four {tmp.placement[0]:.4f} ms, chosen {tmp.placement[1]:.4f} ms", flush=True)
+            sim.perform_steps(tmp, 50)
+            for conc in tmp.u._pair + tmp.v._pair:
+                conc.destroy()
+            del tmp
         sp = sim.make_species([a.rows, a.cols], place_candidates=a.candidates)
         first, best = sp.placement
         sim.perform_steps(sp, 50)
