@@ -340,6 +340,9 @@ def roofline_object(event_ms, passes, steps_per_launch, cells_per_gpu, pmc, valu
         "valu": valu_rate / VALU_PEAK_TLANEOPS if valu_rate else None,
         "useful_valu": useful_rate / VALU_PEAK_TLANEOPS,
         "useful_valu_per_cell_step": useful,
+        # the same rate priced in the REFERENCE's form of the update (53 instructions per cell-step, one per operation of
+        # compute/naive/src/lib.rs:63-79): the share of the VALU roof a kernel that formed every tap afresh would need
+        "reference_form_valu": USEFUL_VALU_PER_CELL_STEP * cells_per_gpu * steps_per_launch / launch_s / 1e12 / VALU_PEAK_TLANEOPS,
         "hbm_physical": hbm_physical,
         # SURVEY section 8(d)'s algorithmic figure (16 B per cell-step): a throughput in GB/s-equivalents,
         # NOT a fraction of the HBM roof once K steps share one HBM pass (it exceeds the peak by design)

@@ -40,7 +40,13 @@ UNITS = [
     ("gs_step_kernels.hip", "gs_step_strict_op.o", STRICT + ["-DGS_TB_OP_ONLY=1"] + KERNEL_FLAGS),
     ("gs_step_kernels.hip", "gs_step_fused.o", ["-DGS_MATH_FUSED=1"] + KERNEL_FLAGS),
     ("gs_util_kernels.hip", "gs_util.o", []),
-    ("gs_api.cpp", "gs_api.o", ["-x", "hip"]),
+    # the host side (contexts and schedule, planes, kernel configuration, the window kernel's runtime, RCCL): only the
+    # C ABI of include/gs_hip.h is visible outside the library
+    ("gs_api.cpp", "gs_api.o", ["-x", "hip", "-fvisibility=hidden"]),
+    ("gs_fields.cpp", "gs_fields.o", ["-x", "hip", "-fvisibility=hidden"]),
+    ("gs_tuner.cpp", "gs_tuner.o", ["-x", "hip", "-fvisibility=hidden"]),
+    ("gs_window.cpp", "gs_window.o", ["-x", "hip", "-fvisibility=hidden"]),
+    ("gs_rccl.cpp", "gs_rccl.o", ["-x", "hip", "-fvisibility=hidden"]),
 ]
 
 

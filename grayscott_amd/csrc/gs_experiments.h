@@ -78,7 +78,7 @@ __device__ __forceinline__ unsigned long long trace_now()
 //   GS_HIP_WINDOW_PATIENCE polls (~1 us each) a workgroup of the persistent window kernel waits for a neighbour's flag
 //                         before the launch gives up (default 2^21, ~2 s; tests set 1 to provoke it)
 //   GS_HIP_WINDOW_WAVES   "left,interior,right": waves in use per window of the left-most / inner / right-most tile column
-//                         of the persistent window kernel's tiling (gs_api.cpp: plan_windows)
+//                         of the persistent window kernel's tiling (gs_window.cpp: plan_windows)
 constexpr int kGsXcdGroupMax = 512; // 8 * 512 workgroups per renumbered group at most
 inline int gs_env_int(const char *name, int unset, int lo, int hi)
 {

@@ -1,4 +1,4 @@
-// gs_kernels.h -- host/device contract between gs_api.cpp and the gfx950 kernels.
+// gs_kernels.h -- host/device contract between the host side (gs_api.cpp, gs_tuner.cpp, gs_window.cpp, gs_fields.cpp) and the gfx950 kernels.
 //
 // One "plane" is a row-major f32 array of one species in one slot for one row slab:
 //   element (r, c) of the slab, r in [-ghost, rows + ghost) (rows outside [0, rows) = ghost rows),
@@ -79,7 +79,7 @@ struct GsStepArgs {
 // The input planes are never written: a launch that gives up (abort set) has destroyed nothing.
 // Windows of one tile column share their height, and columns whose cells cost more (the grid's left and right edge
 // under the clipped rule) get lower windows, so that every workgroup's step takes the same time: they all wait for
-// their neighbours at every exchange, the slowest sets the pace (gs_api.cpp: plan_windows).
+// their neighbours at every exchange, the slowest sets the pace (gs_window.cpp: plan_windows).
 constexpr int kGsWindowMaxNbr = 14;
 struct GsWindowDesc {
     int32_t r0, c0;    // first owned row / column (global)

@@ -1,0 +1,169 @@
+// gs_rccl.cpp -- RCCL, loaded on first use (single-process users never touch it), the one-rank self-test of the
+// ghost-row exchange's call pattern, which libraries the process is bound to, and the error message of the last failure.
+#include "gs_internal.h"
+
+namespace gsi {
+
+thread_local std::string g_last_error;
+
+int32_t fail(int32_t code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+Rccl *rccl()
+{
+    // function-local static: initialised once, thread-safe (C++11)
+    static Rccl *const instance = []() -> Rccl * {
+        static Rccl r;
+        // GS_RCCL_LIBRARY names the library to bind instead of the system's librccl (a custom
+        // RCCL build; the tests' shared-memory transport double, tests/cpp/shm_transport.cpp)
+        const char *user = std::getenv("GS_RCCL_LIBRARY");
+        for (const char *name : {user, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (!name || !*name) continue;
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle || name == user) break; // an explicit choice never falls back silently
+        }
+        if (!r.handle) return nullptr;
+        bool ok = true;
+        auto sym = [&](const char *n) {
+            void *p = dlsym(r.handle, n);
+            if (!p) ok = false;
+            return p;
+        };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!ok) {
+            dlclose(r.handle);
+            r.handle = nullptr;
+            return nullptr;
+        }
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.handle, "ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.handle, "ncclCommUserRank"));
+        r.CommCuDevice = reinterpret_cast<decltype(r.CommCuDevice)>(dlsym(r.handle, "ncclCommCuDevice"));
+        return &r;
+    }();
+    return instance;
+}
+
+} // namespace gsi
+
+using namespace gsi;
+
+extern "C" {
+
+const char *gs_last_error(void) { return g_last_error.c_str(); }
+
+int32_t gs_get_unique_id(void *out128)
+{
+    if (!out128) return fail(GS_ERR_INVALID, "null output");
+    Rccl *R = rccl();
+    if (!R) return fail(GS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+    ncclUniqueId id;
+    GS_NCCL(R, R->GetUniqueId(&id));
+    std::memcpy(out128, &id, sizeof id);
+    return GS_OK;
+}
+
+int32_t gs_rccl_selftest(int32_t device, uint64_t floats)
+{
+    Rccl *R = rccl();
+    if (!R) return fail(GS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+    if (floats == 0 || floats > (1ull << 28)) return fail(GS_ERR_INVALID, "message of %llu floats", (unsigned long long)floats);
+    GS_HIP(hipSetDevice(device));
+    ncclUniqueId id;
+    GS_NCCL(R, R->GetUniqueId(&id));
+    ncclComm_t comm = nullptr;
+    GS_NCCL(R, R->CommInitRank(&comm, 1, id, 0));
+    float *src = nullptr, *dst = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<float> host(floats), back(floats);
+    for (uint64_t i = 0; i < floats; ++i) host[i] = (float)(i % 65521) * 0.25f + 1.0f;
+    int32_t st = GS_OK;
+    auto step = [&](hipError_t e, const char *what) {
+        if (st == GS_OK && e != hipSuccess) st = fail(GS_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    };
+    int least = 0, greatest = 0;
+    step(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+    step(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
+    step(hipMalloc(reinterpret_cast<void **>(&src), floats * sizeof(float)), "hipMalloc");
+    step(hipMalloc(reinterpret_cast<void **>(&dst), floats * sizeof(float)), "hipMalloc");
+    step(hipMemcpy(src, host.data(), floats * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy");
+    step(hipMemset(dst, 0, floats * sizeof(float)), "hipMemset");
+    if (st == GS_OK) {
+        // the call pattern of push_halo: one group, a send and the matching receive, on the halo stream
+        ncclResult_t r = R->GroupStart();
+        if (r == ncclSuccess) r = R->Send(src, (size_t)floats, ncclFloat, 0, comm, stream);
+        if (r == ncclSuccess) r = R->Recv(dst, (size_t)floats, ncclFloat, 0, comm, stream);
+        const ncclResult_t e = R->GroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) st = fail(GS_ERR_RCCL, "grouped ncclSend / ncclRecv to self failed: %s", R->GetErrorString(r));
+    }
+    step(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    step(hipMemcpy(back.data(), dst, floats * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy");
+    if (st == GS_OK && std::memcmp(back.data(), host.data(), floats * sizeof(float)) != 0)
+        st = fail(GS_ERR_RCCL, "the message came back altered");
+    if (stream) (void)hipStreamDestroy(stream);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    R->CommDestroy(comm);
+    (void)hipGetLastError();
+    return st;
+}
+
+// Which HIP runtime and which RCCL this process's libgs_hip.so is bound to (dladdr of an entry point of each), with
+// their versions.  A process that imported torch first resolves libamdhip64.so.7 and librccl.so.1 by SONAME to the
+// copies torch bundles -- the runtime that owns the device pointers the planes live at is then the one RCCL moves them
+// with; a torch-free process gets /opt/rocm's.
+int32_t gs_runtime_info(int32_t load_rccl, char *out, size_t cap)
+{
+    if (!out || cap == 0) return fail(GS_ERR_INVALID, "null output");
+    Dl_info hip_so{}, rccl_so{};
+    int hip_version = 0, rccl_version = 0;
+    (void)dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &hip_so);
+    if (hipRuntimeGetVersion(&hip_version) != hipSuccess) { hip_version = 0; (void)hipGetLastError(); }
+    Rccl *R = load_rccl ? rccl() : nullptr;
+    if (R) {
+        (void)dladdr(reinterpret_cast<const void *>(R->Send), &rccl_so);
+        auto get_version = reinterpret_cast<ncclResult_t (*)(int *)>(dlsym(R->handle, "ncclGetVersion"));
+        if (get_version) (void)get_version(&rccl_version);
+    }
+    const char *user = std::getenv("GS_RCCL_LIBRARY");
+    std::snprintf(out, cap, "{\"hip\": \"%s\", \"hip_runtime_version\": %d, \"rccl\": %s%s%s, \"rccl_version\": %d, "
+                            "\"rccl_named_by_GS_RCCL_LIBRARY\": %s}",
+                  hip_so.dli_fname ? hip_so.dli_fname : "", hip_version, rccl_so.dli_fname ? "\"" : "",
+                  rccl_so.dli_fname ? rccl_so.dli_fname : "null", rccl_so.dli_fname ? "\"" : "", rccl_version,
+                  user && *user ? "true" : "false");
+    return GS_OK;
+}
+
+int32_t gs_ctx_comm_info(const gs_ctx *ctx, int32_t *rccl_ranks, int32_t *rccl_rank, int32_t *rccl_device)
+{
+    if (!ctx) return fail(GS_ERR_INVALID, "null context");
+    int n = 0, r = -1, d = -1;
+    if (ctx->comm) {
+        Rccl *R = rccl();
+        if (!R) return fail(GS_ERR_RCCL, "RCCL is not loaded");
+        if (R->CommCount) GS_NCCL(R, R->CommCount(ctx->comm, &n));
+        if (R->CommUserRank) GS_NCCL(R, R->CommUserRank(ctx->comm, &r));
+        if (R->CommCuDevice) GS_NCCL(R, R->CommCuDevice(ctx->comm, &d));
+    }
+    if (rccl_ranks) *rccl_ranks = n;
+    if (rccl_rank) *rccl_rank = r;
+    if (rccl_device) *rccl_device = d;
+    return GS_OK;
+}
+
+} // extern "C"

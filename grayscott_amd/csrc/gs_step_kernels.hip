@@ -2110,7 +2110,7 @@ static int tb_reduce_fast(int fast, int k = 0, int cpl = 0, int wg = 4)
 }
 
 // Wave slots of the chip for the kernel entry a launch with these parameters would use (the tuner's
-// "a launch of exactly r rounds" candidates, gs_api.cpp); 0 = no such entry.
+// "a launch of exactly r rounds" candidates, gs_tuner.cpp); 0 = no such entry.
 int GS_SUFFIX(gs_tb_wave_slots)(int k, int fast, int cpl)
 {
     if (k < 1 || k > 4 || (cpl != 1 && cpl != 2 && cpl != 4)) return 0;

@@ -1,5 +1,5 @@
 // shm_transport.cpp -- TEST DOUBLE for librccl: the eight nccl* entry points libgs_hip.so binds
-// (gs_api.cpp: struct Rccl), implemented over a POSIX shared-memory mailbox per ordered rank pair.
+// (gs_internal.h: struct Rccl), implemented over a POSIX shared-memory mailbox per ordered rank pair.
 //
 // Why: a 1-GPU box cannot give every rank its own GPU and RCCL refuses two ranks on one device, so
 // the multi-process leg of the library (rank-local slab, K-row ncclSend/ncclRecv groups, ghost-depth

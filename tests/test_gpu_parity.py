@@ -369,7 +369,7 @@ def test_tile_kernel_variants_and_auto_choice():
     assert_bits_equal(in_u.make_scalar_view(sim.context), u, "tile + single steps U")
     assert_bits_equal(in_v.make_scalar_view(sim.context), v, "tile + single steps V")
     # kernel = auto: the window kernel between the resident kernel's 4096 cells and 1.5 M cells when nothing is
-    # pinned (window and steps per launch from a cost model, gs_api.cpp: pick_tile_config); temporal
+    # pinned (window and steps per launch from a cost model, gs_tuner.cpp: pick_tile_config); temporal
     # blocking for slab chains, pinned schedules and everything larger
     ref_u, ref_v = oracle.run(u0, v0, 29, ftz=True)
     for kw, want in ((dict(), "tile"), (dict(devices=[0, 0], kernel=capi.GS_KERNEL_TILE), "tb-k"),
