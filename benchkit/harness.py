@@ -19,7 +19,7 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 # arithmetic the reference's update needs per cell-step when each op is one instruction (taps:
 # 4 corners x (sub, mul, add) + 4 sides x (sub with div:2, add), two species; reaction: 13)
 USEFUL_VALU_PER_CELL_STEP = 53
-# ... and with full difference sharing at 2 columns per lane (gs_step_kernels.hip: cells_vshare): per lane-row and species
+# ... and with full difference sharing at 2 columns per lane (grayscott_amd/csrc/gs_march.h: cells_vshare): per lane-row and species
 # 14 x 2 + 5 tap instructions instead of 20 x 2, the same 13 for the reaction
 USEFUL_VALU_PER_CELL_STEP_SHARED = 46
 NOMINAL_SCLK_MHZ = 2400.0  # the clock VALU_PEAK_TLANEOPS is priced at

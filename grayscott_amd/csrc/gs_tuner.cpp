@@ -5,7 +5,7 @@
 
 namespace gsi {
 
-// Output columns per wave of the temporally blocked kernel (gs_step_kernels.hip: tb_cols_per_wave).
+// Output columns per wave of the temporally blocked kernel (gs_march.h: tb_cols_per_wave).
 long tb_strips(int32_t cols, int fuse, int cpl)
 {
     const long w = (64 - 2 * ((fuse + cpl - 1) / cpl)) * (long)cpl;

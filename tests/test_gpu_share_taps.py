@@ -1,5 +1,5 @@
 """Full difference sharing in the temporally blocked kernel (gs_options.share_taps; cells_vshare in
-grayscott_amd/csrc/gs_step_kernels.hip): the S / SE / SW taps of a row are carried to the next row, where they are --
+grayscott_amd/csrc/gs_march.h): the S / SE / SW taps of a row are carried to the next row, where they are --
 negated -- its N / NW / NE taps.  The reference forms every tap afresh (compute/naive/src/lib.rs:63-71); the shared form
 must give the same BITS: ordinary data, data around the flush-to-zero threshold, signed zeros and equal neighbours
 (where a tap is an exact or a flushed zero of either sign), non-finite values, and the stencils / rates for which the

@@ -7,7 +7,7 @@
 key=value pairs are HipArgs fields (rows_per_block=36 cols_per_lane=2 fuse_steps=4 ...); without them the
 context tunes itself first.  Every wave of the LAST pass leaves five timestamps of the 100 MHz real-time counter
 (entry, tick 3 = first rows used, tick 2K = level pipeline full, tick nticks - 2K = last level-0 row taken,
-exit), its hardware id and its unit (gs_step_kernels.hip: GS_TB_TRACE).  Prints where the time of a pass goes:
+exit), its hardware id and its unit (gs_march.h: GS_TB_TRACE).  Prints where the time of a pass goes:
 the span of the launch against the pass period, when waves start and end, how long the fill / steady / drain
 phases of a unit take, and how many waves are resident over time.
 """

@@ -5,7 +5,7 @@
     GS_HIP_LIBRARY=grayscott_amd/variants/libgs_hip_wintrace.so python tools/window_timeline.py ROWS COLS [key=value ...]
 
 Wave 0 of every workgroup stamps the 100 MHz real-time counter at seven points of each of its last 8 super-steps
-(gs_step_kernels.hip: GS_WIN_TRACE).  Prints, per kind of window, the phases of a super-step: the K steps, ring
+(gs_window_kernel.h: GS_WIN_TRACE).  Prints, per kind of window, the phases of a super-step: the K steps, ring
 stores + drain, barrier, flag + poll (= waiting for the slowest neighbour), barrier, apron loads."""
 import ctypes
 import os
