@@ -174,3 +174,23 @@ def test_species_new_and_a_developing_pattern_at_a_few_megacells():
     assert ".op.ds" in info[0], info
     assert_bits_equal(got_u, ref_u, "pattern crop U")
     assert_bits_equal(got_v, ref_v, "pattern crop V")
+
+
+def test_the_tuner_decides_on_sharing_and_results_do_not_depend_on_it():
+    """share_taps = 0: gs_run's on-line tuner times the configuration it chose with and without sharing (phase E) on
+    passes of the run itself and keeps the faster; whatever it keeps, and while it is still trying, the planes equal
+    those of a run with sharing pinned off."""
+    rows, cols = 1700, 2300
+    outs, tuned = [], None
+    for share in (0, 2):
+        sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_TB, share_taps=share))
+        sp = sim.make_species([rows, cols])
+        for n in (50, 1200, 1200, 1200, 353):
+            sim.perform_steps(sp, n)
+        if share == 0:
+            tuned = sim.context.get_tuned(rows, cols)
+        outs.append([x.make_scalar_view(sim.context) for x in sp.in_out()[:2]])
+        sim.context.close()
+    assert tuned[0] > 0 and tuned[3] in (1, 2), tuned          # a choice was made, sharing included
+    assert_bits_equal(outs[0][0], outs[1][0], f"U, tuner's choice {tuned} vs sharing off")
+    assert_bits_equal(outs[0][1], outs[1][1], f"V, tuner's choice {tuned} vs sharing off")

@@ -5,6 +5,7 @@
 # A failing stage ends the call (no GPU step is started after a failed or timed-out one).
 # Stages:
 #   probe           what the GPU box has: Rust toolchain?, CPU share, rocm-smi's energy counter and power cap
+#   smoke           __graft_entry__.build() + smoke(), as the driver runs them
 #   newtests        this round's new GPU tests first (fast failure)
 #   tests           the whole GPU suite
 #   bench           bench.py as the driver runs it (--steps 20 --warmup 5) and with its defaults
@@ -38,6 +39,8 @@ for stage in "$@"; do
         echo "--- find / -name cargo -o -name rustc (maxdepth 4)"; find / -maxdepth 4 \( -name cargo -o -name rustc \) -not -path '/proc/*' 2>/dev/null | head; echo "(end)";
         echo "--- nproc / cpu quota / memory"; nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; grep MemTotal /proc/meminfo;
         echo "--- rocm-smi energy / power cap"; rocm-smi --showenergycounter --showmaxpower --showpower --showclocks 2>&1 | head -40; } > "$OUT/probe.txt" 2>&1; rc=0; cat "$OUT/probe.txt" ;;
+    smoke)
+      timeout -k 10 600 python __graft_entry__.py --smoke > "$OUT/smoke.log" 2>&1; rc=$?; tail -4 "$OUT/smoke.log" ;;
     newtests)
       timeout -k 10 1100 python -m pytest tests/test_gpu_bench_rehearsal.py tests/test_gpu_timed_sizes.py tests/test_gpu_baseline_configs.py -m gpu -x -q \
         -k "rehearsal or stalled or config3 or developing" \
