@@ -71,6 +71,20 @@ def test_recorded_bench_line_has_the_contract_keys():
                     assert b["developed_pattern"]["energy_pJ_per_cell_step"] > b["energy_pJ_per_cell_step"]
                     assert "closing barrier outside" in b["timing"] and b["value_first_region"] > 0.9 * b["value"]
                     assert b["untimed_steps_before_first_region"] >= b["untimed_steps_after_warmup"] + b["warmup"] + b["steps"]
+                    if "runtime" in b:
+                        # round 5 on: the line says which HIP runtime (and, for N > 1, which RCCL) the library was bound
+                        # to, what every stage cost, how the HBM leg's planes were placed, and prices its rate both in the
+                        # kernel's own form of the update (46 instructions with full difference sharing) and in the reference's
+                        rt = b["runtime"]
+                        assert os.path.basename(rt["hip"]).startswith("libamdhip64.so") and rt["hip_runtime_version"] > 70000000 and rt["torch"]
+                        assert rt["rccl"] is None and rt["bootstrap"] is None          # N = 1: nothing loads RCCL
+                        assert b["stage_seconds"]["timed"] > 0 and sum(b["stage_seconds"].values()) < 120
+                        pl = ss["placement"]
+                        assert 0 < pl["chosen_blocks_ms_per_step"] <= pl["first_blocks_ms_per_step"] * 1.0001
+                        assert abs(ss["frac_of_8TBps"] - pl["chosen_blocks_frac_of_8TBps"]) < 0.03
+                        assert r["useful_valu_per_cell_step"] == (46 if ".ds" in b["config"]["kernel"] else 53)
+                        assert abs(r["reference_form_valu"] - r["useful_valu"] * 53 / r["useful_valu_per_cell_step"]) < 1e-9
+                        assert b["config"]["tuned"]["share_taps"] in (True, False)
     else:  # round 1 format
         assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
