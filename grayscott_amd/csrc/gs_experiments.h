@@ -34,6 +34,11 @@
 #ifndef GS_TB_AUX_STORE
 #define GS_TB_AUX_STORE 0
 #endif
+// GS_VS_ABLATE_HALO 1 = TIMING ONLY, WRONG RESULTS: the march with full difference sharing without its halo board (no LDS
+//                  writes or reads; a lane's halo columns are its own): what the LDS round trip per level costs.
+#ifndef GS_VS_ABLATE_HALO
+#define GS_VS_ABLATE_HALO 0
+#endif
 // GS_WIN_LATE_ROW  1 = the persistent window kernel computes the last of a wave's middle rows behind the step's barrier,
 //                  after issuing the reads of the neighbouring waves' rows (hides the LDS read burst of 16 waves in
 //                  lock-step); 0 = all middle rows before the barrier (round 4's order).

@@ -348,6 +348,9 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
             for (int i = 0; i < K * 2 * 4; ++i) fb.halo[i * kHaloArray + lane * (kHaloArray - 1)] = 0.0f;
         // a new row of level j: its columns go to the board, for the neighbouring lanes
         auto put = [&](int j, int slot, const RowQ<CPL> &r) {
+#if GS_VS_ABLATE_HALO
+            return; // (timing experiment: no halo traffic at all; results are wrong)
+#endif
             float *b = mine + (j * 2 + slot) * kHaloRow;
             b[0] = r.u[0]; b[kHaloArray] = r.v[0]; b[2 * kHaloArray] = r.u[1]; b[3 * kHaloArray] = r.v[1];
             // The elements a lane reads back are written by its NEIGHBOURS, in the same two instructions: to the
@@ -361,8 +364,13 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
         auto widened = [&](int j, int slot) {
             const float *b = mine + (j * 2 + slot) * kHaloRow;
             RowT<CPL> w;
+#if GS_VS_ABLATE_HALO
+            w.u[0] = R[j][slot].u[1]; w.v[0] = R[j][slot].v[1]; w.u[3] = R[j][slot].u[0]; w.v[3] = R[j][slot].v[0];
+            (void)b;
+#else
             w.u[0] = b[2 * kHaloArray - 1]; w.v[0] = b[3 * kHaloArray - 1]; // second column of lane - 1
             w.u[3] = b[1];                  w.v[3] = b[kHaloArray + 1];     // first column of lane + 1
+#endif
             w.u[1] = R[j][slot].u[0]; w.u[2] = R[j][slot].u[1]; w.v[1] = R[j][slot].v[0]; w.v[2] = R[j][slot].v[1];
             return w;
         };

@@ -68,6 +68,10 @@ for stage in "$@"; do
     profile)
       IFS=: read -r ptag extra <<< "$rest"
       GS_BENCH_EXTRA="$extra" timeout -k 10 1100 bash tools/profile_gpu.sh "$ptag" 400 > "$OUT/profile_$ptag.log" 2>&1; rc=$?; tail -5 "$OUT/profile_$ptag.log" ;;
+    sqdetail)
+      # sqdetail:TAG[:bench args]   extra SQ counter passes over bench.py's headline launches (tools/profile_sq_detail.sh)
+      IFS=: read -r ptag extra <<< "$rest"
+      timeout -k 10 1100 bash tools/profile_sq_detail.sh "$ptag" $extra > "$OUT/sqdetail_$ptag.log" 2>&1; rc=$?; tail -30 "$OUT/sqdetail_$ptag.log" ;;
     kprofile)
       # kprofile:TAG:tools/run_steps.py,--rows,1080,...   rocprofv3 passes over a python tool (tools/profile_kernel.sh)
       IFS=: read -r ptag prog <<< "$rest"
@@ -98,6 +102,10 @@ for stage in "$@"; do
       # libpytest:NAME:FILE[,FILE...][:K+EXPRESSION]   GPU tests against grayscott_amd/variants/libgs_hip_NAME.so
       IFS=: read -r lib files kexpr <<< "$rest"
       GS_HIP_LIBRARY=$ROOT/grayscott_amd/variants/libgs_hip_$lib.so timeout -k 10 1100 python -m pytest ${files//,/ } -m gpu -x -q ${kexpr:+-k "${kexpr//+/ }"} > "$OUT/pytest_$lib.log" 2>&1; rc=$?; tail -8 "$OUT/pytest_$lib.log" ;;
+    libpy)
+      # libpy:NAME:SCRIPT[:args]   a python tool against grayscott_amd/variants/libgs_hip_NAME.so
+      IFS=: read -r lib script pyargs <<< "$rest"
+      GS_HIP_LIBRARY=$ROOT/grayscott_amd/variants/libgs_hip_$lib.so timeout -k 10 900 python "$script" ${pyargs//,/ } > "$OUT/$(basename "$script" .py)_$lib.log" 2>&1; rc=$?; tail -12 "$OUT/$(basename "$script" .py)_$lib.log" ;;
     py)
       IFS=: read -r script pyargs <<< "$rest"
       timeout -k 10 900 python "$script" ${pyargs//,/ } > "$OUT/$(basename "$script" .py).log" 2>&1; rc=$?; tail -40 "$OUT/$(basename "$script" .py).log" ;;

@@ -13,8 +13,8 @@ cd /tmp
 export GS_HIP_ROWS_PER_BLOCK=${GS_HIP_ROWS_PER_BLOCK:-122} GS_HIP_FUSE_STEPS=4 GS_HIP_COLS_PER_LANE=2
 pass() { # name counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o bench -- \
-      python3 "$ROOT/bench.py" --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-extra $BENCH_ARGS > "$OUT/bench_$name.json" 2> "$OUT/$name.log"
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o bench -- \
+      python3 "$ROOT/bench.py" --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-extra --no-verify $BENCH_ARGS > "$OUT/bench_$name.json" 2> "$OUT/$name.log"
 }
 BENCH_ARGS="$*"
 pass a SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES
@@ -29,7 +29,7 @@ for name in "abc":
         print(name, "no counters collected"); continue
     vals = {}
     for row in csv.DictReader(open(path)):
-        if "gs_step_tb_k" in row["Kernel_Name"]:
+        if "gs_step_tb" in row["Kernel_Name"]:
             vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     for k, v in sorted(vals.items()):
         print(f"{name} {k:28s} median {statistics.median(v):16.0f}  launches {len(v)}")
