@@ -18,17 +18,23 @@ bool share_on(const gs_ctx *ctx) { return ctx->o.share_taps == 1 || (ctx->o.shar
 
 // GsStepArgs::fast for this context's parameters: bit 0 = the four side weights are 0.5, bit 1 = dt == 1, bit 2 = both
 // and the diagonal weights are pairwise equal and the context wants full difference sharing.
-int fast_of(const gs_ctx *ctx)
+// ... as the parameters alone decide it: bit 2 = full difference sharing is possible (cells_vshare: the diagonal taps of a
+// row pair are each other's negatives when w00 == w22 and w02 == w20)
+static int fast_possible(const gs_ctx *ctx)
 {
     int fast = 0;
     if (!ctx->o.general_kernels) {
         const float(*w)[3] = ctx->p.w;
         if (w[0][1] == 0.5f && w[1][0] == 0.5f && w[1][2] == 0.5f && w[2][1] == 0.5f) fast |= 1;
         if (ctx->p.dt == 1.0f) fast |= 2;
-        // full difference sharing (cells_vshare): the diagonal taps of a row pair are each other's negatives
-        if (fast == 3 && w[0][0] == w[2][2] && w[0][2] == w[2][0] && ctx->o.share_taps != 2 && share_on(ctx)) fast |= 4;
+        if (fast == 3 && w[0][0] == w[2][2] && w[0][2] == w[2][0] && ctx->o.math == GS_MATH_STRICT) fast |= 4;
     }
     return fast;
+}
+int fast_of(const gs_ctx *ctx)
+{
+    const int fast = fast_possible(ctx);
+    return share_on(ctx) ? fast : fast & 3;
 }
 
 // Unit heights that make a launch of the temporally blocked kernel exactly `r` rounds of the chip's wave
@@ -290,11 +296,7 @@ int32_t tune_online(Run &r, int fuse)
             for (int h : heights(candn0, (int)(sizeof candn0 / sizeof candn0[0]), fuse, c)) { d_cpl.push_back(c); d_rpu.push_back(h); }
     const int nn = (int)d_cpl.size();
     // phase E: one candidate, where the choice is open and a variant with full difference sharing exists at all
-    const bool share_open = ctx->o.share_taps == 0 && ctx->o.math == GS_MATH_STRICT && [&] {
-        gs_ctx probe = *ctx; // (fast_of reads options and parameters only)
-        probe.o.share_taps = 1;
-        return (fast_of(&probe) & 4) != 0;
-    }();
+    const bool share_open = ctx->o.share_taps == 0 && (fast_possible(ctx) & 4) != 0;
     const int ne = share_open ? 1 : 0;
     // timed passes per candidate: short passes need more of them for a stable comparison
     const int reps = cells >= (1ull << 27) ? 2 : (cells >= (1ull << 24) ? 6 : 8);
