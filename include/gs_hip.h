@@ -47,7 +47,8 @@
  *     GS_RCCL_LIBRARY       library to bind instead of librccl (a custom RCCL build; the tests' shared-memory
  *                           transport double).  An explicit choice never falls back to the system's librccl.
  *     GS_HIP_TRACE_LAUNCH   1 = print the first 64 kernel launches (label, row ranges, layout) on stderr
- *     GS_HIP_TRACE_TUNER    1 = print every timing window of gs_run's on-line tuner and what it chose
+ *     GS_HIP_TRACE_TUNER    1 = print every timing window of gs_run's on-line tuner and what it chose, and every probe
+ *                           of gs_fields_place
  *   Launch-policy switches for A/B timing (defaults are the measured best; grayscott_amd/csrc/gs_experiments.h):
  *     GS_HIP_EDGE_KINDS     0 = edge units of the marching kernel all take the general path
  *     GS_HIP_EDGE_SPLIT     0 / 1 = never / always dispatch edge units as two half-height units
