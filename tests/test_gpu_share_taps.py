@@ -194,3 +194,22 @@ def test_the_tuner_decides_on_sharing_and_results_do_not_depend_on_it():
     assert tuned[0] > 0 and tuned[3] in (1, 2), tuned          # a choice was made, sharing included
     assert_bits_equal(outs[0][0], outs[1][0], f"U, tuner's choice {tuned} vs sharing off")
     assert_bits_equal(outs[0][1], outs[1][1], f"V, tuner's choice {tuned} vs sharing off")
+
+
+@pytest.mark.parametrize("kw", [dict(boundary=capi.GS_BOUNDARY_ZERO_HALO), dict(devices=[0, 0, 0]), dict(use_graph=1), dict(split=2),
+                                dict(devices=[0, 0], boundary=capi.GS_BOUNDARY_ZERO_HALO)])
+def test_shared_taps_under_the_other_schedules(kw):
+    """The sharing variant inside everything else gs_run can do with the marching kernel: the zero-halo rule (edge units
+    change, interior ones share), slab chains (interior units next to a seam read the neighbour's ghost rows, the
+    boundary bands are 4-row units), hipGraph replay, row bands."""
+    boundary = kw.get("boundary", capi.GS_BOUNDARY_CLIPPED)
+    for shape, seed in [((150, 700), 61), ((97, 1250), 62)]:
+        u0, v0 = stress_fields(shape, seed)
+        for steps in (9, 70):
+            ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True, boundary=boundary)
+            a = dict(kernel=capi.GS_KERNEL_TB, cols_per_lane=2, share_taps=1, rows_per_block=9)
+            a.update(kw)
+            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(**a))
+            assert ".op.ds" in info[0], info
+            assert_bits_equal(got_u, ref_u, f"U {info[0]} {shape} steps {steps} {kw}")
+            assert_bits_equal(got_v, ref_v, f"V {info[0]} {shape} steps {steps} {kw}")
