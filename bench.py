@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the replay that compares the timed planes with an independent run (and, on one GPU, "
                          "the single-step HBM leg that is part of it)")
+    ap.add_argument("--no-place", action="store_true",
+                    help="planes as hipMalloc hands them out (default: Species of >= 2^26 cells per GPU are placed by "
+                         "measurement, gs_fields_place with 28 candidate blocks)")
     ap.add_argument("--no-peer-chain", action="store_true",
                     help="N > 1: skip rank 0's in-process chain over all GPUs (hipMemcpyPeerAsync, no RCCL) after the timed job")
     ap.add_argument("--bootstrap", choices=("nccl", "gloo"), default="nccl",
@@ -168,19 +171,21 @@ def main() -> int:
     # Nothing is allocated, freed or filled between tuning and timing -- round 2's line read 8 % low because 4 GiB of
     # planes were created in that gap and the first launches after it ran on an idle chip's clocks.  The same holds for
     # the planes of the replay (single GPU: a second context pinned to the single-step stream kernel).
+    # Placement by measurement (gs_fields_place): about one 1 GiB block in six reads fast, and since round 5 the marching
+    # kernel is fast enough to feel it (1.09 M on four blocks as hipMalloc hands them out, 1.22 M on four fast ones,
+    # profiles/r05_cross_lane.md).  Every Species of the timed regions and of the replay takes the best four of 32 blocks.
+    place = 28 if cells_per_gpu >= (1 << 26) and not args.no_place else 0
     with stage("setup", 900):
-        species = sim.make_species([rows, cols])
+        species = sim.make_species([rows, cols], place_candidates=place)
         species.steps_done = 0
         sp_dev, sim_s, sp_s, sp_dev_s = None, None, None, None
         if single and verify:
             sim_s = Simulation.new(Parameters(), HipArgs(devices=[local_rank], kernel=capi.GS_KERNEL_STREAM))
-            # placement by measurement (gs_fields_place): the HBM-bound single-step kernel reads at one of three levels
-            # depending on where its four planes land; the replay's Species takes the best four of sixteen blocks
-            sp_s = sim_s.make_species([rows, cols], place_candidates=0 if cells < (1 << 26) else 12)
+            sp_s = sim_s.make_species([rows, cols], place_candidates=place)
             sp_s.steps_done = 0
         if with_extra:
             u0, v0 = developed_start(rows, cols)
-            sp_dev = upload_species(sim, u0, v0)
+            sp_dev = upload_species(sim, u0, v0, place)
             if sim_s is not None:
                 sp_dev_s = upload_species(sim_s, u0, v0)
             del u0, v0
@@ -374,7 +379,10 @@ def main() -> int:
             "cells_per_gpu": cells // world,
             "kernel": kernel_name,
             "tuned": {"rows_per_unit": tuned[0], "steps_per_pass": tuned[1], "cols_per_lane": tuned[2],
-                      "share_taps": tuned[3] == 1 if tuned[3] else None},
+                      "share_taps": {1: "within lanes", 2: "off", 3: "across lanes"}.get(tuned[3])},
+            # (ms per single step of the first four blocks, of the chosen four) as gs_fields_place's probes read them
+            "placement": {"candidates": place, "timed_species_ms": getattr(species, "placement", None),
+                          "developed_species_ms": getattr(sp_dev, "placement", None) if sp_dev is not None else None},
             "launches_per_pass": 1 if single else 2,
             "partition": "single GPU" if single else f"{world} row slabs, RCCL send/recv ghost rows",
         },

@@ -11,7 +11,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from .harness import (BYTES_PER_CELL_STEP, HBM_COPY_CEILING_GBS, HBM_PEAK_GBS, NOMINAL_SCLK_MHZ, USEFUL_VALU_PER_CELL_STEP,
-                      USEFUL_VALU_PER_CELL_STEP_SHARED, VALU_PEAK_TLANEOPS, usable_cpus)
+                      USEFUL_VALU_PER_CELL_STEP_SHARED, USEFUL_VALU_PER_CELL_STEP_SHARED_ACROSS, VALU_PEAK_TLANEOPS, usable_cpus)
 
 
 def cpu_baseline(target_seconds: float = 12.0):
@@ -120,16 +120,14 @@ def developed_start(rows, cols):
     return u0, v0
 
 
-def upload_species(sim, u0, v0):
-    """A Species of `sim`'s context whose input planes hold (u0, v0); `steps_done` counts what it has run."""
-    from grayscott_amd import Evolving, HipConcentration, Species
-
+def upload_species(sim, u0, v0, place_candidates: int = 0):
+    """A Species of `sim`'s context whose input planes hold (u0, v0); `steps_done` counts what it has run.
+    `place_candidates` > 0: its four planes are placed by measurement first (gs_fields_place)."""
     ctx = sim.context
-    u = Evolving([HipConcentration(ctx, u0.shape), HipConcentration(ctx, u0.shape)])
-    v = Evolving([HipConcentration(ctx, u0.shape), HipConcentration(ctx, u0.shape)])
-    u.in_out()[0].upload(ctx, u0)
-    v.in_out()[0].upload(ctx, v0)
-    species = Species(ctx, u, v)
+    species = sim.make_species(list(u0.shape), place_candidates=place_candidates)
+    in_u, in_v, _, _ = species.in_out()
+    in_u.upload(ctx, u0)
+    in_v.upload(ctx, v0)
     species.steps_done = 0
     return species
 
@@ -275,7 +273,7 @@ def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_
             c.destroy()
     if getattr(sp_s, "placement", None):
         first, best = sp_s.placement
-        single_step["placement"] = {"how": "gs_fields_place: best four of 4 + 12 candidate blocks, single-step probes",
+        single_step["placement"] = {"how": "gs_fields_place: best four of the candidate blocks (config.placement.candidates + 4), single-step probes",
                                     "first_blocks_ms_per_step": first, "chosen_blocks_ms_per_step": best,
                                     "first_blocks_frac_of_8TBps": BYTES_PER_CELL_STEP * cells / (first * 1e-3) / 1e9 / HBM_PEAK_GBS if first else None,
                                     "chosen_blocks_frac_of_8TBps": BYTES_PER_CELL_STEP * cells / (best * 1e-3) / 1e9 / HBM_PEAK_GBS if best else None}
@@ -302,7 +300,10 @@ def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_
 def useful_valu_per_cell_step(kernel_name: str) -> int:
     """Arithmetic instructions per cell-step of the kernel's form of the reference's update, each operation one
     instruction: 53 as the reference writes it (compute/naive/src/lib.rs:63-79), 46 with full difference sharing at 2
-    columns per lane (the `.ds` variants: the N / NW / NE taps are the negated S / SE / SW taps of the row above)."""
+    columns per lane (the `.ds` variants: the N / NW / NE taps are the negated S / SE / SW taps of the row above), 41 when
+    the differences that cross a lane boundary are also formed once (the `.dx` variants)."""
+    if ".dx" in kernel_name:
+        return USEFUL_VALU_PER_CELL_STEP_SHARED_ACROSS
     return USEFUL_VALU_PER_CELL_STEP_SHARED if ".ds" in kernel_name else USEFUL_VALU_PER_CELL_STEP
 
 

@@ -647,6 +647,9 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
         st = fail(GS_ERR_INVALID, "tile_shape must be 0 (auto), 1 (32 x 64), 2 (16 x 64) or 3 (64 x 64), not %d", ctx->o.tile_shape);
     if (st == GS_OK && ctx->o.boundary != GS_BOUNDARY_CLIPPED && ctx->o.boundary != GS_BOUNDARY_ZERO_HALO)
         st = fail(GS_ERR_INVALID, "unknown boundary rule %d", ctx->o.boundary);
+    if (st == GS_OK && (ctx->o.share_taps < 0 || ctx->o.share_taps > 3))
+        st = fail(GS_ERR_INVALID, "share_taps must be 0 (chosen on line), 1 (within a lane), 2 (off) or 3 (across lanes too), not %d",
+                  ctx->o.share_taps);
     if (st != GS_OK) { delete ctx; return st; }
 
     const int32_t one = 0;

@@ -1,6 +1,7 @@
 // gs_fields.cpp -- planes (gs_field): one f32 array per species, slot and row slab in HBM, with ghost rows; the
 // Concentration contract of the reference (data/src/concentration/mod.rs:198-296) on the device: creation, fills, uploads,
 // downloads (blocking and overlapped), colour mapping, and placement by measurement.
+#include <algorithm>
 #include "gs_internal.h"
 
 using namespace gsi;
@@ -77,8 +78,8 @@ int32_t gs_field_create(gs_ctx *ctx, gs_field **out, uint64_t rows, uint64_t col
 int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidates, float *first_ms, float *best_ms)
 {
     if (!ctx || !planes) return fail(GS_ERR_INVALID, "null argument");
-    if (candidates < 1 || candidates > 12) return fail(GS_ERR_INVALID, "1 to 12 extra candidate blocks, not %d", candidates);
-    if (ctx->total_slabs() != 1) return fail(GS_ERR_UNSUPPORTED, "placement by measurement is for single-slab contexts");
+    if (candidates < 1 || candidates > 28) return fail(GS_ERR_INVALID, "1 to 28 extra candidate blocks, not %d", candidates);
+    if (ctx->slabs.size() != 1) return fail(GS_ERR_UNSUPPORTED, "placement by measurement is for contexts with one slab per process");
     for (int i = 0; i < 4; ++i) {
         if (!planes[i] || planes[i]->ctx != ctx) return fail(GS_ERR_INVALID, "bad plane %d", i);
         GS_TRY(same_shape(planes[0], planes[i]));
@@ -141,13 +142,28 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
     };
     int best[4] = {0, 1, 2, 3};
     float best_t = 0.0f, first_t = 0.0f;
-    // the four that are there, then pseudo-random 4-subsets of the pool (a fixed sequence: the same candidates every time)
+    // Phase 1: the four that are there, then pseudo-random 4-subsets of the pool (a fixed sequence: the same candidates
+    // every time), 12 per block on average.  A probe's time is, to a good approximation, a sum over its four blocks
+    // (profiles/r05_cross_lane.md: about one block in six is "fast", a set reads at one of five levels by how many fast
+    // blocks it holds), so the mean over the probes a block took part in ranks the blocks.
     uint32_t rng = 0x9e3779b9u;
     const int trials = have > 4 ? 3 * have : 1;
+    std::vector<float> sum((size_t)have, 0.0f);
+    std::vector<int> cnt((size_t)have, 0);
+    static const bool trace = gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1) != 0;
+    auto timed = [&](const int (&pick)[4], float *ms) -> int32_t {
+        const int32_t st = probe(pick, ms);
+        if (st != GS_OK) return st;
+        if (trace)
+            std::fprintf(stderr, "gs_hip placement: blocks %2d %2d %2d %2d (%p %p %p %p): %.4f ms per step\n", pick[0], pick[1], pick[2],
+                         pick[3], (void *)blocks[(size_t)pick[0]], (void *)blocks[(size_t)pick[1]], (void *)blocks[(size_t)pick[2]],
+                         (void *)blocks[(size_t)pick[3]], *ms / 4.0f);
+        return GS_OK;
+    };
     for (int t = 0; t < trials; ++t) {
         int pick[4] = {0, 1, 2, 3};
         if (t > 0) {
-            int order[16];
+            int order[32];
             for (int i = 0; i < have; ++i) order[i] = i;
             for (int i = 0; i < 4; ++i) { // partial Fisher-Yates
                 rng = rng * 1664525u + 1013904223u;
@@ -157,31 +173,29 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
             }
         }
         float ms = 0.0f;
-        const int32_t st = probe(pick, &ms);
+        const int32_t st = timed(pick, &ms);
         if (st != GS_OK) { release(4); return st; }
         if (t == 0) first_t = ms;
-        static const bool trace = gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1) != 0;
-        if (trace)
-            std::fprintf(stderr, "gs_hip placement: blocks %2d %2d %2d %2d (%p %p %p %p): %.4f ms per step\n", pick[0], pick[1], pick[2],
-                         pick[3], (void *)blocks[(size_t)pick[0]], (void *)blocks[(size_t)pick[1]], (void *)blocks[(size_t)pick[2]],
-                         (void *)blocks[(size_t)pick[3]], ms / 4.0f);
+        for (int i = 0; i < 4; ++i) { sum[(size_t)pick[i]] += ms; ++cnt[(size_t)pick[i]]; }
         if (t == 0 || ms < 0.995f * best_t) { best_t = ms; std::memcpy(best, pick, sizeof best); }
     }
-    // one sweep of single-block exchanges around the best set found: every member against every block outside it
+    // Phase 2: every 4-subset of the six best-ranked blocks (15 probes)
     if (have > 4) {
-        for (int i = 0; i < 4; ++i)
-            for (int b = 0; b < have; ++b) {
-                bool member = false;
-                for (int j = 0; j < 4; ++j) member = member || best[j] == b;
-                if (member) continue;
-                int pick[4];
-                std::memcpy(pick, best, sizeof pick);
-                pick[i] = b;
-                float ms = 0.0f;
-                const int32_t st = probe(pick, &ms);
-                if (st != GS_OK) { release(4); return st; }
-                if (ms < 0.995f * best_t) { best_t = ms; std::memcpy(best, pick, sizeof best); }
-            }
+        std::vector<int> rank;
+        for (int b = 0; b < have; ++b)
+            if (cnt[(size_t)b] > 0) rank.push_back(b);
+        std::sort(rank.begin(), rank.end(), [&](int x, int y) { return sum[(size_t)x] / cnt[(size_t)x] < sum[(size_t)y] / cnt[(size_t)y]; });
+        const int top = (int)rank.size() < 6 ? (int)rank.size() : 6;
+        for (int i0 = 0; i0 < top; ++i0)
+            for (int i1 = i0 + 1; i1 < top; ++i1)
+                for (int i2 = i1 + 1; i2 < top; ++i2)
+                    for (int i3 = i2 + 1; i3 < top; ++i3) {
+                        const int pick[4] = {rank[(size_t)i0], rank[(size_t)i1], rank[(size_t)i2], rank[(size_t)i3]};
+                        float ms = 0.0f;
+                        const int32_t st = timed(pick, &ms);
+                        if (st != GS_OK) { release(4); return st; }
+                        if (ms < 0.995f * best_t) { best_t = ms; std::memcpy(best, pick, sizeof best); }
+                    }
     }
     // hand the chosen blocks to the planes; the probes have written into every block: zeros again
     std::vector<float *> chosen(4);

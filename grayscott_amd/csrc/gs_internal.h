@@ -122,7 +122,7 @@ struct gs_ctx {
     uint64_t tuned_rows = 0, tuned_cols = 0;
     int tuned_fuse = 0, tuned_rpu = 0, tuned_split = 0, tuned_k = 0; // tuned_k: fused steps per pass chosen
     int tuned_cpl = 0;                                               // columns per lane chosen
-    int tuned_share = 1;                                             // full difference sharing chosen (0 / 1)
+    int tuned_share = 1;                                             // difference sharing chosen (share_mode: 0 / 1 / 2)
     // every finished choice (a context that alternates between grids does not re-tune)
     struct Tuned { uint64_t rows, cols; int fuse, rpu, split, k, cpl, share; };
     std::vector<Tuned> tuned_cache;
@@ -174,7 +174,7 @@ struct gs_ctx {
         int32_t seq = 0;
         uint64_t fallbacks = 0;
     } win;
-    int share_now = 1; // full difference sharing in force when gs_options.share_taps leaves the choice open (fast_of)
+    int share_now = 1; // form of difference sharing in force when gs_options.share_taps leaves the choice open (share_mode)
     int cu_count = 0; // compute units of the first slab's device
     int total_slabs() const { return world * (int)slabs.size(); }
     int global_index(int i) const { return rank * (int)slabs.size() + i; }
@@ -216,7 +216,7 @@ int32_t run_steps(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_fiel
                   bool allow_window);
 // gs_tuner.cpp
 long tb_strips(int32_t cols, int fuse, int cpl);
-bool share_on(const gs_ctx *ctx);
+int share_mode(const gs_ctx *ctx);
 int fast_of(const gs_ctx *ctx);
 int fit_heights(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse, int cpl, int fast, int *out, int max, bool partial = false);
 bool tuned_for(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse);

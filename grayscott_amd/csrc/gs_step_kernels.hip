@@ -313,17 +313,18 @@ static int tb_waves_of(const void *f)
 }
 
 // The variant that runs for GsStepArgs::fast = `fast` with k fused steps, cpl columns per lane and wg waves per
-// workgroup: 0 (general), 1 (side weights 0.5), 3 (and dt == 1) or 7 (and full difference sharing: built for 2 columns
-// per lane, 2 to 4 fused steps).
+// workgroup: 0 (general), 1 (side weights 0.5), 3 (and dt == 1), 7 (and full difference sharing: built for 2 columns
+// per lane, 2 to 4 fused steps) or 15 (and across lanes).
 static int tb_reduce_fast(int fast, int k = 0, int cpl = 0, int wg = 4)
 {
     // The fused build has no use for bit 0 (its taps are sub + fma already) and measured slower
     // with bit 1 (profiles/r01_sweeps.md, runs 48/49): it always runs the general variant.  dt == 1
     // alone (fast == 2) is not worth a variant either, and bit 2 means nothing without the other two.
-    fast &= GS_MATH_FUSED ? 0 : 7;
+    fast &= GS_MATH_FUSED ? 0 : 15;
     if (!(fast & 1)) return 0;
-    if (fast == 7) {
+    if ((fast & 7) == 7) {
 #if !GS_MATH_FUSED
+        if ((fast & 8) && gs_tb_op_kernel_strict(k, 15, cpl, wg)) return 15;
         if (gs_tb_op_kernel_strict(k, 7, cpl, wg)) return 7;
 #endif
         return 3;
@@ -350,17 +351,22 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
      {"tb-k1" C "/" GS_MATH_NAME ".op", "tb-k2" C "/" GS_MATH_NAME ".op", "tb-k3" C "/" GS_MATH_NAME ".op",            \
       "tb-k4" C "/" GS_MATH_NAME ".op"},                                                        \
      {"tb-k1" C "/" GS_MATH_NAME ".op.ds", "tb-k2" C "/" GS_MATH_NAME ".op.ds", "tb-k3" C "/" GS_MATH_NAME ".op.ds",   \
-      "tb-k4" C "/" GS_MATH_NAME ".op.ds"}}
-    static const char *const names[3][3][4] = {GS_TB_NAMES("c1"), GS_TB_NAMES("c2"), GS_TB_NAMES("")};
+      "tb-k4" C "/" GS_MATH_NAME ".op.ds"},                                                     \
+     {"tb-k1" C "/" GS_MATH_NAME ".op.dx", "tb-k2" C "/" GS_MATH_NAME ".op.dx", "tb-k3" C "/" GS_MATH_NAME ".op.dx",   \
+      "tb-k4" C "/" GS_MATH_NAME ".op.dx"}}
+    // ".op.dx": ... and across lanes (tb_march, FAST & 8)
+    static const char *const names[3][4][4] = {GS_TB_NAMES("c1"), GS_TB_NAMES("c2"), GS_TB_NAMES("")};
 #undef GS_TB_NAMES
     // "f": the fair-progress form (16-wave workgroups) of one-round launches
-    static const char *const names16[2][3] = {{"tb-k4c1f/" GS_MATH_NAME, "tb-k4c1f/" GS_MATH_NAME ".op", "tb-k4c1f/" GS_MATH_NAME ".op.ds"},
-                                              {"tb-k4c2f/" GS_MATH_NAME, "tb-k4c2f/" GS_MATH_NAME ".op", "tb-k4c2f/" GS_MATH_NAME ".op.ds"}};
+    static const char *const names16[2][4] = {
+        {"tb-k4c1f/" GS_MATH_NAME, "tb-k4c1f/" GS_MATH_NAME ".op", "tb-k4c1f/" GS_MATH_NAME ".op.ds", "tb-k4c1f/" GS_MATH_NAME ".op.dx"},
+        {"tb-k4c2f/" GS_MATH_NAME, "tb-k4c2f/" GS_MATH_NAME ".op", "tb-k4c2f/" GS_MATH_NAME ".op.ds", "tb-k4c2f/" GS_MATH_NAME ".op.dx"}};
+    auto name_of = [](int f) { return f == 15 ? 3 : (f == 7 ? 2 : (f ? 1 : 0)); };
     if (k < 1 || k > 4 || a.cols <= 0 || a.rows_per_unit <= 0) return hipErrorInvalidValue;
     const int cpl = a.cpl == 0 ? 4 : a.cpl;
     if (cpl != 1 && cpl != 2 && cpl != 4) return hipErrorInvalidValue;
     const int fast = tb_reduce_fast(a.fast, k, cpl);
-    if (name) *name = names[cpl == 1 ? 0 : (cpl == 2 ? 1 : 2)][fast == 7 ? 2 : (fast ? 1 : 0)][k - 1];
+    if (name) *name = names[cpl == 1 ? 0 : (cpl == 2 ? 1 : 2)][name_of(fast)][k - 1];
     const long rpu = a.rows_per_unit;
     const long rows_a = (long)a.ra1 - a.ra0;
     const long W = tb_cols_per_wave(k, cpl);
@@ -455,7 +461,7 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     args.fair_from = fair_from_env >= 0 ? fair_from_env : 0;
     void *kargs[] = {&args};
     if (fair_fn) {
-        if (name) *name = names16[cpl == 1 ? 0 : 1][fast16 == 7 ? 2 : (fast16 ? 1 : 0)];
+        if (name) *name = names16[cpl == 1 ? 0 : 1][name_of(fast16)];
         return hipLaunchKernel(fair_fn, dim3((unsigned)((units + 15) / 16)), dim3(1024), kargs, 0, s);
     }
     const long blocks = (units + 3) / 4;
@@ -530,6 +536,16 @@ const void *gs_tb_op_kernel_strict(int k, int fast, int cpl, int wg)
         case 2: return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_ds_k)<2>);
         case 3: return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_ds_k)<3>);
         case 4: return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_ds_k)<4>);
+        default: return nullptr;
+        }
+    }
+    if (fast == 15) { // ... and across lanes
+        if (cpl != 2) return nullptr;
+        if (wg == 16) return k == 4 ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_dx_k)<4, 16>) : nullptr;
+        switch (k) {
+        case 2: return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_dx_k)<2>);
+        case 3: return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_dx_k)<3>);
+        case 4: return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_dx_k)<4>);
         default: return nullptr;
         }
     }

@@ -12,12 +12,21 @@ long tb_strips(int32_t cols, int fuse, int cpl)
     return (cols + w - 1) / w;
 }
 
-// Is full difference sharing in force (when the parameters allow it)?  Pinned by gs_options.share_taps, else what the
-// on-line tuner last chose or is trying (gs_ctx::share_now), else on.
-bool share_on(const gs_ctx *ctx) { return ctx->o.share_taps == 1 || (ctx->o.share_taps == 0 && ctx->share_now != 0); }
+// The form of difference sharing in force (when the parameters allow it): 0 = none, 1 = within a lane (the halo-board
+// march), 2 = also across lanes.  Pinned by gs_options.share_taps (1 / 2 / 3 = within / none / across), else what the
+// on-line tuner last chose or is trying (gs_ctx::share_now), else 1.
+int share_mode(const gs_ctx *ctx)
+{
+    switch (ctx->o.share_taps) {
+    case 1: return 1;
+    case 2: return 0;
+    case 3: return 2;
+    default: return ctx->share_now;
+    }
+}
 
 // GsStepArgs::fast for this context's parameters: bit 0 = the four side weights are 0.5, bit 1 = dt == 1, bit 2 = both
-// and the diagonal weights are pairwise equal and the context wants full difference sharing.
+// and the diagonal weights are pairwise equal and the context wants full difference sharing, bit 3 = also across lanes.
 // ... as the parameters alone decide it: bit 2 = full difference sharing is possible (cells_vshare: the diagonal taps of a
 // row pair are each other's negatives when w00 == w22 and w02 == w20)
 static int fast_possible(const gs_ctx *ctx)
@@ -33,8 +42,9 @@ static int fast_possible(const gs_ctx *ctx)
 }
 int fast_of(const gs_ctx *ctx)
 {
-    const int fast = fast_possible(ctx);
-    return share_on(ctx) ? fast : fast & 3;
+    const int fast = fast_possible(ctx), mode = share_mode(ctx);
+    if (!(fast & 4) || mode == 0) return fast & 3;
+    return mode == 2 ? fast | 8 : fast;
 }
 
 // Unit heights that make a launch of the temporally blocked kernel exactly `r` rounds of the chip's wave
@@ -295,9 +305,10 @@ int32_t tune_online(Run &r, int fuse)
         for (int c : cpls)
             for (int h : heights(candn0, (int)(sizeof candn0 / sizeof candn0[0]), fuse, c)) { d_cpl.push_back(c); d_rpu.push_back(h); }
     const int nn = (int)d_cpl.size();
-    // phase E: one candidate, where the choice is open and a variant with full difference sharing exists at all
+    // phase E: two candidates (sharing across lanes too, no sharing), where the choice is open and a variant with full
+    // difference sharing exists at all
     const bool share_open = ctx->o.share_taps == 0 && (fast_possible(ctx) & 4) != 0;
-    const int ne = share_open ? 1 : 0;
+    const int ne = share_open ? 2 : 0;
     // timed passes per candidate: short passes need more of them for a stable comparison
     const int reps = cells >= (1ull << 27) ? 2 : (cells >= (1ull << 24) ? 6 : 8);
     constexpr int kMaxBatch = (int)(sizeof(gs_ctx::Tuning::batch) / sizeof(gs_ctx::Trial));
@@ -359,7 +370,7 @@ int32_t tune_online(Run &r, int fuse)
                 std::fprintf(stderr, "gs_hip tuner %llux%llu: unit %3d rows, %d band(s), %d steps/pass, %d col/lane%s: "
                                      "%.4f ms/step (windows %.3f %.3f ms)\n",
                              (unsigned long long)f->rows, (unsigned long long)f->cols, t.rpu, t.V, t.k, t.cpl,
-                             t.share ? "" : ", taps not shared", ms, w0, w1);
+                             t.share == 1 ? "" : (t.share ? ", taps shared across lanes" : ", taps not shared"), ms, w0, w1);
             // prefer the incumbent unless the newcomer is clearly faster: by 1 %, or by 3 % when it
             // fuses fewer steps (more HBM traffic, slower remainder passes: a tie is not worth it)
             // ... and a taller unit of the same layout wins a near-tie: it recomputes fewer rows, and on large
@@ -430,12 +441,12 @@ int32_t tune_online(Run &r, int fuse)
                 t.V = tu->best_split;
                 t.k = altk[i];
                 if (t.rpu == 0 || t.k >= fuse) continue;
-            } else if (phase == 4) { // what phases A-D chose, without full difference sharing
+            } else if (phase == 4) { // what phases A-D chose, sharing across lanes too (the first) / without sharing
                 t.rpu = tu->best_rpu;
                 t.V = tu->best_split;
                 t.k = tu->best_k;
                 t.cpl = tu->best_cpl;
-                t.share = 0;
+                t.share = i == 0 ? 2 : 0;
                 // (only 2 columns per lane and 2 to 4 fused steps have a sharing variant: elsewhere nothing to compare)
                 if (t.rpu == 0 || t.cpl != 2 || t.k < 2) continue;
             } else { // phase 3 (phase 1 has no candidates)
@@ -490,7 +501,7 @@ int32_t tune_online(Run &r, int fuse)
         if (gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1))
             std::fprintf(stderr, "gs_hip tuner %llux%llu: chose unit %d rows, %d steps/pass, %d col/lane, taps %s\n",
                          (unsigned long long)f->rows, (unsigned long long)f->cols, done.rpu, done.k, done.cpl,
-                         done.share ? "shared" : "not shared");
+                         done.share == 1 ? "shared" : (done.share ? "shared across lanes" : "not shared"));
         for (auto e : tu->events)
             if (e) (void)hipEventDestroy(e);
         ctx->tunings.erase(ctx->tunings.begin() + (tu - ctx->tunings.data()));
@@ -510,7 +521,7 @@ int32_t gs_ctx_get_tuned(const gs_ctx *ctx, uint64_t slab_rows, uint64_t cols, i
     if (!ctx) return fail(GS_ERR_INVALID, "null context");
     int rpu = 0, k = 0, cpl = 0, share = 0;
     for (const gs_ctx::Tuned &t : ctx->tuned_cache)
-        if (t.rows == slab_rows && t.cols == cols) { rpu = t.rpu; k = t.k; cpl = t.cpl; share = t.share ? 1 : 2; } // the newest entry wins
+        if (t.rows == slab_rows && t.cols == cols) { rpu = t.rpu; k = t.k; cpl = t.cpl; share = t.share == 1 ? 1 : (t.share ? 3 : 2); } // the newest entry wins
     if (rows_per_block) *rows_per_block = rpu;
     if (fuse_steps) *fuse_steps = k;
     if (cols_per_lane) *cols_per_lane = cpl;
@@ -523,13 +534,13 @@ int32_t gs_ctx_set_tuned(gs_ctx *ctx, uint64_t slab_rows, uint64_t cols, int32_t
 {
     if (!ctx) return fail(GS_ERR_INVALID, "null context");
     if (rows_per_block < 1 || fuse_steps < 1 || fuse_steps > kGhostRows ||
-        (cols_per_lane != 1 && cols_per_lane != 2 && cols_per_lane != 4) || share_taps < 0 || share_taps > 2)
+        (cols_per_lane != 1 && cols_per_lane != 2 && cols_per_lane != 4) || share_taps < 0 || share_taps > 3)
         return fail(GS_ERR_INVALID, "bad configuration (unit %d rows, %d steps per pass, %d columns per lane, share_taps %d)",
                     rows_per_block, fuse_steps, cols_per_lane, share_taps);
     // keyed like gs_run's own choices: by the steps per pass it was asked to fuse
     const int fuse = ctx->o.fuse_steps > 0 ? (ctx->o.fuse_steps > kGhostRows ? kGhostRows : ctx->o.fuse_steps) : kGhostRows;
     if (fuse_steps > fuse) return fail(GS_ERR_INVALID, "%d steps per pass exceed fuse_steps = %d", fuse_steps, fuse);
-    remember_tuned(ctx, gs_ctx::Tuned{slab_rows, cols, fuse, rows_per_block, 1, fuse_steps, cols_per_lane, share_taps == 2 ? 0 : 1});
+    remember_tuned(ctx, gs_ctx::Tuned{slab_rows, cols, fuse, rows_per_block, 1, fuse_steps, cols_per_lane, share_taps == 2 ? 0 : (share_taps == 3 ? 2 : 1)});
     return GS_OK;
 }
 

@@ -174,9 +174,12 @@ typedef struct gs_options {
     int32_t share_taps;      /* full difference sharing in the temporally blocked kernel (the S / SE / SW taps of a  *
                               * row are, negated, the N / NW / NE taps of the next: 46 instead of 52 arithmetic    *
                               * instructions per cell-step, bit-identical; needs side weights 0.5, dt == 1 and      *
-                              * w[0][0] == w[2][2], w[0][2] == w[2][0] -- true of every stencil of the reference -- *
-                              * and runs at 3 instead of 4 waves per SIMD): 0 = chosen on line by gs_run like the  *
-                              * unit height (slab chains and untuned runs: on), 1 = on, 2 = off                    */
+                              * w[0][0] == w[2][2], w[0][2] == w[2][0] -- true of every stencil of the reference):  *
+                              * 0 = chosen on line by gs_run like the unit height (slab chains and untuned runs: 1), *
+                              * 1 = on, 2 = off, 3 = on and ACROSS lanes too (the three differences that cross a    *
+                              * lane boundary are computed by one of the two lanes and read by the other as DPP      *
+                              * operands: 41 instructions per cell-step, half the LDS traffic; faster where the      *
+                              * power cap sets the clock, slower where issue slots do)                               */
     int32_t reserved[3];
 } gs_options;
 
@@ -272,16 +275,19 @@ int32_t gs_step(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs
 int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *v1,
                uint64_t steps, int32_t *result_slot);
 
-/* Placement by measurement, for the planes of a large Species on a single-slab context (optional; the HBM-bound
- * single-step kernel gains up to 14 %, the temporally blocked kernel of gs_run does not care).  Where a hipMalloc lands
- * in HBM is below what a process controls, and four 1 GiB planes read at one of three levels (0.66 / 0.70 / 0.75 of
- * 8 TB/s at 16384^2) depending on it.  This call draws `candidates` (1..12) more blocks of the planes' size, times the
- * single-step kernel over 4-subsets of the pool (3 x pool-size random subsets, then one sweep of single-block exchanges
- * around the best: ~100 probes of four steps each, 0.4 s at 16384^2 with 12 candidates), gives the four planes the blocks
- * that read best together and frees the rest.  Measured (profiles/r05_placement.md): first four blocks 0.63-0.66 of
- * 8 TB/s, best of 4 + 4 blocks 0.67-0.68, best of 4 + 12 blocks 0.70-0.75.  Call it on FRESHLY CREATED planes, before they
- * are filled: their contents are not kept -- all four are zero-filled on return, as gs_field_create leaves them.
- * first_ms / best_ms (optional): time per step of the planes' original blocks and of the chosen ones. */
+/* Placement by measurement, for the planes of a large Species on a context with one slab per process (optional; the
+ * HBM-bound single-step kernel gains up to 19 %, the temporally blocked kernel of gs_run up to 12 % at 16384^2: since
+ * round 5 it is fast enough to be held back by badly placed planes, 1.09 M instead of 1.22 M Mcells x steps/s).  Where a
+ * hipMalloc lands in HBM is below what a process controls: about one 1 GiB block in six reads fast, and four planes
+ * read at one of several levels (0.65 ... 0.75 of 8 TB/s at 16384^2) by how many fast blocks they hold.  This call draws
+ * `candidates` (1..28) more blocks of the planes' size, times the single-step kernel over 3 x pool-size random 4-subsets
+ * of the pool, ranks the blocks by the mean time of the subsets they were in, times every 4-subset of the six best-ranked
+ * (~110 probes of four steps each, 0.5 s at 16384^2 with 28 candidates, 32 GiB held meanwhile), gives the four planes the
+ * blocks that read best together and frees the rest.  Measured (profiles/r05_placement.md, r05_cross_lane.md): first
+ * four blocks 0.63-0.66 of 8 TB/s, best of 4 + 12 blocks 0.70-0.75 (0.68 when the pool holds fewer than four fast
+ * blocks), best of 4 + 28 blocks 0.75.  Call it on FRESHLY CREATED planes, before they are filled: their contents are not
+ * kept -- all four are zero-filled on return, as gs_field_create leaves them.  first_ms / best_ms (optional): time per
+ * step of the planes' original blocks and of the chosen ones. */
 int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidates, float *first_ms, float *best_ms);
 
 /* Wait for everything enqueued on this context (all local devices and streams). */
@@ -318,7 +324,7 @@ int32_t gs_timer_start(gs_ctx *ctx);
 int32_t gs_timer_stop(gs_ctx *ctx, float *elapsed_ms);
 
 /* The configuration gs_run uses for slabs of `slab_rows` x `cols` cells: unit height, steps fused per
- * pass, columns per lane, full difference sharing (1 = on, 2 = off, as gs_options.share_taps; _set_ takes 0 as "on")
+ * pass, columns per lane, full difference sharing (1 = on, 2 = off, 3 = across lanes too, as gs_options.share_taps; _set_ takes 0 as 1)
  * (zeros from _get_ when nothing was chosen yet).  Single-slab contexts find it
  * themselves (on-line tuning inside gs_run); a slab chain takes what it is given: one process tunes on a
  * single slab of the slab's shape, reads the result with _get_ and every process of the chain sets it

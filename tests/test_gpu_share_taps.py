@@ -1,7 +1,8 @@
-"""Full difference sharing in the temporally blocked kernel (gs_options.share_taps; cells_vshare in
+"""Full difference sharing in the temporally blocked kernel (gs_options.share_taps; cells_vshare and tb_march in
 grayscott_amd/csrc/gs_march.h): the S / SE / SW taps of a row are carried to the next row, where they are --
-negated -- its N / NW / NE taps.  The reference forms every tap afresh (compute/naive/src/lib.rs:63-71); the shared form
-must give the same BITS: ordinary data, data around the flush-to-zero threshold, signed zeros and equal neighbours
+negated -- its N / NW / NE taps; in the second form (share_taps = 3, ".op.dx") the differences that cross a lane
+boundary are also computed once, by the lane on the right, and read by the lane on the left as DPP operands.  The
+reference forms every tap afresh (compute/naive/src/lib.rs:63-71); both shared forms must give the same BITS: ordinary data, data around the flush-to-zero threshold, signed zeros and equal neighbours
 (where a tap is an exact or a flushed zero of either sign), non-finite values, and the stencils / rates for which the
 variant must NOT run.  Everything against the CPU oracle, through the C ABI.
 """
@@ -48,26 +49,34 @@ def _few_values_fields(shape, seed, values):
     return u0, v0
 
 
-SHARED = dict(kernel=capi.GS_KERNEL_TB, cols_per_lane=2, share_taps=1)
+# (gs_options.share_taps, what the launch label ends in): within a lane / across lanes too
+MODES = [(1, ".op.ds"), (3, ".op.dx")]
+mode_cases = pytest.mark.parametrize("mode", MODES, ids=["ds", "dx"])
 
 
+def shared(mode):
+    return dict(kernel=capi.GS_KERNEL_TB, cols_per_lane=2, share_taps=mode[0])
+
+
+@mode_cases
 @pytest.mark.parametrize("fuse", [4, 3, 2])
 @pytest.mark.parametrize("rpb", [1, 5, 12, 40])
-def test_shared_taps_bit_exact(fuse, rpb):
+def test_shared_taps_bit_exact(fuse, rpb, mode):
     """Interior units of every height (1 row: nothing but ramp-up ticks and one stored row; 40: several trips of the
     six-tick loop and its remainders), 2 to 4 fused steps, strips and chunks on every side of the interior ones."""
     for shape, maker, seed in [((61, 700), stress_fields, 21), ((64, 500), _tiny_fields, 22), ((130, 380), stress_fields, 23)]:
         u0, v0 = maker(shape, seed)
         for steps in (1, fuse, 2 * fuse + 1, 23):
             ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True)
-            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(fuse_steps=fuse, rows_per_block=rpb, **SHARED))
+            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(fuse_steps=fuse, rows_per_block=rpb, **shared(mode)))
             if steps >= fuse:
-                assert info[0].startswith(f"tb-k{fuse}c2/strict.op.ds"), info
+                assert info[0].startswith(f"tb-k{fuse}c2/strict{mode[1]}"), info
             assert_bits_equal(got_u, ref_u, f"U {info[0]} {shape} steps {steps} rpb {rpb}")
             assert_bits_equal(got_v, ref_v, f"V {info[0]} {shape} steps {steps} rpb {rpb}")
 
 
-def test_shared_taps_signed_zeros_and_equal_neighbours():
+@mode_cases
+def test_shared_taps_signed_zeros_and_equal_neighbours(mode):
     """Taps that are exact zeros of either sign, differences that flush: the carried tap has the other sign of zero than
     the tap the reference forms, and the accumulator must not be able to tell.  Also with feed = kill = 0, where the sign
     of a zero accumulator reaches the output (du = Du * acc - 0 + 0 * (1 - u))."""
@@ -79,12 +88,13 @@ def test_shared_taps_signed_zeros_and_equal_neighbours():
                 u0, v0 = _few_values_fields(shape, seed, vals)
                 for steps in (1, 4, 9):
                     ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True)
-                    got_u, got_v, info = gpu_run(u0, v0, steps, params=p, args=args(fuse_steps=4, rows_per_block=6, **SHARED))
+                    got_u, got_v, info = gpu_run(u0, v0, steps, params=p, args=args(fuse_steps=4, rows_per_block=6, **shared(mode)))
                     assert_bits_equal(got_u, ref_u, f"U {info[0]} {shape} steps {steps} {p}")
                     assert_bits_equal(got_v, ref_v, f"V {info[0]} {shape} steps {steps} {p}")
 
 
-def test_a_positive_zero_among_negative_zeros():
+@mode_cases
+def test_a_positive_zero_among_negative_zeros(mode):
     """The case a folded `0 - x` would get wrong: a cell +0 whose eight neighbours are -0 (every tap the reference forms
     is -0, its accumulator stays +0; the carried taps are +0), feed = 0 so that nothing hides the accumulator's sign."""
     shape = (40, 400)
@@ -95,20 +105,21 @@ def test_a_positive_zero_among_negative_zeros():
     p = Parameters(feed_rate=0.0, kill_rate=0.0)
     for steps in (1, 2, 4, 8):
         ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True)
-        got_u, got_v, info = gpu_run(u0, v0, steps, params=p, args=args(fuse_steps=4, rows_per_block=8, **SHARED))
-        assert ".op.ds" in info[0] or steps < 4, info
+        got_u, got_v, info = gpu_run(u0, v0, steps, params=p, args=args(fuse_steps=4, rows_per_block=8, **shared(mode)))
+        assert mode[1] in info[0] or steps < 4, info
         assert_bits_equal(got_u, ref_u, f"U {info[0]} steps {steps}")
         assert_bits_equal(got_v, ref_v, f"V {info[0]} steps {steps}")
 
 
-def test_shared_taps_spread_non_finite_values_like_the_reference():
+@mode_cases
+def test_shared_taps_spread_non_finite_values_like_the_reference(mode):
     u0, v0 = stress_fields((48, 520), 41)
     u0[20, 250] = np.nan
     v0[30, 130] = np.inf
     u0[10, 400] = -np.inf
     for steps in (1, 4, 6):
         ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True)
-        got_u, got_v, info = gpu_run(u0, v0, steps, args=args(fuse_steps=4, rows_per_block=8, **SHARED))
+        got_u, got_v, info = gpu_run(u0, v0, steps, args=args(fuse_steps=4, rows_per_block=8, **shared(mode)))
         # NaN payloads are not part of the contract: NaNs must sit in the same cells
         assert np.array_equal(np.isnan(got_u), np.isnan(ref_u)) and np.array_equal(np.isnan(got_v), np.isnan(ref_v)), info
         fin = ~np.isnan(ref_u) & ~np.isnan(ref_v)
@@ -121,9 +132,10 @@ def test_variant_only_where_its_conditions_hold():
     same bits either way, the label says which."""
     sym = ((0.125, 0.5, 0.375), (0.5, 0.0, 0.5), (0.375, 0.5, 0.125))      # w00 == w22, w02 == w20
     asym = ((0.125, 0.5, 0.375), (0.5, 0.0, 0.5), (0.75, 0.5, 1.0))
-    cases = [(Parameters(), 1, ".op.ds"), (Parameters(), 2, ".op"), (Parameters(weights=sym), 1, ".op.ds"),
-             (Parameters(weights=asym), 1, ".op"), (Parameters(time_step=0.5), 1, ".op"),
-             (Parameters(weights=((1, 1, 1), (1, 0, 1), (1, 1, 1))), 1, "strict")]
+    cases = [(Parameters(), 1, ".op.ds"), (Parameters(), 3, ".op.dx"), (Parameters(), 2, ".op"),
+             (Parameters(weights=sym), 1, ".op.ds"), (Parameters(weights=sym), 3, ".op.dx"),
+             (Parameters(weights=asym), 1, ".op"), (Parameters(weights=asym), 3, ".op"), (Parameters(time_step=0.5), 3, ".op"),
+             (Parameters(weights=((1, 1, 1), (1, 0, 1), (1, 1, 1))), 3, "strict")]
     u0, v0 = stress_fields((50, 600), 51)
     for p, share, suffix in cases:
         ref_u, ref_v = oracle.run(u0, v0, 9, oracle_params(p), ftz=True)
@@ -153,8 +165,8 @@ def test_species_new_and_a_developing_pattern_at_a_few_megacells():
     u0 += rng.random(u0.shape, dtype=np.float32) * np.float32(0.01)
     v0 += rng.random(v0.shape, dtype=np.float32) * np.float32(0.01)
     outs = []
-    for share in (1, 2):
-        # (a launch of one round of wave slots: the in-step form, 16-wave workgroups with 132 KB of halo boards)
+    for share in (1, 3, 2):
+        # (a launch of one round of wave slots: the in-step form, 16-wave workgroups with 132 / 65 KB of halo boards)
         sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_TB, cols_per_lane=2, share_taps=share, no_tune=1))
         sp_new = sim.make_species([rows, cols])
         sp_dev = species_from_arrays(sim, u0, v0)
@@ -162,23 +174,25 @@ def test_species_new_and_a_developing_pattern_at_a_few_megacells():
             sim.perform_steps(sp_new, n)
         sim.perform_steps(sp_dev, 400)
         label = sim.context.info()[0]
-        assert (".op.ds" in label) == (share == 1) and label.startswith("tb-k4c2f/"), label
+        assert label.split("@")[0] == "tb-k4c2f/strict" + {1: ".op.ds", 3: ".op.dx", 2: ".op"}[share], label
         outs.append([x.make_scalar_view(sim.context) for x in sp_new.in_out()[:2] + sp_dev.in_out()[:2]])
         sim.context.close()
-    for a, b, what in zip(outs[0], outs[1], ("new U", "new V", "pattern U", "pattern V")):
-        assert_bits_equal(a, b, what + " shared vs unshared")
-    # the oracle on the small pattern start, 40 steps, through the same configuration
+    for a, b, c, what in zip(outs[0], outs[1], outs[2], ("new U", "new V", "pattern U", "pattern V")):
+        assert_bits_equal(a, c, what + " shared vs unshared")
+        assert_bits_equal(b, c, what + " shared across lanes vs unshared")
+    # the oracle on the small pattern start, 40 steps, through the same configurations
     ref_u, ref_v = oracle.run(u0[:300, :600].copy(), v0[:300, :600].copy(), 40, ftz=True)
-    got_u, got_v, info = gpu_run(u0[:300, :600].copy(), v0[:300, :600].copy(), 40,
-                                 args=args(kernel=capi.GS_KERNEL_TB, cols_per_lane=2, share_taps=1, no_tune=1))
-    assert ".op.ds" in info[0], info
-    assert_bits_equal(got_u, ref_u, "pattern crop U")
-    assert_bits_equal(got_v, ref_v, "pattern crop V")
+    for share, suffix in MODES:
+        got_u, got_v, info = gpu_run(u0[:300, :600].copy(), v0[:300, :600].copy(), 40,
+                                     args=args(kernel=capi.GS_KERNEL_TB, cols_per_lane=2, share_taps=share, no_tune=1))
+        assert suffix in info[0], info
+        assert_bits_equal(got_u, ref_u, "pattern crop U " + suffix)
+        assert_bits_equal(got_v, ref_v, "pattern crop V " + suffix)
 
 
 def test_the_tuner_decides_on_sharing_and_results_do_not_depend_on_it():
-    """share_taps = 0: gs_run's on-line tuner times the configuration it chose with and without sharing (phase E) on
-    passes of the run itself and keeps the faster; whatever it keeps, and while it is still trying, the planes equal
+    """share_taps = 0: gs_run's on-line tuner times the configuration it chose with sharing within a lane, across lanes
+    and without (phase E) on passes of the run itself and keeps the fastest; whatever it keeps, and while it is still trying, the planes equal
     those of a run with sharing pinned off."""
     rows, cols = 1700, 2300
     outs, tuned = [], None
@@ -191,14 +205,15 @@ def test_the_tuner_decides_on_sharing_and_results_do_not_depend_on_it():
             tuned = sim.context.get_tuned(rows, cols)
         outs.append([x.make_scalar_view(sim.context) for x in sp.in_out()[:2]])
         sim.context.close()
-    assert tuned[0] > 0 and tuned[3] in (1, 2), tuned          # a choice was made, sharing included
+    assert tuned[0] > 0 and tuned[3] in (1, 2, 3), tuned         # a choice was made, sharing included
     assert_bits_equal(outs[0][0], outs[1][0], f"U, tuner's choice {tuned} vs sharing off")
     assert_bits_equal(outs[0][1], outs[1][1], f"V, tuner's choice {tuned} vs sharing off")
 
 
+@mode_cases
 @pytest.mark.parametrize("kw", [dict(boundary=capi.GS_BOUNDARY_ZERO_HALO), dict(devices=[0, 0, 0]), dict(use_graph=1), dict(split=2),
                                 dict(devices=[0, 0], boundary=capi.GS_BOUNDARY_ZERO_HALO)])
-def test_shared_taps_under_the_other_schedules(kw):
+def test_shared_taps_under_the_other_schedules(kw, mode):
     """The sharing variant inside everything else gs_run can do with the marching kernel: the zero-halo rule (edge units
     change, interior ones share), slab chains (interior units next to a seam read the neighbour's ghost rows, the
     boundary bands are 4-row units), hipGraph replay, row bands."""
@@ -207,9 +222,9 @@ def test_shared_taps_under_the_other_schedules(kw):
         u0, v0 = stress_fields(shape, seed)
         for steps in (9, 70):
             ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True, boundary=boundary)
-            a = dict(kernel=capi.GS_KERNEL_TB, cols_per_lane=2, share_taps=1, rows_per_block=9)
+            a = dict(rows_per_block=9, **shared(mode))
             a.update(kw)
             got_u, got_v, info = gpu_run(u0, v0, steps, args=args(**a))
-            assert ".op.ds" in info[0], info
+            assert mode[1] in info[0], info
             assert_bits_equal(got_u, ref_u, f"U {info[0]} {shape} steps {steps} {kw}")
             assert_bits_equal(got_v, ref_v, f"V {info[0]} {shape} steps {steps} {kw}")

@@ -9,7 +9,8 @@ launches with rocm-smi sampled beside it (clock, power, the accumulated-energy c
         -- python3 tools/energy_table.py --profile --data new        (short: a few launches per flavour)
 
 Flavours (all on the same pinned schedule: 4 steps per pass, 2 columns per lane, `--rows-per-unit` rows):
-  strict.op.ds  the kernel for the default parameters with full difference sharing (gs_options.share_taps = 1)
+  strict.op.dx  the kernel for the default parameters with full difference sharing, across lanes too (share_taps = 3)
+  strict.op.ds  ... with full difference sharing within a lane (share_taps = 1)
   strict.op   the kernel for the default parameters (side taps `v_sub_f32 ... div:2`, no `* dt`), share_taps = 2
   strict      the same build without the parameter specialisations (general_kernels = 1): sub, mul, add taps
   fused       GS_MATH_FUSED: sub + fma taps, denormals kept (not bit-exact below 1e-37)
@@ -27,7 +28,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from grayscott_amd import HipArgs, Parameters, Simulation, capi  # noqa: E402
 
-FLAVOURS = (("strict.op.ds", {"share_taps": 1}), ("strict.op", {"share_taps": 2}), ("strict", {"general_kernels": 1}),
+FLAVOURS = (("strict.op.dx", {"share_taps": 3}), ("strict.op.ds", {"share_taps": 1}), ("strict.op", {"share_taps": 2}), ("strict", {"general_kernels": 1}),
             ("fused", {"math": capi.GS_MATH_FUSED}))
 
 
@@ -39,7 +40,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--rows-per-unit", type=int, default=122)
     ap.add_argument("--data", default="new,developed")
-    ap.add_argument("--flavours", default="strict.op.ds,strict.op,strict,fused")
+    ap.add_argument("--flavours", default="strict.op.dx,strict.op.ds,strict.op,strict,fused", help="comma- or plus-separated")
     ap.add_argument("--profile", action="store_true", help="under rocprofv3: 40 steps per flavour, no sampling")
     a = ap.parse_args()
     rows, cols = a.rows, a.cols
@@ -47,7 +48,7 @@ def main():
     datas = a.data.split(",")
     sims = {}
     for name, kw in FLAVOURS:
-        if name not in a.flavours.split(","):
+        if name not in a.flavours.replace("+", ",").split(","):
             continue
         sim = Simulation.new(Parameters(), HipArgs(devices=[0], rows_per_block=a.rows_per_unit, fuse_steps=4,
                                                    cols_per_lane=2, **kw))

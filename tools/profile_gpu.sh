@@ -30,7 +30,7 @@ json.dump(b["config"]["tuned"], open(out + "/layout.json", "w"))
 t = b["config"]["tuned"]
 open(out + "/layout.env", "w").write(
     f"export GS_HIP_ROWS_PER_BLOCK={t['rows_per_unit']} GS_HIP_FUSE_STEPS={t['steps_per_pass']} GS_HIP_COLS_PER_LANE={t['cols_per_lane']}"
-    f" GS_HIP_SHARE_TAPS={2 if t.get('share_taps') is False else 1}\n"
+    f" GS_HIP_SHARE_TAPS={ {'off': 2, 'across lanes': 3}.get(t.get('share_taps'), 1) }\n"
     if t["rows_per_unit"] > 0 else "")
 PY
 source "$OUT/layout.env"

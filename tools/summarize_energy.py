@@ -14,9 +14,9 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"strict.op.ds": "gs_step_tb_ds_k_strict<4, 4>", "strict.op": "gs_step_tb_k_strict<4, 3, 2, 4>",
+KERNELS = {"strict.op.dx": "gs_step_tb_dx_k_strict<4, 4>", "strict.op.ds": "gs_step_tb_ds_k_strict<4, 4>", "strict.op": "gs_step_tb_k_strict<4, 3, 2, 4>",
            "strict": "gs_step_tb_k_strict<4, 0, 2, 4>", "fused": "gs_step_tb_k_fused<4, 0, 2, 4>"}
-USEFUL = {"strict.op.ds": 46, "strict.op": 53, "strict": 63, "fused": 47}   # the update's arithmetic as this flavour issues it
+USEFUL = {"strict.op.dx": 41, "strict.op.ds": 46, "strict.op": 53, "strict": 63, "fused": 47}   # the update's arithmetic as this flavour issues it
 
 
 def pmc(run_dir, data):

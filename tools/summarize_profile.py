@@ -42,7 +42,7 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     bench0 = json.loads(open(os.path.join(src, "bench_stats.json")).read().strip().splitlines()[-1])
     label = bench0["config"]["kernel"]
-    auto = ("gs_step_tb_ds_k" if ".ds" in label else "gs_step_tb_k") if label.startswith("tb-") else "gs_step_stream_k"
+    auto = ("gs_step_tb_dx_k" if ".dx" in label else "gs_step_tb_ds_k" if ".ds" in label else "gs_step_tb_k") if label.startswith("tb-") else "gs_step_stream_k"
     needle = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "auto" else auto
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -110,7 +110,7 @@ def main():
                 f"| SQ_WAVES | {med.get('SQ_WAVES', 0):.0f} | waves per launch |",
                 f"| SQ_INSTS_VALU | {med['SQ_INSTS_VALU']/1e6:.1f} M wave-instructions | "
                 f"{med['SQ_INSTS_VALU']*64/cell_steps:.1f} instruction-lanes per cell-step "
-                f"({46 if '.ds' in bench['config']['kernel'] else 53} are the arithmetic of the update in this kernel's form) |",
+                f"({41 if '.dx' in bench['config']['kernel'] else 46 if '.ds' in bench['config']['kernel'] else 53} are the arithmetic of the update in this kernel's form) |",
             ]
             if "GRBM_GUI_ACTIVE" in med:
                 cyc = med["GRBM_GUI_ACTIVE"] / 8.0
