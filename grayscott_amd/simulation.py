@@ -157,7 +157,7 @@ class HipContext:
         return float(ms.value)
 
     def get_tuned(self, slab_rows: int, cols: int) -> Tuple[int, int, int, int]:
-        """(rows per unit, steps fused per pass, columns per lane, share_taps: 1 = on, 2 = off) chosen for slabs of
+        """(rows per unit, steps fused per pass, columns per lane, share_taps: 1 = on, 2 = off, 3 = across lanes too) chosen for slabs of
         this shape; zeros when nothing was chosen yet (``gs_ctx_get_tuned``)."""
         a, b, c, d = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
         capi.check(self._lib.gs_ctx_get_tuned(self.handle, slab_rows, cols, ctypes.byref(a), ctypes.byref(b),
