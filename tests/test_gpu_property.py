@@ -31,7 +31,7 @@ def cases(draw):
     rpb = draw(st.sampled_from([0, 1, 2, 3, 5, 8, 16, 33]))
     if kernel == capi.GS_KERNEL_WINDOW:           # steps per exchange (even) and full window rows
         fuse = draw(st.sampled_from([0, 2, 4, 6, 8]))
-        rpb = draw(st.sampled_from([0, 80, 96]))
+        rpb = draw(st.sampled_from([0, 80]))
     split = draw(st.integers(0, 4))
     slabs = draw(st.integers(1, 4))
     cpl = draw(st.sampled_from([0, 1, 2, 4]))
@@ -109,7 +109,7 @@ def larger_cases(draw):
     rpb = draw(st.sampled_from([0, 0, 3, 8, 10, 16, 21, 39, 64])) if pinned else 0
     if kernel == capi.GS_KERNEL_WINDOW:           # (grids that are not one round of windows: the test falls back to auto)
         fuse = draw(st.sampled_from([0, 4, 8]))
-        rpb = draw(st.sampled_from([0, 80, 96]))
+        rpb = draw(st.sampled_from([0, 80]))
     cpl = draw(st.sampled_from([0, 1, 2, 4])) if pinned else 0
     slabs = draw(st.sampled_from([1, 1, 2, 3])) if pinned else 1
     tile_shape = draw(st.integers(0, 3))
