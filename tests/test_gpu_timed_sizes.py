@@ -74,8 +74,9 @@ def _seeded(rows, cols):
 
 
 def _assert_production(label):
-    # the default schedule, tuned: "tb-k<K>[c<cpl>]/strict.op[.ds]@<rows>x<bands>" (.ds: full difference sharing)
-    assert label.startswith("tb-k") and ("/strict.op@" in label or "/strict.op.ds@" in label), label
+    # the default schedule, tuned: "tb-k<K>[c<cpl>]/strict.op[.ds|.dx]@<rows>x<bands>" (.ds / .dx: full difference sharing
+    # within a lane / across lanes too)
+    assert label.startswith("tb-k") and any(f"/strict.op{x}@" in label for x in ("", ".ds", ".dx")), label
 
 
 def test_default_schedule_16384_403_steps_vs_stream_kernel():
