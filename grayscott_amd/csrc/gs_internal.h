@@ -101,6 +101,11 @@ struct SlabRt {
     int timed = 0; // passes recorded since the timing was switched on
 };
 
+// The form of difference sharing (share_mode, gs_tuner.cpp) of runs that have not been tuned: across lanes too -- never
+// slower than sharing within a lane by more than 1 % in any measurement, 3-5 % faster on developed patterns
+// (profiles/r05_cross_lane.md).
+constexpr int kShareDefault = 2;
+
 struct gs_ctx {
     gs_params p;
     gs_options o;
@@ -122,7 +127,7 @@ struct gs_ctx {
     uint64_t tuned_rows = 0, tuned_cols = 0;
     int tuned_fuse = 0, tuned_rpu = 0, tuned_split = 0, tuned_k = 0; // tuned_k: fused steps per pass chosen
     int tuned_cpl = 0;                                               // columns per lane chosen
-    int tuned_share = 1;                                             // difference sharing chosen (share_mode: 0 / 1 / 2)
+    int tuned_share = kShareDefault;                                 // difference sharing chosen (share_mode: 0 / 1 / 2)
     // every finished choice (a context that alternates between grids does not re-tune)
     struct Tuned { uint64_t rows, cols; int fuse, rpu, split, k, cpl, share; };
     std::vector<Tuned> tuned_cache;
@@ -131,7 +136,7 @@ struct gs_ctx {
     struct Trial { int rpu, V, k, cpl, reps, share; };
     struct Tuning {
         uint64_t rows = 0, cols = 0;
-        int fuse = 0, next = 0, best_rpu = 0, best_split = 0, best_k = 0, best_cpl = 0, best_share = 1;
+        int fuse = 0, next = 0, best_rpu = 0, best_split = 0, best_k = 0, best_cpl = 0, best_share = kShareDefault;
         float best_ms = 0.f;
         Trial batch[16];
         int nb = 0;
@@ -174,7 +179,7 @@ struct gs_ctx {
         int32_t seq = 0;
         uint64_t fallbacks = 0;
     } win;
-    int share_now = 1; // form of difference sharing in force when gs_options.share_taps leaves the choice open (share_mode)
+    int share_now = kShareDefault; // form of difference sharing in force when gs_options.share_taps leaves the choice open (share_mode)
     int cu_count = 0; // compute units of the first slab's device
     int total_slabs() const { return world * (int)slabs.size(); }
     int global_index(int i) const { return rank * (int)slabs.size() + i; }

@@ -14,7 +14,7 @@ long tb_strips(int32_t cols, int fuse, int cpl)
 
 // The form of difference sharing in force (when the parameters allow it): 0 = none, 1 = within a lane (the halo-board
 // march), 2 = also across lanes.  Pinned by gs_options.share_taps (1 / 2 / 3 = within / none / across), else what the
-// on-line tuner last chose or is trying (gs_ctx::share_now), else 1.
+// on-line tuner last chose or is trying (gs_ctx::share_now), else 2 (kShareDefault).
 int share_mode(const gs_ctx *ctx)
 {
     switch (ctx->o.share_taps) {
@@ -244,7 +244,7 @@ void remember_tuned(gs_ctx *ctx, const gs_ctx::Tuned &t)
 //   pinned): 1 and 4 columns per lane -- more, narrower waves for small grids; fewer, wider ones
 //   with 16-byte accesses -- with a few unit heights each (large grids skip the candidates that
 //   would only multiply tiny units); phase E (gs_options.share_taps = 0 and the parameters allow it): the
-//   chosen configuration without full difference sharing -- A-D run with it.  A-C run with the untuned layout
+//   chosen configuration with difference sharing within a lane only and without any -- A-D run with sharing across lanes too.  A-C run with the untuned layout
 //   (pick_cols_per_lane).  Every list of heights is a fixed ladder plus the heights that make a launch a whole
 //   number of rounds of the chip's wave slots (fit_heights).
 int32_t tune_online(Run &r, int fuse)
@@ -305,7 +305,7 @@ int32_t tune_online(Run &r, int fuse)
         for (int c : cpls)
             for (int h : heights(candn0, (int)(sizeof candn0 / sizeof candn0[0]), fuse, c)) { d_cpl.push_back(c); d_rpu.push_back(h); }
     const int nn = (int)d_cpl.size();
-    // phase E: two candidates (sharing across lanes too, no sharing), where the choice is open and a variant with full
+    // phase E: two candidates (sharing within a lane only, no sharing), where the choice is open and a variant with full
     // difference sharing exists at all
     const bool share_open = ctx->o.share_taps == 0 && (fast_possible(ctx) & 4) != 0;
     const int ne = share_open ? 2 : 0;
@@ -370,7 +370,7 @@ int32_t tune_online(Run &r, int fuse)
                 std::fprintf(stderr, "gs_hip tuner %llux%llu: unit %3d rows, %d band(s), %d steps/pass, %d col/lane%s: "
                                      "%.4f ms/step (windows %.3f %.3f ms)\n",
                              (unsigned long long)f->rows, (unsigned long long)f->cols, t.rpu, t.V, t.k, t.cpl,
-                             t.share == 1 ? "" : (t.share ? ", taps shared across lanes" : ", taps not shared"), ms, w0, w1);
+                             t.share == 2 ? "" : (t.share ? ", taps shared within lanes only" : ", taps not shared"), ms, w0, w1);
             // prefer the incumbent unless the newcomer is clearly faster: by 1 %, or by 3 % when it
             // fuses fewer steps (more HBM traffic, slower remainder passes: a tie is not worth it)
             // ... and a taller unit of the same layout wins a near-tie: it recomputes fewer rows, and on large
@@ -403,7 +403,7 @@ int32_t tune_online(Run &r, int fuse)
     }
     const int phase_end[5] = {ncand, ncand + nalt, ncand + nalt + nk, ncand + nalt + nk + nn, ncand + nalt + nk + nn + ne};
     constexpr int kLast = 4;
-    int warm_cpl = 0, warm_k = 0, warm_share = 1; // kernel of the newest pass enqueued by this call
+    int warm_cpl = 0, warm_k = 0, warm_share = kShareDefault; // kernel of the newest pass enqueued by this call
     bool out_of_steps = false;
     // The first milliseconds of work on an idle chip run slow (the first windows of a 16384^2 context measured
     // 0.32 ms per step against 0.255 a few passes later: clocks, first touches), which used to cost whichever
@@ -429,7 +429,7 @@ int32_t tune_online(Run &r, int fuse)
         int nb = 0;
         int32_t st = GS_OK;
         for (; tu->next < phase_end[phase] && nb < kMaxBatch && st == GS_OK; ++tu->next) {
-            gs_ctx::Trial t{0, V0, fuse, base_cpl, reps, 1};
+            gs_ctx::Trial t{0, V0, fuse, base_cpl, reps, kShareDefault};
             const int i = tu->next - (phase ? phase_end[phase - 1] : 0);
             if (phase == 0) {
                 t.rpu = cand[i];
@@ -441,12 +441,12 @@ int32_t tune_online(Run &r, int fuse)
                 t.V = tu->best_split;
                 t.k = altk[i];
                 if (t.rpu == 0 || t.k >= fuse) continue;
-            } else if (phase == 4) { // what phases A-D chose, sharing across lanes too (the first) / without sharing
+            } else if (phase == 4) { // what phases A-D chose, sharing within a lane only (the first) / without sharing
                 t.rpu = tu->best_rpu;
                 t.V = tu->best_split;
                 t.k = tu->best_k;
                 t.cpl = tu->best_cpl;
-                t.share = i == 0 ? 2 : 0;
+                t.share = i == 0 ? 1 : 0;
                 // (only 2 columns per lane and 2 to 4 fused steps have a sharing variant: elsewhere nothing to compare)
                 if (t.rpu == 0 || t.cpl != 2 || t.k < 2) continue;
             } else { // phase 3 (phase 1 has no candidates)
@@ -483,7 +483,7 @@ int32_t tune_online(Run &r, int fuse)
             }
             ctx->o.rows_per_block = 0;
             ctx->o.cols_per_lane = user_cpl;
-            ctx->share_now = 1;
+            ctx->share_now = kShareDefault;
             tu->batch[nb++] = t;
         }
         if (st != GS_OK) return st;
@@ -501,7 +501,7 @@ int32_t tune_online(Run &r, int fuse)
         if (gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1))
             std::fprintf(stderr, "gs_hip tuner %llux%llu: chose unit %d rows, %d steps/pass, %d col/lane, taps %s\n",
                          (unsigned long long)f->rows, (unsigned long long)f->cols, done.rpu, done.k, done.cpl,
-                         done.share == 1 ? "shared" : (done.share ? "shared across lanes" : "not shared"));
+                         done.share == 2 ? "shared, across lanes too" : (done.share ? "shared within lanes" : "not shared"));
         for (auto e : tu->events)
             if (e) (void)hipEventDestroy(e);
         ctx->tunings.erase(ctx->tunings.begin() + (tu - ctx->tunings.data()));
@@ -540,7 +540,7 @@ int32_t gs_ctx_set_tuned(gs_ctx *ctx, uint64_t slab_rows, uint64_t cols, int32_t
     // keyed like gs_run's own choices: by the steps per pass it was asked to fuse
     const int fuse = ctx->o.fuse_steps > 0 ? (ctx->o.fuse_steps > kGhostRows ? kGhostRows : ctx->o.fuse_steps) : kGhostRows;
     if (fuse_steps > fuse) return fail(GS_ERR_INVALID, "%d steps per pass exceed fuse_steps = %d", fuse_steps, fuse);
-    remember_tuned(ctx, gs_ctx::Tuned{slab_rows, cols, fuse, rows_per_block, 1, fuse_steps, cols_per_lane, share_taps == 2 ? 0 : (share_taps == 3 ? 2 : 1)});
+    remember_tuned(ctx, gs_ctx::Tuned{slab_rows, cols, fuse, rows_per_block, 1, fuse_steps, cols_per_lane, share_taps == 2 ? 0 : (share_taps == 1 ? 1 : (share_taps == 3 ? 2 : kShareDefault))});
     return GS_OK;
 }
 

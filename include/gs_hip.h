@@ -175,7 +175,7 @@ typedef struct gs_options {
                               * row are, negated, the N / NW / NE taps of the next: 46 instead of 52 arithmetic    *
                               * instructions per cell-step, bit-identical; needs side weights 0.5, dt == 1 and      *
                               * w[0][0] == w[2][2], w[0][2] == w[2][0] -- true of every stencil of the reference):  *
-                              * 0 = chosen on line by gs_run like the unit height (slab chains and untuned runs: 1), *
+                              * 0 = chosen on line by gs_run like the unit height (slab chains and untuned runs: 3), *
                               * 1 = on, 2 = off, 3 = on and ACROSS lanes too (the three differences that cross a    *
                               * lane boundary are computed by one of the two lanes and read by the other as DPP      *
                               * operands: 41 instructions per cell-step, half the LDS traffic; faster where the      *
@@ -324,7 +324,7 @@ int32_t gs_timer_start(gs_ctx *ctx);
 int32_t gs_timer_stop(gs_ctx *ctx, float *elapsed_ms);
 
 /* The configuration gs_run uses for slabs of `slab_rows` x `cols` cells: unit height, steps fused per
- * pass, columns per lane, full difference sharing (1 = on, 2 = off, 3 = across lanes too, as gs_options.share_taps; _set_ takes 0 as 1)
+ * pass, columns per lane, full difference sharing (1 = on, 2 = off, 3 = across lanes too, as gs_options.share_taps; _set_ takes 0 as 3)
  * (zeros from _get_ when nothing was chosen yet).  Single-slab contexts find it
  * themselves (on-line tuning inside gs_run); a slab chain takes what it is given: one process tunes on a
  * single slab of the slab's shape, reads the result with _get_ and every process of the chain sets it

@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--rows-per-unit", type=int, default=122, help="0 = the on-line tuner's schedule")
     ap.add_argument("--data", default="new,developed")
     ap.add_argument("--forms", default="ds,dx")
+    ap.add_argument("--fresh-steps", type=int, default=0,
+                    help="Species::new only: every window is this many steps of a FRESH Species after 100 warm-up steps (small grids "
+                         "develop their pattern within one long window); median of --rounds windows per form")
     a = ap.parse_args()
     rows, cols = a.rows, a.cols
     cells = rows * cols
@@ -51,6 +54,33 @@ def main():
             species["developed"] = bench.upload_species(sim, *start)
             sim.perform_steps(species["developed"], 2000)
         rpu, k, cpl = a.rows_per_unit, 4, 2
+        if a.fresh_steps > 0:
+            import statistics
+            if rpu == 0:
+                scratch = sim.make_species([rows, cols])
+                for _ in range(12):
+                    sim.perform_steps(scratch, 400)
+                    rpu, k, cpl, _ = ctx.get_tuned(rows, cols)
+                    if rpu > 0:
+                        break
+                del scratch
+            rates = {f: [] for f in a.forms.split(",")}
+            for rnd in range(a.rounds):
+                for form in rates:
+                    ctx.set_tuned(rows, cols, rpu, k, cpl, FORMS[form])
+                    sp = sim.make_species([rows, cols], place_candidates=a.place)
+                    sim.perform_steps(sp, 100)
+                    ctx.timer_start()
+                    sim.prepare_steps(sp, a.fresh_steps)
+                    ms = ctx.timer_stop()
+                    rates[form].append(cells * a.fresh_steps / (ms * 1e-3) / 1e6)
+                    label = ctx.info()[0]
+                    del sp
+            for form, r in rates.items():
+                print(json.dumps({"data": "new, fresh Species per window", "context": c, "form": form, "steps": a.fresh_steps, "windows": len(r),
+                                  "schedule": [rpu, k, cpl], "Mcells_steps_per_s_median": statistics.median(r), "min": min(r), "max": max(r)}), flush=True)
+            ctx.close()
+            continue
         if a.rows_per_unit == 0:                                    # ... or what the tuner chooses on the first input
             first = next(iter(species.values()))
             for _ in range(12):
