@@ -244,7 +244,7 @@ void remember_tuned(gs_ctx *ctx, const gs_ctx::Tuned &t)
 //   pinned): 1 and 4 columns per lane -- more, narrower waves for small grids; fewer, wider ones
 //   with 16-byte accesses -- with a few unit heights each (large grids skip the candidates that
 //   would only multiply tiny units); phase E (gs_options.share_taps = 0 and the parameters allow it): the
-//   chosen configuration with difference sharing within a lane only and without any -- A-D run with sharing across lanes too.  A-C run with the untuned layout
+//   chosen configuration without difference sharing -- A-D run with it (the default form: across lanes too).  A-C run with the untuned layout
 //   (pick_cols_per_lane).  Every list of heights is a fixed ladder plus the heights that make a launch a whole
 //   number of rounds of the chip's wave slots (fit_heights).
 int32_t tune_online(Run &r, int fuse)
@@ -305,10 +305,13 @@ int32_t tune_online(Run &r, int fuse)
         for (int c : cpls)
             for (int h : heights(candn0, (int)(sizeof candn0 / sizeof candn0[0]), fuse, c)) { d_cpl.push_back(c); d_rpu.push_back(h); }
     const int nn = (int)d_cpl.size();
-    // phase E: two candidates (sharing within a lane only, no sharing), where the choice is open and a variant with full
-    // difference sharing exists at all
+    // phase E: one candidate (no sharing), where the choice is open and a variant with full difference sharing exists at
+    // all.  Sharing within a lane only (share_taps = 1) is not a candidate: against the default form it is within 1 % where
+    // it wins and 3-5 % behind on every developed pattern once the power cap has set the clock -- which a timing window of
+    // a few passes on a chip that was idle a moment ago does not show (at 4096^2 the windows preferred it on every input
+    // and the run then lost 5 %, profiles/r05_cross_lane.md, section 3).
     const bool share_open = ctx->o.share_taps == 0 && (fast_possible(ctx) & 4) != 0;
-    const int ne = share_open ? 2 : 0;
+    const int ne = share_open ? 1 : 0;
     // timed passes per candidate: short passes need more of them for a stable comparison
     const int reps = cells >= (1ull << 27) ? 2 : (cells >= (1ull << 24) ? 6 : 8);
     constexpr int kMaxBatch = (int)(sizeof(gs_ctx::Tuning::batch) / sizeof(gs_ctx::Trial));
@@ -441,12 +444,12 @@ int32_t tune_online(Run &r, int fuse)
                 t.V = tu->best_split;
                 t.k = altk[i];
                 if (t.rpu == 0 || t.k >= fuse) continue;
-            } else if (phase == 4) { // what phases A-D chose, sharing within a lane only (the first) / without sharing
+            } else if (phase == 4) { // what phases A-D chose, without difference sharing
                 t.rpu = tu->best_rpu;
                 t.V = tu->best_split;
                 t.k = tu->best_k;
                 t.cpl = tu->best_cpl;
-                t.share = i == 0 ? 1 : 0;
+                t.share = 0;
                 // (only 2 columns per lane and 2 to 4 fused steps have a sharing variant: elsewhere nothing to compare)
                 if (t.rpu == 0 || t.cpl != 2 || t.k < 2) continue;
             } else { // phase 3 (phase 1 has no candidates)

@@ -175,11 +175,12 @@ typedef struct gs_options {
                               * row are, negated, the N / NW / NE taps of the next: 46 instead of 52 arithmetic    *
                               * instructions per cell-step, bit-identical; needs side weights 0.5, dt == 1 and      *
                               * w[0][0] == w[2][2], w[0][2] == w[2][0] -- true of every stencil of the reference):  *
-                              * 0 = chosen on line by gs_run like the unit height (slab chains and untuned runs: 3), *
-                              * 1 = on, 2 = off, 3 = on and ACROSS lanes too (the three differences that cross a    *
-                              * lane boundary are computed by one of the two lanes and read by the other as DPP      *
-                              * operands: 41 instructions per cell-step, half the LDS traffic; faster where the      *
-                              * power cap sets the clock, slower where issue slots do)                               */
+                              * 0 = on (form 3) unless gs_run's on-line tuner measures the chosen configuration   *
+                              * faster without, 1 = on, WITHIN a lane only (46 instructions per cell-step; the halo  *
+                              * columns of a lane's two go through an LDS board), 2 = off, 3 = on and ACROSS lanes   *
+                              * too (the three differences that cross a lane boundary are formed by one of the two  *
+                              * lanes and read by the other as DPP operands: 41 instructions per cell-step, half the *
+                              * LDS traffic; 3-5 % less energy per cell-step than form 1 on every input)             */
     int32_t reserved[3];
 } gs_options;
 

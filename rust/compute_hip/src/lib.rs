@@ -90,8 +90,8 @@ pub struct HipArgs {
     #[arg(long, env = "GS_HIP_GENERAL_KERNELS", default_value_t = 0)]
     pub hip_general_kernels: i32,
 
-    /// Full difference sharing in the temporally blocked kernel: 0 = chosen on line, 1 = on, 2 = off,
-    /// 3 = on and across lanes too (bit-identical every way)
+    /// Full difference sharing in the temporally blocked kernel: 0 = on (form 3) unless measured slower, 1 = within a lane only, 2 = off,
+    /// 3 = across lanes too (bit-identical every way)
     #[arg(long, env = "GS_HIP_SHARE_TAPS", default_value_t = 0)]
     pub hip_share_taps: i32,
 
