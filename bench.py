@@ -62,7 +62,7 @@ def parse_args():
                          "the single-step HBM leg that is part of it)")
     ap.add_argument("--no-place", action="store_true",
                     help="planes as hipMalloc hands them out (default: Species of >= 2^26 cells per GPU are placed by "
-                         "measurement, gs_fields_place with 28 candidate blocks)")
+                         "measurement, gs_fields_place with up to 124 candidate blocks)")
     ap.add_argument("--no-peer-chain", action="store_true",
                     help="N > 1: skip rank 0's in-process chain over all GPUs (hipMemcpyPeerAsync, no RCCL) after the timed job")
     ap.add_argument("--bootstrap", choices=("nccl", "gloo"), default="nccl",
@@ -171,10 +171,12 @@ def main() -> int:
     # Nothing is allocated, freed or filled between tuning and timing -- round 2's line read 8 % low because 4 GiB of
     # planes were created in that gap and the first launches after it ran on an idle chip's clocks.  The same holds for
     # the planes of the replay (single GPU: a second context pinned to the single-step stream kernel).
-    # Placement by measurement (gs_fields_place): about one 1 GiB block in six reads fast, and since round 5 the marching
-    # kernel is fast enough to feel it (1.09 M on four blocks as hipMalloc hands them out, 1.22 M on four fast ones,
-    # profiles/r05_cross_lane.md).  Every Species of the timed regions and of the replay takes the best four of 32 blocks.
-    place = 28 if cells_per_gpu >= (1 << 26) and not args.no_place else 0
+    # Placement by measurement (gs_fields_place): hipMalloc's blocks come from two pools, most from one, and four planes
+    # split 2 + 2 over them read 14 % faster than four of one pool; since round 5 the marching kernel is fast enough to feel
+    # it (1.09 M on four blocks as hipMalloc hands them out, 1.18-1.23 M on a 2 + 2 set, profiles/r05_cross_lane.md).  Every
+    # Species of the timed regions and of the replay draws blocks (12, then 16 at a time, at most 124) until it has two of
+    # the rarer kind.
+    place = 124 if cells_per_gpu >= (1 << 26) and not args.no_place else 0
     with stage("setup", 900):
         species = sim.make_species([rows, cols], place_candidates=place)
         species.steps_done = 0

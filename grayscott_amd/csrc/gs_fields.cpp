@@ -78,7 +78,7 @@ int32_t gs_field_create(gs_ctx *ctx, gs_field **out, uint64_t rows, uint64_t col
 int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidates, float *first_ms, float *best_ms)
 {
     if (!ctx || !planes) return fail(GS_ERR_INVALID, "null argument");
-    if (candidates < 1 || candidates > 28) return fail(GS_ERR_INVALID, "1 to 28 extra candidate blocks, not %d", candidates);
+    if (candidates < 1 || candidates > 124) return fail(GS_ERR_INVALID, "1 to 124 extra candidate blocks, not %d", candidates);
     if (ctx->slabs.size() != 1) return fail(GS_ERR_UNSUPPORTED, "placement by measurement is for contexts with one slab per process");
     for (int i = 0; i < 4; ++i) {
         if (!planes[i] || planes[i]->ctx != ctx) return fail(GS_ERR_INVALID, "bad plane %d", i);
@@ -95,7 +95,6 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
     GS_HIP(hipSetDevice(sl.device));
     const size_t pitch = (size_t)f0->pitch;
     const size_t n = (size_t)(f0->s[0].rows + 2 * kGhostRows) * pitch + 2 * kGuardFloats;
-    const int total = 4 + candidates;
     std::vector<float *> blocks;
     for (int i = 0; i < 4; ++i) blocks.push_back(planes[i]->s[0].alloc);
     auto release = [&](int keep_from) { // frees the blocks from index keep_from on
@@ -103,26 +102,13 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
             if (blocks[i]) (void)hipFree(blocks[i]);
         blocks.resize((size_t)keep_from);
     };
-    for (int i = 4; i < total; ++i) {
-        float *b = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&b), n * sizeof(float)) != hipSuccess) { // fewer candidates: fine
-            (void)hipGetLastError();
-            break;
-        }
-        blocks.push_back(b);
-    }
-    const int have = (int)blocks.size();
-    // zeros everywhere (what gs_field_create leaves; the four planes come out zero-filled whichever blocks they get)
-    for (float *b : blocks) {
-        const hipError_t e = hipMemsetAsync(b, 0, n * sizeof(float), sl.compute);
-        if (e != hipSuccess) { release(4); return fail(GS_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e)); }
-    }
     auto row0_of = [&](float *b) { return b + kGuardFloats + (size_t)kGhostRows * pitch; };
     // a probe: four single steps ping-ponging between (a, b) and (c, d), timed with the context's events
     GsStepArgs base = make_args(ctx, planes[0], planes[1], planes[2], planes[3], 0, 1);
     base.ra0 = 0;
     base.ra1 = base.rows;
     const bool fused = ctx->o.math == GS_MATH_FUSED;
+    static const bool trace = gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1) != 0;
     auto probe = [&](const int (&pick)[4], float *ms) -> int32_t {
         float *p[4];
         for (int i = 0; i < 4; ++i) p[i] = row0_of(blocks[(size_t)pick[i]]);
@@ -138,63 +124,103 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
         GS_HIP(hipEventRecord(sl.t1, sl.compute));
         GS_HIP(hipEventSynchronize(sl.t1));
         GS_HIP(hipEventElapsedTime(ms, sl.t0, sl.t1));
-        return GS_OK;
-    };
-    int best[4] = {0, 1, 2, 3};
-    float best_t = 0.0f, first_t = 0.0f;
-    // Phase 1: the four that are there, then pseudo-random 4-subsets of the pool (a fixed sequence: the same candidates
-    // every time), 12 per block on average.  A probe's time is, to a good approximation, a sum over its four blocks
-    // (profiles/r05_cross_lane.md: about one block in six is "fast", a set reads at one of five levels by how many fast
-    // blocks it holds), so the mean over the probes a block took part in ranks the blocks.
-    uint32_t rng = 0x9e3779b9u;
-    const int trials = have > 4 ? 3 * have : 1;
-    std::vector<float> sum((size_t)have, 0.0f);
-    std::vector<int> cnt((size_t)have, 0);
-    static const bool trace = gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1) != 0;
-    auto timed = [&](const int (&pick)[4], float *ms) -> int32_t {
-        const int32_t st = probe(pick, ms);
-        if (st != GS_OK) return st;
         if (trace)
-            std::fprintf(stderr, "gs_hip placement: blocks %2d %2d %2d %2d (%p %p %p %p): %.4f ms per step\n", pick[0], pick[1], pick[2],
+            std::fprintf(stderr, "gs_hip placement: blocks %3d %3d %3d %3d (%p %p %p %p): %.4f ms per step\n", pick[0], pick[1], pick[2],
                          pick[3], (void *)blocks[(size_t)pick[0]], (void *)blocks[(size_t)pick[1]], (void *)blocks[(size_t)pick[2]],
                          (void *)blocks[(size_t)pick[3]], *ms / 4.0f);
         return GS_OK;
     };
-    for (int t = 0; t < trials; ++t) {
-        int pick[4] = {0, 1, 2, 3};
-        if (t > 0) {
-            int order[32];
-            for (int i = 0; i < have; ++i) order[i] = i;
-            for (int i = 0; i < 4; ++i) { // partial Fisher-Yates
-                rng = rng * 1664525u + 1013904223u;
-                const int j = i + (int)((rng >> 8) % (uint32_t)(have - i));
-                std::swap(order[i], order[j]);
-                pick[i] = order[i];
-            }
-        }
+    // What the probes of rounds 4 and 5 say about this memory (profiles/r05_cross_lane.md, section 4): the blocks hipMalloc
+    // hands out come from TWO pools, most of them from one; four planes read by how they are split over the two -- 4 + 0:
+    // 0.82 ms per single step at 16384^2, 3 + 1: 0.77, 2 + 2: 0.72 when the inputs (and so the outputs) are one of each,
+    // 0.76-0.80 when both inputs are of one pool.  So: draw blocks in batches, time random 4-subsets, class the blocks by
+    // the mean time of the subsets they were in (the rare kind pulls its subsets down), stop drawing once there are two of
+    // each class, and time the arrangements (common, rare, common, rare) of the clearest members.
+    int best[4] = {0, 1, 2, 3};
+    float best_t = 0.0f, first_t = 0.0f;
+    uint32_t rng = 0x9e3779b9u;
+    auto draw = [&](uint32_t n) { rng = rng * 1664525u + 1013904223u; return (int)((rng >> 8) % n); };
+    std::vector<float> sum;
+    std::vector<int> cnt;
+    std::vector<int> rare, common; // block indices by class, clearest first
+    auto timed = [&](const int (&pick)[4], bool count) -> int32_t {
         float ms = 0.0f;
-        const int32_t st = timed(pick, &ms);
-        if (st != GS_OK) { release(4); return st; }
-        if (t == 0) first_t = ms;
-        for (int i = 0; i < 4; ++i) { sum[(size_t)pick[i]] += ms; ++cnt[(size_t)pick[i]]; }
-        if (t == 0 || ms < 0.995f * best_t) { best_t = ms; std::memcpy(best, pick, sizeof best); }
-    }
-    // Phase 2: every 4-subset of the six best-ranked blocks (15 probes)
-    if (have > 4) {
-        std::vector<int> rank;
+        GS_TRY(probe(pick, &ms));
+        if (count)
+            for (int i = 0; i < 4; ++i) { sum[(size_t)pick[i]] += ms; ++cnt[(size_t)pick[i]]; }
+        if (best_t == 0.0f || ms < 0.995f * best_t) { best_t = ms; std::memcpy(best, pick, sizeof best); }
+        return GS_OK;
+    };
+    int drawn = 0;
+    while (true) {
+        const int old = (int)blocks.size();
+        const int batch = old == 4 ? (candidates < 12 ? candidates : 12) : (candidates - drawn < 16 ? candidates - drawn : 16);
+        for (int i = 0; i < batch; ++i) {
+            float *b = nullptr;
+            if (hipMalloc(reinterpret_cast<void **>(&b), n * sizeof(float)) != hipSuccess) { // fewer candidates: fine
+                (void)hipGetLastError();
+                drawn = candidates;
+                break;
+            }
+            const hipError_t e = hipMemsetAsync(b, 0, n * sizeof(float), sl.compute); // zeros, as gs_field_create leaves a plane
+            blocks.push_back(b);
+            if (e != hipSuccess) { release(4); return fail(GS_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e)); }
+            ++drawn;
+        }
+        const int have = (int)blocks.size();
+        sum.resize((size_t)have, 0.0f);
+        cnt.resize((size_t)have, 0);
+        if (old == 4) { // the four that are there
+            const int pick[4] = {0, 1, 2, 3};
+            const int32_t st = timed(pick, true);
+            if (st != GS_OK) { release(4); return st; }
+            first_t = best_t;
+        }
+        if (have == 4) break; // nothing could be drawn
+        // three random 4-subsets per new block, each holding it
+        for (int nb = old == 4 ? 0 : old; nb < have; ++nb)
+            for (int rep = 0; rep < 3; ++rep) {
+                int pick[4] = {nb, nb, nb, nb};
+                const int at = draw(4);
+                for (int i = 0; i < 4; ++i) {
+                    if (i == at) continue;
+                    bool fresh;
+                    do {
+                        pick[i] = draw((uint32_t)have);
+                        fresh = pick[i] != nb;
+                        for (int j = 0; j < i; ++j) fresh = fresh && (j == at || pick[j] != pick[i]);
+                    } while (!fresh);
+                }
+                const int32_t st = timed(pick, true);
+                if (st != GS_OK) { release(4); return st; }
+            }
+        // two classes?  by the means, split half way between the extremes when they are at least 3 % apart
+        std::vector<int> order;
         for (int b = 0; b < have; ++b)
-            if (cnt[(size_t)b] > 0) rank.push_back(b);
-        std::sort(rank.begin(), rank.end(), [&](int x, int y) { return sum[(size_t)x] / cnt[(size_t)x] < sum[(size_t)y] / cnt[(size_t)y]; });
-        const int top = (int)rank.size() < 6 ? (int)rank.size() : 6;
-        for (int i0 = 0; i0 < top; ++i0)
-            for (int i1 = i0 + 1; i1 < top; ++i1)
-                for (int i2 = i1 + 1; i2 < top; ++i2)
-                    for (int i3 = i2 + 1; i3 < top; ++i3) {
-                        const int pick[4] = {rank[(size_t)i0], rank[(size_t)i1], rank[(size_t)i2], rank[(size_t)i3]};
-                        float ms = 0.0f;
-                        const int32_t st = timed(pick, &ms);
+            if (cnt[(size_t)b] > 0) order.push_back(b);
+        auto mean = [&](int b) { return sum[(size_t)b] / (float)cnt[(size_t)b]; };
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return mean(x) < mean(y); });
+        rare.clear();
+        common.clear();
+        const float lo = mean(order.front()), hi = mean(order.back());
+        if (hi - lo > 0.03f * hi)
+            for (int b : order) (mean(b) < 0.5f * (lo + hi) ? rare : common).push_back(b);
+        std::reverse(common.begin(), common.end()); // clearest first
+        if (trace)
+            std::fprintf(stderr, "gs_hip placement: %d blocks, means %.4f ... %.4f ms per step, %zu of the rarer kind\n", have, lo / 4.0f,
+                         hi / 4.0f, rare.size());
+        if ((rare.size() >= 2 && common.size() >= 2) || drawn >= candidates) break;
+    }
+    // (common, rare, common, rare) over the three clearest of each class: U's planes of one pool, V's of the other
+    if (rare.size() >= 2 && common.size() >= 2) {
+        const int nr = (int)rare.size() < 3 ? (int)rare.size() : 3, nc = (int)common.size() < 3 ? (int)common.size() : 3;
+        for (int r0 = 0; r0 < nr; ++r0)
+            for (int r1 = r0 + 1; r1 < nr; ++r1)
+                for (int c0 = 0; c0 < nc; ++c0)
+                    for (int c1 = c0 + 1; c1 < nc; ++c1) {
+                        const int pick[4] = {common[(size_t)c0], rare[(size_t)r0], common[(size_t)c1], rare[(size_t)r1]};
+                        const int32_t st = timed(pick, false);
                         if (st != GS_OK) { release(4); return st; }
-                        if (ms < 0.995f * best_t) { best_t = ms; std::memcpy(best, pick, sizeof best); }
                     }
     }
     // hand the chosen blocks to the planes; the probes have written into every block: zeros again

@@ -278,17 +278,19 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
 
 /* Placement by measurement, for the planes of a large Species on a context with one slab per process (optional; the
  * HBM-bound single-step kernel gains up to 19 %, the temporally blocked kernel of gs_run up to 12 % at 16384^2: since
- * round 5 it is fast enough to be held back by badly placed planes, 1.09 M instead of 1.22 M Mcells x steps/s).  Where a
- * hipMalloc lands in HBM is below what a process controls: about one 1 GiB block in six reads fast, and four planes
- * read at one of several levels (0.65 ... 0.75 of 8 TB/s at 16384^2) by how many fast blocks they hold.  This call draws
- * `candidates` (1..28) more blocks of the planes' size, times the single-step kernel over 3 x pool-size random 4-subsets
- * of the pool, ranks the blocks by the mean time of the subsets they were in, times every 4-subset of the six best-ranked
- * (~110 probes of four steps each, 0.5 s at 16384^2 with 28 candidates, 32 GiB held meanwhile), gives the four planes the
- * blocks that read best together and frees the rest.  Measured (profiles/r05_placement.md, r05_cross_lane.md): first
- * four blocks 0.63-0.66 of 8 TB/s, best of 4 + 12 blocks 0.70-0.75 (0.68 when the pool holds fewer than four fast
- * blocks), best of 4 + 28 blocks 0.75.  Call it on FRESHLY CREATED planes, before they are filled: their contents are not
- * kept -- all four are zero-filled on return, as gs_field_create leaves them.  first_ms / best_ms (optional): time per
- * step of the planes' original blocks and of the chosen ones. */
+ * round 5 it is fast enough to be held back by badly placed planes, 1.09 M instead of 1.2 M Mcells x steps/s).  Where a
+ * hipMalloc lands in HBM is below what a process controls, but it can be measured: the 1 GiB blocks come in TWO kinds,
+ * most of one kind, and four planes read by how they are split over the two -- 4 + 0: 0.82 ms per single step at
+ * 16384^2 (0.65 of 8 TB/s), 3 + 1: 0.77, 2 + 2 with U's planes of one kind and V's of the other: 0.71 (0.75).  This call
+ * draws more blocks of the planes' size (12, then 16 at a time, at most `candidates`, 1..124), times the single-step
+ * kernel over random 4-subsets (three per new block), classes the blocks by the mean time of the subsets they were in,
+ * stops drawing once it has two of each kind, times the (common, rare, common, rare) arrangements of the clearest
+ * members, gives the four planes the best set seen and frees the rest: ~60 probes of four steps each and 16 GiB held for
+ * 0.3 s at 16384^2 when the first batch holds both kinds; 1.5 s and 128 GiB at the very most.  Measured
+ * (profiles/r05_placement.md, r05_cross_lane.md section 4): first four blocks 0.63-0.74 of 8 TB/s, chosen 0.75.  Call
+ * it on FRESHLY CREATED planes, before they are filled: their contents are not kept -- all four are zero-filled on
+ * return, as gs_field_create leaves them.  first_ms / best_ms (optional): time per step of the planes' original blocks
+ * and of the chosen ones. */
 int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidates, float *first_ms, float *best_ms);
 
 /* Wait for everything enqueued on this context (all local devices and streams). */
