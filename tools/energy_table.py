@@ -54,11 +54,13 @@ def main():
                                                    cols_per_lane=2, **kw))
         sims[name] = [sim, {}]
     start = bench.developed_start(rows, cols) if "developed" in datas else None
+    place = 124 if cells >= (1 << 26) else 0
     for name, (sim, species) in sims.items():
         if "new" in datas:
-            species["new"] = sim.make_species([rows, cols])
+            # (planes placed by measurement: unplaced, the flavours would be compared on different draws of blocks)
+            species["new"] = sim.make_species([rows, cols], place_candidates=place)
         if "developed" in datas:
-            species["developed"] = bench.upload_species(sim, *start)
+            species["developed"] = bench.upload_species(sim, *start, place)
             sim.perform_steps(species["developed"], 4000)
     del start
     if a.profile:
