@@ -398,6 +398,14 @@ def main() -> int:
         result["ranks"] = per_rank
     if clocks:
         add_clocks(roofline, result, clocks)
+    if single_step and roofline.get("hbm_physical") and single_step.get("frac_of_8TBps"):
+        # the marching kernel's physical HBM rate against what the HBM-bound single-step kernel reads on planes placed the
+        # same way: off the power cap and within a fifth of it, the launch is held back by where its planes lie
+        # (profiles/r05_cross_lane.md, section 4), whatever the VALU fraction says
+        ratio = roofline["hbm_physical"] / single_step["frac_of_8TBps"]
+        roofline["hbm_physical_over_single_step_leg"] = ratio
+        if roofline["bound"] == "valu-issue" and ratio >= 0.8:
+            roofline["bound"] = "hbm of these planes"
     if developed is not None:
         result["value_developed_pattern"] = developed["value"]
         result["developed_pattern"] = developed

@@ -24,12 +24,12 @@ def test_recorded_bench_line_has_the_contract_keys():
     if "algorithmic_GBps" in r:
         # round 2 on: the object names the roof that binds.  The 16 B per cell-step figure of SURVEY 8(d)
         # is kept as a throughput (`algorithmic_*`), never as the fraction of a roof.
-        assert r["bound"] in ("valu-issue", "power-capped valu", "hbm")
+        assert r["bound"] in ("valu-issue", "power-capped valu", "hbm of these planes", "hbm")
         assert abs(r["algorithmic_GBps"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) \
             < 1e-6 * r["algorithmic_GBps"]
         assert abs(r["algorithmic_frac"] - r["algorithmic_GBps"] / 8000.0) < 1e-9
         assert 0 < r["useful_valu"] < 1
-        if r["bound"] in ("valu-issue", "power-capped valu"):
+        if r["bound"] in ("valu-issue", "power-capped valu", "hbm of these planes"):
             assert r["steps_per_launch"] >= 3 and r["unit"] == "T lane-ops/s" and abs(r["peak"] - 78.6432) < 1e-3
             if r["valu_insts_per_launch"]:
                 assert abs(r["achieved"] - r["valu_insts_per_launch"] * 64 / (r["launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
@@ -44,7 +44,7 @@ def test_recorded_bench_line_has_the_contract_keys():
             assert b["repeats"] >= 5 and b["value_min"] <= b["value"] <= b["value_max"]
             d = b["developed_pattern"]
             assert d["value"] == b["value_developed_pattern"] and d["repeats"] >= 5 and d["value_min"] <= d["value"] <= d["value_max"]
-            assert d["roofline"]["bound"] in ("valu-issue", r["bound"]) and 0 < d["roofline"]["frac"] < r["frac"] + 0.05
+            assert d["roofline"]["bound"] in ("valu-issue", "power-capped valu", r["bound"]) and 0 < d["roofline"]["frac"] < r["frac"] + 0.05
             assert r["frac_source"] and (r["counters_layout"] is None or r["counters_layout"]["rows_per_unit"] > 0)
             assert r["profile_launch_ms"] is None or 0.8 < r["profile_launch_ms"] / r["launch_ms"] < 1.25
             assert b["config"]["grid"] == [16384, 16384] and b["config"]["tuned"]["rows_per_unit"] > 0
@@ -66,7 +66,11 @@ def test_recorded_bench_line_has_the_contract_keys():
                     assert abs(ss["hbm_GBps"] - 16 * 16384 * 16384 / (ss["launch_ms"] * 1e-3) / 1e9) < 1e-6 * ss["hbm_GBps"]
                     assert abs(ss["frac_of_8TBps"] - ss["hbm_GBps"] / 8000.0) < 1e-9 and 0.6 < ss["frac_of_8TBps"] < 1.0
                     assert 0.8 < ss["value"] * 1e6 * 16 / 1e9 / ss["hbm_GBps"] <= 1.0005      # wall rate <= event rate
-                    assert r["bound"] in ("valu-issue", "power-capped valu")
+                    assert r["bound"] in ("valu-issue", "power-capped valu", "hbm of these planes")
+                    if "hbm_physical_over_single_step_leg" in r:     # end of round 5: the marching kernel feels its planes
+                        assert abs(r["hbm_physical_over_single_step_leg"] - r["hbm_physical"] / ss["frac_of_8TBps"]) < 1e-9
+                        assert (r["bound"] == "hbm of these planes") == (
+                            r["hbm_physical_over_single_step_leg"] >= 0.8 and r["bound"] != "power-capped valu")
                     assert 800 < b["energy_pJ_per_cell_step"] < 3000
                     assert b["developed_pattern"]["energy_pJ_per_cell_step"] > b["energy_pJ_per_cell_step"]
                     assert "closing barrier outside" in b["timing"] and b["value_first_region"] > 0.9 * b["value"]
