@@ -177,6 +177,8 @@ def main() -> int:
     # Species of the timed regions and of the replay draws blocks (12, then 16 at a time, at most 124) until it has two of
     # the rarer kind.
     place = 124 if cells_per_gpu >= (1 << 26) and not args.no_place else 0
+    if args.rehearsal:
+        place = min(place, 12)          # the ranks of a rehearsal share one GPU's memory
     with stage("setup", 900):
         species = sim.make_species([rows, cols], place_candidates=place)
         species.steps_done = 0
