@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the replay that compares the timed planes with an independent run (and, on one GPU, "
                          "the single-step HBM leg that is part of it)")
+    ap.add_argument("--place-candidates", type=int, default=-1,
+                    help="candidate blocks of gs_fields_place for every Species (default -1: 124 from 2^26 cells per GPU on, else none)")
     ap.add_argument("--no-place", action="store_true",
                     help="planes as hipMalloc hands them out (default: Species of >= 2^26 cells per GPU are placed by "
                          "measurement, gs_fields_place with up to 124 candidate blocks)")
@@ -179,6 +181,8 @@ def main() -> int:
     place = 124 if cells_per_gpu >= (1 << 26) and not args.no_place else 0
     if args.rehearsal:
         place = min(place, 12)          # the ranks of a rehearsal share one GPU's memory
+    if args.place_candidates >= 0:
+        place = args.place_candidates
     with stage("setup", 900):
         species = sim.make_species([rows, cols], place_candidates=place)
         species.steps_done = 0

@@ -30,10 +30,14 @@ def _bench(args, env=None, timeout=900):
 
 
 def test_gpus_2_rehearsal_without_torchrun_prints_a_verified_line(built):
-    r = _bench(["--gpus", "2", "--rehearsal", "--steps", "24", "--warmup", "5", "--repeats", "3", "--grid", "4096x2048"])
+    # (--place-candidates 3: every rank places its slab's planes by measurement, as the full-size run does)
+    r = _bench(["--gpus", "2", "--rehearsal", "--steps", "24", "--warmup", "5", "--repeats", "3", "--grid", "4096x2048",
+                "--place-candidates", "3"])
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and len(line["ranks"]) == 2
+    pl = line["config"]["placement"]
+    assert pl["candidates"] == 3 and 0 < pl["timed_species_ms"][1] <= pl["timed_species_ms"][0] * 1.0001, pl
     assert line["config"]["grid"] == [4096, 2048] and "REHEARSAL" in line["data"]
     v = line["verified"]
     assert v["equal"] is True and v["mismatching_ranks"] == [] and v["blocks"] >= 4 and v["steps"] > 24, v
