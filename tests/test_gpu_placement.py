@@ -18,7 +18,7 @@ def _built(built):
     assert capi.device_count() >= 1, "no MI355X visible"
 
 
-@pytest.mark.parametrize("shape,candidates", [((300, 700), 3), ((64, 128), 1), ((1, 1), 2), ((1500, 2100), 4)])
+@pytest.mark.parametrize("shape,candidates", [((300, 700), 3), ((64, 128), 1), ((1, 1), 2), ((1500, 2100), 4), ((200, 300), 40), ((96, 256), 124)])
 def test_species_new_on_placed_planes_matches_the_oracle(shape, candidates):
     sim = Simulation.new(Parameters(), HipArgs(devices=[0]))
     sp = sim.make_species(shape, place_candidates=candidates)
