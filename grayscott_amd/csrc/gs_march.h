@@ -177,6 +177,76 @@ __device__ __forceinline__ void cells_vshare(const GsStepArgs &a, const RowT<CPL
     c.sw_u[CPL - 1] = a.w[2][0] * (p.u[CPL] - z.u[CPL + 1]);  c.sw_v[CPL - 1] = a.w[2][0] * (p.v[CPL] - z.v[CPL + 1]); // SW tap of cell CPL + 1
 }
 
+// ... and sharing ACROSS lanes (FAST & 8).  Three differences cross the boundary between two lanes in every row -- the side
+// tap between the columns left and right of it and the two diagonals -- and in cells_vshare both lanes compute all three
+// from each other's halo columns: 10 of its 92 arithmetic instructions per lane-row.  Here the lane on the RIGHT of a
+// boundary computes them, from its left neighbour's second column (zl, pl: the only halo column left, half the board and
+// half its traffic), and the lane on the left takes them as DPP operands (wave_shl:1) of the three accumulations they
+// belong to: -W of the neighbour's cell 1 is the E tap of its own cell 2, the neighbour's SE tap of its left column the
+// SE tap, and the neighbour's SW tap of the tick before, negated, the NE tap.  82 arithmetic instructions per lane-row,
+// 41 per cell-step, 6 of them with a DPP operand -- which stalls the SIMD for about three issue slots and costs no joules:
+// 3-5 % faster wherever the power cap sets the clock, within 1 % elsewhere (profiles/r05_cross_lane.md).
+//
+// acc -/+ the RIGHT neighbour's x in one instruction (lane 63, sacrificial, takes 0).  Volatile: never moved into the
+// branch around the stores, where the sacrificial lanes -- whose taps their neighbours need -- are off.  s_nop 1: the two
+// wait states a DPP read needs behind the VALU write of its register, whichever instruction wrote it (the compiler does
+// not look into half_diff's asm; without the s_nop the same build runs 4-6 % SLOWER).
+__device__ __forceinline__ float minus_next(float acc, float x)
+{
+    float r;
+    asm volatile("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ float plus_next(float acc, float x)
+{
+    float r;
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+// One row of a level, 2 columns per lane: z = the row (own columns), p = the row below it, zl / pl = (U, V) of the left
+// neighbour's second column in those rows.  The carry's slots here: s = S of cells 1, 2; se = SE of the column left of the
+// lane's and of cell 1; sw[0] = SW of cell 1 (the LEFT NEIGHBOUR reads it, a tick later), sw[1] = SW of cell 2 (own use).
+template <int FAST>
+__device__ __forceinline__ void cells_xshare(const GsStepArgs &a, const RowQ<2> &z, const RowQ<2> &p, float zl_u, float zl_v,
+                                             float pl_u, float pl_v, TapCarry<2> &c, float (&nu)[2], float (&nv)[2])
+{
+    static_assert((FAST & 13) == 13 && !GS_MATH_FUSED, "a specialisation of the strict build");
+    // the three differences across the left boundary
+    const float w1u = half_diff(zl_u, z.u[0]), w1v = half_diff(zl_v, z.v[0]);                     // W of cell 1
+    const float se0u = a.w[2][2] * (p.u[0] - zl_u), se0v = a.w[2][2] * (p.v[0] - zl_v);           // SE of the column left of it
+    const float sw1u = a.w[2][0] * (pl_u - z.u[0]), sw1v = a.w[2][0] * (pl_v - z.v[0]);           // SW of cell 1
+    // cell 1
+    const float u = z.u[0], v = z.v[0];
+    float acc_u = zero_minus(c.se_u[0]), acc_v = zero_minus(c.se_v[0]);                           // NW
+    c.se_u[0] = se0u;                                 c.se_v[0] = se0v;
+    acc_u = acc_u - c.s_u[0];                         acc_v = acc_v - c.s_v[0];                   // N
+    acc_u = acc_u - c.sw_u[1];                        acc_v = acc_v - c.sw_v[1];                  // NE
+    acc_u = acc_u + w1u;                              acc_v = acc_v + w1v;                        // W
+    const float eu = half_diff(z.u[1], u), ev = half_diff(z.v[1], v);
+    acc_u = acc_u + eu;                               acc_v = acc_v + ev;                         // E
+    acc_u = acc_u + sw1u;                             acc_v = acc_v + sw1v;                       // SW
+    c.s_u[0] = half_diff(p.u[0], u);                  c.s_v[0] = half_diff(p.v[0], v);
+    acc_u = acc_u + c.s_u[0];                         acc_v = acc_v + c.s_v[0];                   // S
+    const float seu = a.w[2][2] * (p.u[1] - u), sev = a.w[2][2] * (p.v[1] - v);
+    acc_u = acc_u + seu;                              acc_v = acc_v + sev;                        // SE
+    react<(FAST & 2) != 0>(a, u, v, acc_u, acc_v, nu[0], nv[0]);
+    // cell 2
+    const float u2 = z.u[1], v2 = z.v[1];
+    acc_u = zero_minus(c.se_u[1]);                    acc_v = zero_minus(c.se_v[1]);              // NW
+    c.se_u[1] = seu;                                  c.se_v[1] = sev;
+    acc_u = acc_u - c.s_u[1];                         acc_v = acc_v - c.s_v[1];                   // N
+    acc_u = minus_next(acc_u, c.sw_u[0]);             acc_v = minus_next(acc_v, c.sw_v[0]);       // NE
+    c.sw_u[0] = sw1u;                                 c.sw_v[0] = sw1v;
+    acc_u = acc_u - eu;                               acc_v = acc_v - ev;                         // W
+    acc_u = minus_next(acc_u, w1u);                   acc_v = minus_next(acc_v, w1v);             // E
+    c.sw_u[1] = a.w[2][0] * (p.u[0] - u2);            c.sw_v[1] = a.w[2][0] * (p.v[0] - v2);
+    acc_u = acc_u + c.sw_u[1];                        acc_v = acc_v + c.sw_v[1];                  // SW
+    c.s_u[1] = half_diff(p.u[1], u2);                 c.s_v[1] = half_diff(p.v[1], v2);
+    acc_u = acc_u + c.s_u[1];                         acc_v = acc_v + c.s_v[1];                   // S
+    acc_u = plus_next(acc_u, se0u);                   acc_v = plus_next(acc_v, se0v);             // SE
+    react<(FAST & 2) != 0>(a, u2, v2, acc_u, acc_v, nu[1], nv[1]);
+}
+
 // Buffer-instruction forms of the plane accesses: address = 128-bit resource in SGPRs (base pointer of
 // the unit's first row) + per-lane byte offset (one VGPR for the whole march) + scalar byte offset of
 // the row: no 64-bit per-lane addresses to keep or to recompute per row.  The resource is raw (stride 0)
@@ -331,130 +401,8 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
     // in use known at compile time, and the loop behind them (6 ticks per trip: the row slots' 2 x the queue's 3) has no
     // test but "ticks left": every slot index is static, nothing is copied from register to register.
     constexpr bool VS = EDGE == 0 && (FAST & 5) == 5 && !GS_MATH_FUSED && CPL == 2;
-    // ... and sharing ACROSS lanes (FAST & 8).  Three differences cross the boundary between two lanes in every row -- the
-    // side tap between the columns left and right of it and the two diagonals -- and in the form below both lanes compute
-    // all three from each other's halo columns: 10 of its 92 arithmetic instructions per lane-row.  Here the lane on the
-    // RIGHT of a boundary computes them, from its left neighbour's second column (the only halo column left: half the
-    // board, half its traffic), and the lane on the left takes them as DPP operands (wave_shl:1) of the three
-    // accumulations they belong to: -W of the neighbour's cell 1 is the E tap of its own cell 2, the neighbour's SE tap of
-    // its left column the SE tap, and the neighbour's SW tap of the tick before, negated, the NE tap.  82 arithmetic
-    // instructions per lane-row, 41 per cell-step, 6 of them with a DPP operand -- which stalls the SIMD for about three
-    // issue slots: a gain where the power cap sets the clock (every developed pattern), a loss where the issue slots do
-    // (Species::new on the chips that need the least power); the on-line tuner times both (profiles/r05_cross_lane.md).
-    if constexpr (VS && (FAST & 8) != 0) {
-        RowQ<CPL> R[K][2]; // own columns of the two newest rows of level j
-        // taps of the row a level has just finished: S of cells 1, 2; SE of the column left of the lane's and of cell 1;
-        // SW of cell 2 (own use) and of cell 1 (the left neighbour's use)
-        struct { float s_u[2], s_v[2], se_u[2], se_v[2], sw_u[2], sw_v[2]; } C[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                R[j][0].u[e] = 0.f; R[j][0].v[e] = 0.f; R[j][1].u[e] = 0.f; R[j][1].v[e] = 0.f;
-                C[j].s_u[e] = 0.f; C[j].s_v[e] = 0.f; C[j].se_u[e] = 0.f; C[j].se_v[e] = 0.f; C[j].sw_u[e] = 0.f; C[j].sw_v[e] = 0.f;
-            }
-        }
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        f2 *const mine = reinterpret_cast<f2 *>(fb.halo) + 1 + lane; // (level 0, slot 0); the left neighbour's pair is mine[-1]
-        if (lane == 0)
-#pragma unroll
-            for (int i = 0; i < 2 * K; ++i) mine[i * kCrossLanes - 1] = f2{0.f, 0.f};
-        // acc -/+ the RIGHT neighbour's x in one instruction (lane 63, sacrificial, takes 0).  Volatile: never moved into the
-        // branch around the stores, where the sacrificial lanes -- whose taps their neighbours need -- are off.  s_nop 1:
-        // the two wait states a DPP read needs behind the VALU write of its register, whichever instruction wrote it
-        // (the compiler does not look into half_diff's asm; without the s_nop the same build runs 4-6 % SLOWER).
-        auto minus_next = [](float acc, float x) {
-            float r;
-            asm volatile("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x), "v"(acc));
-            return r;
-        };
-        auto plus_next = [](float acc, float x) {
-            float r;
-            asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x), "v"(acc));
-            return r;
-        };
-        auto put = [&](int j, int slot, const RowQ<CPL> &r) {
-            mine[(j * 2 + slot) * kCrossLanes] = f2{r.u[1], r.v[1]};
-            // what a lane reads back was written by its NEIGHBOUR in the same instruction (see the form below)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
-        auto xs_tick = [&](int tick, int par, int qs, int levels, bool store) {
-            const int l0 = first + tick;
-            GS_TRACE_AT(tick == 3, 1);
-            GS_TRACE_AT(tick == 2 * K, 2);
-            GS_TRACE_AT(tick == nticks - 2 * K, 3);
-            fair_tick(tick);
-            R[0][par] = q[qs];
-            put(0, par, R[0][par]);
-            if constexpr (!LATE) q[qs] = fetch(l0 + 3);
-#pragma unroll
-            for (int j = 1; j <= K; ++j) {
-                if (j > levels) break;
-                const RowQ<CPL> &z = R[j - 1][par ^ 1], &p = R[j - 1][par]; // the row and the row below it
-                auto &c = C[j - 1];
-                const f2 zl = mine[((j - 1) * 2 + (par ^ 1)) * kCrossLanes - 1], pl = mine[((j - 1) * 2 + par) * kCrossLanes - 1];
-                // the three differences across the left boundary
-                const float w1u = half_diff(zl.x, z.u[0]), w1v = half_diff(zl.y, z.v[0]);                       // W of cell 1
-                const float se0u = a.w[2][2] * (p.u[0] - zl.x), se0v = a.w[2][2] * (p.v[0] - zl.y);           // SE of the column left of it
-                const float sw1u = a.w[2][0] * (pl.x - z.u[0]), sw1v = a.w[2][0] * (pl.y - z.v[0]);           // SW of cell 1
-                float nu[CPL], nv[CPL];
-                // cell 1
-                const float u = z.u[0], v = z.v[0];
-                float acc_u = zero_minus(c.se_u[0]), acc_v = zero_minus(c.se_v[0]);                           // NW
-                c.se_u[0] = se0u;                                 c.se_v[0] = se0v;
-                acc_u = acc_u - c.s_u[0];                         acc_v = acc_v - c.s_v[0];                   // N
-                acc_u = acc_u - c.sw_u[1];                        acc_v = acc_v - c.sw_v[1];                  // NE
-                acc_u = acc_u + w1u;                              acc_v = acc_v + w1v;                        // W
-                const float eu = half_diff(z.u[1], u), ev = half_diff(z.v[1], v);
-                acc_u = acc_u + eu;                               acc_v = acc_v + ev;                         // E
-                acc_u = acc_u + sw1u;                             acc_v = acc_v + sw1v;                       // SW
-                c.s_u[0] = half_diff(p.u[0], u);                  c.s_v[0] = half_diff(p.v[0], v);
-                acc_u = acc_u + c.s_u[0];                         acc_v = acc_v + c.s_v[0];                   // S
-                const float seu = a.w[2][2] * (p.u[1] - u), sev = a.w[2][2] * (p.v[1] - v);
-                acc_u = acc_u + seu;                              acc_v = acc_v + sev;                        // SE
-                react<(FAST & 2) != 0>(a, u, v, acc_u, acc_v, nu[0], nv[0]);
-                // cell 2
-                const float u2 = z.u[1], v2 = z.v[1];
-                acc_u = zero_minus(c.se_u[1]);                    acc_v = zero_minus(c.se_v[1]);              // NW
-                c.se_u[1] = seu;                                  c.se_v[1] = sev;
-                acc_u = acc_u - c.s_u[1];                         acc_v = acc_v - c.s_v[1];                   // N
-                acc_u = minus_next(acc_u, c.sw_u[0]);             acc_v = minus_next(acc_v, c.sw_v[0]);       // NE
-                c.sw_u[0] = sw1u;                                 c.sw_v[0] = sw1v;
-                acc_u = acc_u - eu;                               acc_v = acc_v - ev;                         // W
-                acc_u = minus_next(acc_u, w1u);                   acc_v = minus_next(acc_v, w1v);            // E
-                c.sw_u[1] = a.w[2][0] * (p.u[0] - u2);            c.sw_v[1] = a.w[2][0] * (p.v[0] - v2);
-                acc_u = acc_u + c.sw_u[1];                        acc_v = acc_v + c.sw_v[1];                  // SW
-                c.s_u[1] = half_diff(p.u[1], u2);                 c.s_v[1] = half_diff(p.v[1], v2);
-                acc_u = acc_u + c.s_u[1];                         acc_v = acc_v + c.s_v[1];                   // S
-                acc_u = plus_next(acc_u, se0u);                   acc_v = plus_next(acc_v, se0v);             // SE
-                react<(FAST & 2) != 0>(a, u2, v2, acc_u, acc_v, nu[1], nv[1]);
-                if (j < K) {
-#pragma unroll
-                    for (int e = 0; e < CPL; ++e) { R[j][par].u[e] = nu[e]; R[j][par].v[e] = nv[e]; }
-                    put(j, par, R[j][par]);
-                } else if (store && store_ok) {
-                    store_cols_buf<CPL>(wu, voff, (l0 - K - ur0) * pitch_bytes, nu);
-                    store_cols_buf<CPL>(wv, voff, (l0 - K - ur0) * pitch_bytes, nv);
-                }
-            }
-            if constexpr (LATE) q[qs] = fetch(l0 + 3);
-        };
-        // the same peeled ramp-up and 6-tick trips as the form below (every slot index static, no register copies)
-#pragma unroll
-        for (int tick = 0; tick < 2 * K; ++tick) xs_tick(tick, tick & 1, tick % 3, (tick + 1) / 2, false);
-        int t = 2 * K;
-        for (; t + 6 <= nticks; t += 6) {
-#pragma unroll
-            for (int s6 = 0; s6 < 6; ++s6) xs_tick(t + s6, s6 & 1, (2 * K + s6) % 3, K, true);
-        }
-#pragma unroll
-        for (int s6 = 0; s6 < 5; ++s6)
-            if (t + s6 < nticks) xs_tick(t + s6, s6 & 1, (2 * K + s6) % 3, K, true);
-        return;
-    }
     if constexpr (VS) {
+        constexpr bool XS = (FAST & 8) != 0; // ... and across lanes (cells_xshare): only the left neighbour's second column is handed over
         RowQ<CPL> R[K][2]; // own columns of the two newest rows of level j
         TapCarry<CPL> C[K];
 #pragma unroll
@@ -468,18 +416,31 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
                 C[j].s_u[e] = 0.f; C[j].s_v[e] = 0.f; C[j].se_u[e] = 0.f; C[j].se_v[e] = 0.f; C[j].sw_u[e] = 0.f; C[j].sw_v[e] = 0.f;
             }
         }
+        typedef float f2 __attribute__((ext_vector_type(2)));
         float *const mine = fb.halo + 1 + lane; // this lane's element of the first array of (level 0, slot 0)
-        if (lane < 2) // elements 0 and 65 of every array: read by the sacrificial lanes only
+        f2 *const mine2 = reinterpret_cast<f2 *>(fb.halo) + 1 + lane; // XS: its (U, V) pair; the left neighbour's is mine2[-1]
+        // the pads, read by the sacrificial lanes only: elements 0 and 65 of every array / element 0 of every row of pairs
+        if constexpr (XS) {
+            if (lane == 0)
 #pragma unroll
-            for (int i = 0; i < K * 2 * 4; ++i) fb.halo[i * kHaloArray + lane * (kHaloArray - 1)] = 0.0f;
+                for (int i = 0; i < 2 * K; ++i) mine2[i * kCrossLanes - 1] = f2{0.f, 0.f};
+        } else {
+            if (lane < 2)
+#pragma unroll
+                for (int i = 0; i < K * 2 * 4; ++i) fb.halo[i * kHaloArray + lane * (kHaloArray - 1)] = 0.0f;
+        }
         // a new row of level j: its columns go to the board, for the neighbouring lanes
         auto put = [&](int j, int slot, const RowQ<CPL> &r) {
 #if GS_VS_ABLATE_HALO
             return; // (timing experiment: no halo traffic at all; results are wrong)
 #endif
-            float *b = mine + (j * 2 + slot) * kHaloRow;
-            b[0] = r.u[0]; b[kHaloArray] = r.v[0]; b[2 * kHaloArray] = r.u[1]; b[3 * kHaloArray] = r.v[1];
-            // The elements a lane reads back are written by its NEIGHBOURS, in the same two instructions: to the
+            if constexpr (XS) {
+                mine2[(j * 2 + slot) * kCrossLanes] = f2{r.u[1], r.v[1]};
+            } else {
+                float *b = mine + (j * 2 + slot) * kHaloRow;
+                b[0] = r.u[0]; b[kHaloArray] = r.v[0]; b[2 * kHaloArray] = r.u[1]; b[3 * kHaloArray] = r.v[1];
+            }
+            // The elements a lane reads back are written by its NEIGHBOURS, in the same instructions: to the
             // compiler, which sees one lane, they are unrelated to the lane's own stores and could be read first.  The
             // LDS executes a wave's instructions in order; the fence pair keeps the compiler from moving the reads up.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -514,8 +475,13 @@ __device__ __forceinline__ void tb_march(const GsStepArgs &a, int ur0, int ur1, 
             for (int j = 1; j <= K; ++j) {
                 if (j > levels) break;
                 float nu[CPL], nv[CPL];
-                const RowT<CPL> z = widened(j - 1, par ^ 1), p = widened(j - 1, par);
-                cells_vshare<FAST, CPL>(a, z, p, C[j - 1], nu, nv);
+                if constexpr (XS) {
+                    const f2 zl = mine2[((j - 1) * 2 + (par ^ 1)) * kCrossLanes - 1], pl = mine2[((j - 1) * 2 + par) * kCrossLanes - 1];
+                    cells_xshare<FAST>(a, R[j - 1][par ^ 1], R[j - 1][par], zl.x, zl.y, pl.x, pl.y, C[j - 1], nu, nv);
+                } else {
+                    const RowT<CPL> z = widened(j - 1, par ^ 1), p = widened(j - 1, par);
+                    cells_vshare<FAST, CPL>(a, z, p, C[j - 1], nu, nv);
+                }
                 if (j < K) {
 #pragma unroll
                     for (int e = 0; e < CPL; ++e) { R[j][par].u[e] = nu[e]; R[j][par].v[e] = nv[e]; }
