@@ -22,7 +22,7 @@ USEFUL_VALU_PER_CELL_STEP = 53
 # ... and with full difference sharing at 2 columns per lane (grayscott_amd/csrc/gs_march.h: cells_vshare): per lane-row and species
 # 14 x 2 + 5 tap instructions instead of 20 x 2, the same 13 for the reaction
 USEFUL_VALU_PER_CELL_STEP_SHARED = 46
-# ... and with the three differences that cross a lane boundary computed by one lane only (tb_march, FAST & 8): 82 per lane-row
+# ... and with the three differences that cross a lane boundary computed by one lane only (cells_xshare): 82 per lane-row
 USEFUL_VALU_PER_CELL_STEP_SHARED_ACROSS = 41
 NOMINAL_SCLK_MHZ = 2400.0  # the clock VALU_PEAK_TLANEOPS is priced at
 

@@ -354,7 +354,7 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
       "tb-k4" C "/" GS_MATH_NAME ".op.ds"},                                                     \
      {"tb-k1" C "/" GS_MATH_NAME ".op.dx", "tb-k2" C "/" GS_MATH_NAME ".op.dx", "tb-k3" C "/" GS_MATH_NAME ".op.dx",   \
       "tb-k4" C "/" GS_MATH_NAME ".op.dx"}}
-    // ".op.dx": ... and across lanes (tb_march, FAST & 8)
+    // ".op.dx": ... and across lanes (cells_xshare)
     static const char *const names[3][4][4] = {GS_TB_NAMES("c1"), GS_TB_NAMES("c2"), GS_TB_NAMES("")};
 #undef GS_TB_NAMES
     // "f": the fair-progress form (16-wave workgroups) of one-round launches

@@ -1,4 +1,4 @@
-"""Full difference sharing in the temporally blocked kernel (gs_options.share_taps; cells_vshare and tb_march in
+"""Full difference sharing in the temporally blocked kernel (gs_options.share_taps; cells_vshare and cells_xshare in
 grayscott_amd/csrc/gs_march.h): the S / SE / SW taps of a row are carried to the next row, where they are --
 negated -- its N / NW / NE taps; in the second form (share_taps = 3, ".op.dx") the differences that cross a lane
 boundary are also computed once, by the lane on the right, and read by the lane on the left as DPP operands.  The
