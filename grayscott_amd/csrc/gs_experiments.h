@@ -73,6 +73,7 @@ __device__ __forceinline__ unsigned long long trace_now()
 // Integer environment switch, clamped to [lo, hi]; `unset` when the variable is absent or empty.
 //   GS_HIP_TRACE_LAUNCH   1 = print the first 64 kernel launches of the process (label, row ranges, layout)
 //   GS_HIP_TRACE_TUNER    1 = print every timing window of gs_run's on-line tuner and its choice (and gs_fields_place's probes)
+//   GS_HIP_PLACE_ALL      1 = gs_fields_place draws all its candidates even when it has two blocks of each kind (diagnostics)
 //   GS_HIP_EDGE_KINDS     0 = every edge unit of the marching kernel takes the general path (default 1: cheap kinds)
 //   GS_HIP_EDGE_SPLIT     0 / 1 = never / always dispatch edge units as two half-height units (default: by size)
 //   GS_HIP_FAIR           0 / 1 = never / always run one-round launches as in-step 16-wave workgroups

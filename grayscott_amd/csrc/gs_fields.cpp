@@ -209,7 +209,8 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
         if (trace)
             std::fprintf(stderr, "gs_hip placement: %d blocks, means %.4f ... %.4f ms per step, %zu of the rarer kind\n", have, lo / 4.0f,
                          hi / 4.0f, rare.size());
-        if ((rare.size() >= 2 && common.size() >= 2) || drawn >= candidates) break;
+        static const bool draw_all = gs_env_int("GS_HIP_PLACE_ALL", 0, 0, 1) != 0; // diagnostics: never stop early
+        if ((rare.size() >= 2 && common.size() >= 2 && !draw_all) || drawn >= candidates) break;
     }
     // (common, rare, common, rare) over the three clearest of each class: U's planes of one pool, V's of the other
     if (rare.size() >= 2 && common.size() >= 2) {
