@@ -211,7 +211,8 @@ def main() -> int:
         else:
             # A slab chain does not tune on line: rank 0 tunes on a throw-away single slab of the slab's
             # shape and every rank is handed the same configuration (grayscott_amd/dist.py).
-            tuned = gsd.share_tuning(sim, rows // world, cols, rank, world, device=red_dev, local_device=local_rank)
+            tuned = gsd.share_tuning(sim, rows // world, cols, rank, world, device=red_dev, local_device=local_rank,
+                                     place_candidates=place)
 
     def barrier():
         if world > 1:

@@ -91,7 +91,7 @@ def bootstrap(backend: Optional[str] = None, id_source: Optional[Callable[[], by
 
 
 def share_tuning(sim, slab_rows: int, cols: int, rank: int, world: int, device: str = "cpu",
-                 tune_steps: int = 400, local_device: int = 0) -> Tuple[int, int, int]:
+                 tune_steps: int = 400, local_device: int = 0, place_candidates: int = 0) -> Tuple[int, int, int]:
     """Give every process of a slab chain the same tuned kernel configuration.
 
     Multi-process contexts do not tune on line (a timing window would have to be collective).
@@ -108,7 +108,8 @@ def share_tuning(sim, slab_rows: int, cols: int, rank: int, world: int, device: 
         scratch = Simulation.new(sim.params, HipArgs(devices=[local_device], math=args.math, kernel=args.kernel,
                                                      fuse_steps=args.fuse_steps, boundary=args.boundary,
                                                      general_kernels=args.general_kernels, share_taps=args.share_taps))
-        species = scratch.make_species([slab_rows, cols])
+        # (placed like the slabs it stands for: on badly placed planes the tuner measures the HBM, not the kernel)
+        species = scratch.make_species([slab_rows, cols], place_candidates=place_candidates)
         for _ in range(8):                       # long calls wait for their tuning phases
             scratch.perform_steps(species, tune_steps)
             choice = list(scratch.context.get_tuned(slab_rows, cols))
