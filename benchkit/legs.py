@@ -122,7 +122,7 @@ def developed_start(rows, cols):
 
 def upload_species(sim, u0, v0, place_candidates: int = 0):
     """A Species of `sim`'s context whose input planes hold (u0, v0); `steps_done` counts what it has run.
-    `place_candidates` > 0: its four planes are placed by measurement first (gs_fields_place)."""
+    `place_candidates` > 0: its four planes are placed by measurement (gs_fields_place; they keep their contents)."""
     ctx = sim.context
     species = sim.make_species(list(u0.shape), place_candidates=place_candidates)
     in_u, in_v, _, _ = species.in_out()

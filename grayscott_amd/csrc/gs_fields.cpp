@@ -138,109 +138,137 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
     // each class, and time the arrangements (common, rare, common, rare) of the clearest members.
     int best[4] = {0, 1, 2, 3};
     float best_t = 0.0f, first_t = 0.0f;
-    uint32_t rng = 0x9e3779b9u;
-    auto draw = [&](uint32_t n) { rng = rng * 1664525u + 1013904223u; return (int)((rng >> 8) % n); };
-    std::vector<float> sum;
-    std::vector<int> cnt;
-    std::vector<int> rare, common; // block indices by class, clearest first
-    auto timed = [&](const int (&pick)[4], bool count) -> int32_t {
-        float ms = 0.0f;
-        GS_TRY(probe(pick, &ms));
-        if (count)
-            for (int i = 0; i < 4; ++i) { sum[(size_t)pick[i]] += ms; ++cnt[(size_t)pick[i]]; }
-        if (best_t == 0.0f || ms < 0.995f * best_t) { best_t = ms; std::memcpy(best, pick, sizeof best); }
-        return GS_OK;
-    };
-    int drawn = 0;
-    while (true) {
-        const int old = (int)blocks.size();
-        const int batch = old == 4 ? (candidates < 12 ? candidates : 12) : (candidates - drawn < 16 ? candidates - drawn : 16);
-        for (int i = 0; i < batch; ++i) {
-            float *b = nullptr;
-            if (hipMalloc(reinterpret_cast<void **>(&b), n * sizeof(float)) != hipSuccess) { // fewer candidates: fine
-                (void)hipGetLastError();
-                drawn = candidates;
-                break;
-            }
-            const hipError_t e = hipMemsetAsync(b, 0, n * sizeof(float), sl.compute); // zeros, as gs_field_create leaves a plane
-            blocks.push_back(b);
-            if (e != hipSuccess) { release(4); return fail(GS_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e)); }
-            ++drawn;
+    // The planes keep their contents: a copy is set aside before the first probe writes into their blocks and goes into
+    // the blocks they end up with (or back, if anything fails).  Without room for the copy nothing is done.
+    float *stash[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; ++i)
+        if (hipMalloc(reinterpret_cast<void **>(&stash[i]), n * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int j = 0; j < i; ++j) (void)hipFree(stash[j]);
+            return GS_OK;
         }
-        const int have = (int)blocks.size();
-        sum.resize((size_t)have, 0.0f);
-        cnt.resize((size_t)have, 0);
-        if (old == 4) { // the four that are there
-            const int pick[4] = {0, 1, 2, 3};
-            const int32_t st = timed(pick, true);
-            if (st != GS_OK) { release(4); return st; }
-            first_t = best_t;
+    for (int i = 0; i < 4; ++i) {
+        const hipError_t e = hipMemcpyAsync(stash[i], blocks[(size_t)i], n * sizeof(float), hipMemcpyDeviceToDevice, sl.compute);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(sl.compute);
+            for (float *p : stash) (void)hipFree(p);
+            return fail(GS_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
         }
-        if (have == 4) break; // nothing could be drawn
-        // three random 4-subsets per new block, each holding it
-        for (int nb = old == 4 ? 0 : old; nb < have; ++nb)
-            for (int rep = 0; rep < 3; ++rep) {
-                int pick[4] = {nb, nb, nb, nb};
-                const int at = draw(4);
-                for (int i = 0; i < 4; ++i) {
-                    if (i == at) continue;
-                    bool fresh;
-                    do {
-                        pick[i] = draw((uint32_t)have);
-                        fresh = pick[i] != nb;
-                        for (int j = 0; j < i; ++j) fresh = fresh && (j == at || pick[j] != pick[i]);
-                    } while (!fresh);
+        (void)hipMemsetAsync(blocks[(size_t)i], 0, n * sizeof(float), sl.compute); // every probe runs on zeros, like the candidates
+    }
+    auto search = [&]() -> int32_t {
+        uint32_t rng = 0x9e3779b9u;
+        auto draw = [&](uint32_t n) { rng = rng * 1664525u + 1013904223u; return (int)((rng >> 8) % n); };
+        std::vector<float> sum;
+        std::vector<int> cnt;
+        std::vector<int> rare, common; // block indices by class, clearest first
+        auto timed = [&](const int (&pick)[4], bool count) -> int32_t {
+            float ms = 0.0f;
+            GS_TRY(probe(pick, &ms));
+            if (count)
+                for (int i = 0; i < 4; ++i) { sum[(size_t)pick[i]] += ms; ++cnt[(size_t)pick[i]]; }
+            if (best_t == 0.0f || ms < 0.995f * best_t) { best_t = ms; std::memcpy(best, pick, sizeof best); }
+            return GS_OK;
+        };
+        int drawn = 0;
+        while (true) {
+            const int old = (int)blocks.size();
+            const int batch = old == 4 ? (candidates < 12 ? candidates : 12) : (candidates - drawn < 16 ? candidates - drawn : 16);
+            for (int i = 0; i < batch; ++i) {
+                float *b = nullptr;
+                if (hipMalloc(reinterpret_cast<void **>(&b), n * sizeof(float)) != hipSuccess) { // fewer candidates: fine
+                    (void)hipGetLastError();
+                    drawn = candidates;
+                    break;
                 }
+                const hipError_t e = hipMemsetAsync(b, 0, n * sizeof(float), sl.compute); // zeros, as gs_field_create leaves a plane
+                blocks.push_back(b);
+                if (e != hipSuccess) { release(4); return fail(GS_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e)); }
+                ++drawn;
+            }
+            const int have = (int)blocks.size();
+            sum.resize((size_t)have, 0.0f);
+            cnt.resize((size_t)have, 0);
+            if (old == 4) { // the four that are there
+                const int pick[4] = {0, 1, 2, 3};
                 const int32_t st = timed(pick, true);
                 if (st != GS_OK) { release(4); return st; }
+                first_t = best_t;
             }
-        // two classes?  by the means, split half way between the extremes when they are at least 3 % apart
-        std::vector<int> order;
-        for (int b = 0; b < have; ++b)
-            if (cnt[(size_t)b] > 0) order.push_back(b);
-        auto mean = [&](int b) { return sum[(size_t)b] / (float)cnt[(size_t)b]; };
-        std::sort(order.begin(), order.end(), [&](int x, int y) { return mean(x) < mean(y); });
-        rare.clear();
-        common.clear();
-        const float lo = mean(order.front()), hi = mean(order.back());
-        if (hi - lo > 0.03f * hi)
-            for (int b : order) (mean(b) < 0.5f * (lo + hi) ? rare : common).push_back(b);
-        std::reverse(common.begin(), common.end()); // clearest first
-        if (trace)
-            std::fprintf(stderr, "gs_hip placement: %d blocks, means %.4f ... %.4f ms per step, %zu of the rarer kind\n", have, lo / 4.0f,
-                         hi / 4.0f, rare.size());
-        static const bool draw_all = gs_env_int("GS_HIP_PLACE_ALL", 0, 0, 1) != 0; // diagnostics: never stop early
-        if ((rare.size() >= 2 && common.size() >= 2 && !draw_all) || drawn >= candidates) break;
-    }
-    // (common, rare, common, rare) over the three clearest of each class: U's planes of one pool, V's of the other
-    if (rare.size() >= 2 && common.size() >= 2) {
-        const int nr = (int)rare.size() < 3 ? (int)rare.size() : 3, nc = (int)common.size() < 3 ? (int)common.size() : 3;
-        for (int r0 = 0; r0 < nr; ++r0)
-            for (int r1 = r0 + 1; r1 < nr; ++r1)
-                for (int c0 = 0; c0 < nc; ++c0)
-                    for (int c1 = c0 + 1; c1 < nc; ++c1) {
-                        const int pick[4] = {common[(size_t)c0], rare[(size_t)r0], common[(size_t)c1], rare[(size_t)r1]};
-                        const int32_t st = timed(pick, false);
-                        if (st != GS_OK) { release(4); return st; }
+            if (have == 4) break; // nothing could be drawn
+            // three random 4-subsets per new block, each holding it
+            for (int nb = old == 4 ? 0 : old; nb < have; ++nb)
+                for (int rep = 0; rep < 3; ++rep) {
+                    int pick[4] = {nb, nb, nb, nb};
+                    const int at = draw(4);
+                    for (int i = 0; i < 4; ++i) {
+                        if (i == at) continue;
+                        bool fresh;
+                        do {
+                            pick[i] = draw((uint32_t)have);
+                            fresh = pick[i] != nb;
+                            for (int j = 0; j < i; ++j) fresh = fresh && (j == at || pick[j] != pick[i]);
+                        } while (!fresh);
                     }
-    }
-    // hand the chosen blocks to the planes; the probes have written into every block: zeros again
+                    const int32_t st = timed(pick, true);
+                    if (st != GS_OK) { release(4); return st; }
+                }
+            // two classes?  by the means, split half way between the extremes when they are at least 3 % apart
+            std::vector<int> order;
+            for (int b = 0; b < have; ++b)
+                if (cnt[(size_t)b] > 0) order.push_back(b);
+            auto mean = [&](int b) { return sum[(size_t)b] / (float)cnt[(size_t)b]; };
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return mean(x) < mean(y); });
+            rare.clear();
+            common.clear();
+            const float lo = mean(order.front()), hi = mean(order.back());
+            if (hi - lo > 0.03f * hi)
+                for (int b : order) (mean(b) < 0.5f * (lo + hi) ? rare : common).push_back(b);
+            std::reverse(common.begin(), common.end()); // clearest first
+            if (trace)
+                std::fprintf(stderr, "gs_hip placement: %d blocks, means %.4f ... %.4f ms per step, %zu of the rarer kind\n", have, lo / 4.0f,
+                             hi / 4.0f, rare.size());
+            static const bool draw_all = gs_env_int("GS_HIP_PLACE_ALL", 0, 0, 1) != 0; // diagnostics: never stop early
+            if ((rare.size() >= 2 && common.size() >= 2 && !draw_all) || drawn >= candidates) break;
+        }
+        // (common, rare, common, rare) over the three clearest of each class: U's planes of one pool, V's of the other
+        if (rare.size() >= 2 && common.size() >= 2) {
+            const int nr = (int)rare.size() < 3 ? (int)rare.size() : 3, nc = (int)common.size() < 3 ? (int)common.size() : 3;
+            for (int r0 = 0; r0 < nr; ++r0)
+                for (int r1 = r0 + 1; r1 < nr; ++r1)
+                    for (int c0 = 0; c0 < nc; ++c0)
+                        for (int c1 = c0 + 1; c1 < nc; ++c1) {
+                            const int pick[4] = {common[(size_t)c0], rare[(size_t)r0], common[(size_t)c1], rare[(size_t)r1]};
+                            const int32_t st = timed(pick, false);
+                            if (st != GS_OK) { release(4); return st; }
+                        }
+        }
+        return GS_OK;
+    };
+    const int32_t searched = search(); // (on failure only the planes' own four blocks are left)
+    if (searched != GS_OK) { best[0] = 0; best[1] = 1; best[2] = 2; best[3] = 3; }
+    // hand the chosen blocks to the planes, with the contents set aside
     std::vector<float *> chosen(4);
     for (int i = 0; i < 4; ++i) chosen[(size_t)i] = blocks[(size_t)best[i]];
+    hipError_t copied = hipSuccess;
     for (int i = 0; i < 4; ++i) {
         FieldSlab &fs = planes[i]->s[0];
         fs.alloc = chosen[(size_t)i];
         fs.row0 = row0_of(fs.alloc);
-        planes[i]->ghost_depth = kGhostRows;
-        GS_HIP(hipMemsetAsync(fs.alloc, 0, n * sizeof(float), sl.compute));
+        const hipError_t e = hipMemcpyAsync(fs.alloc, stash[i], n * sizeof(float), hipMemcpyDeviceToDevice, sl.compute);
+        if (e != hipSuccess) copied = e;
     }
-    GS_HIP(hipStreamSynchronize(sl.compute));
+    const hipError_t synced = hipStreamSynchronize(sl.compute);
     for (float *b : blocks) {
         bool used = false;
         for (float *c : chosen) used = used || c == b;
         if (!used) (void)hipFree(b);
     }
+    for (float *p : stash) (void)hipFree(p);
     (void)hipGetLastError();
+    if (copied != hipSuccess || synced != hipSuccess)
+        return fail(GS_ERR_HIP, "restoring the planes' contents failed: %s", hipGetErrorString(copied != hipSuccess ? copied : synced));
+    if (searched != GS_OK) return searched;
     if (first_ms) *first_ms = first_t / 4.0f;
     if (best_ms) *best_ms = best_t / 4.0f;
     return GS_OK;

@@ -95,6 +95,8 @@ class HipArgs:
     no_tune: int = field(default_factory=lambda: _env_int("GS_HIP_NO_TUNE", 0))
     tile_shape: int = field(default_factory=lambda: _env_int("GS_HIP_TILE_SHAPE", 0))
     share_taps: int = field(default_factory=lambda: _env_int("GS_HIP_SHARE_TAPS", 0))
+    # not a gs_options field: what make_species hands to gs_fields_place for every Species it creates (0 = no placement)
+    place_candidates: int = field(default_factory=lambda: _env_int("GS_HIP_PLACE_CANDIDATES", 0))
     rank: int = 0
     world: int = 1
     unique_id: Optional[bytes] = None
@@ -408,23 +410,11 @@ class Species:
     @classmethod
     def new(cls, context: HipContext, shape: Sequence[int], place_candidates: int = 0) -> "Species":
         """``Species::new`` (data/src/concentration/mod.rs:36-59).  ``place_candidates`` > 0 (not in the reference): the
-        four planes are first given the best of 4 + n candidate allocations as the single-step kernel measures them
-        (``gs_fields_place``); ``placement`` then holds (ms per step of the first four blocks, of the chosen four)."""
+        four planes are then given the best set of blocks out of up to 4 + n candidate allocations as the single-step kernel
+        measures them (``Species.place``)."""
         shape = (int(shape[0]), int(shape[1]))
-        placement = None
-        if place_candidates > 0:
-            planes = [HipConcentration(context, shape) for _ in range(4)]
-            arr = (ctypes.c_void_p * 4)(*[p.handle for p in planes])
-            first, best = ctypes.c_float(0), ctypes.c_float(0)
-            capi.check(context._lib.gs_fields_place(context.handle, arr, int(place_candidates), ctypes.byref(first),
-                                                    ctypes.byref(best)))
-            placement = (float(first.value), float(best.value))
-            u, v = Evolving([planes[0], planes[2]]), Evolving([planes[1], planes[3]])
-            # as Evolving.ones_out / zeros_out: the OUTPUT slot is what Species::new fills (U = 1, V = 0)
-            capi.check(context._lib.gs_field_fill(context.handle, u.out().handle, 1.0))
-        else:
-            u = Evolving.ones_out(context, shape)
-            v = Evolving.zeros_out(context, shape)
+        u = Evolving.ones_out(context, shape)
+        v = Evolving.zeros_out(context, shape)
         num_range, frac, row_shift = (7, 8), 16, 4
         sl = []
         for i in (0, 1):
@@ -435,8 +425,22 @@ class Species:
         v.out().fill_slice(context, sl, 1.0)
         s = cls(context, u, v)
         s.flip()
-        s.placement = placement
+        s.placement = None
+        if place_candidates > 0:
+            s.place(place_candidates)
         return s
+
+    def place(self, candidates: int) -> Tuple[float, float]:
+        """Placement by measurement (``gs_fields_place``): the four planes move to the blocks that read best together, with
+        their contents.  Returns and remembers (``placement``) the time per single step, in ms, of the blocks they had and
+        of the blocks they have now."""
+        in_u, in_v, out_u, out_v = self.in_out()
+        arr = (ctypes.c_void_p * 4)(in_u.handle, in_v.handle, out_u.handle, out_v.handle)
+        first, best = ctypes.c_float(0), ctypes.c_float(0)
+        ctx = self._context
+        capi.check(ctx._lib.gs_fields_place(ctx.handle, arr, int(candidates), ctypes.byref(first), ctypes.byref(best)))
+        self.placement = (float(first.value), float(best.value))
+        return self.placement
 
     def context(self) -> HipContext:
         return self._context
@@ -486,8 +490,11 @@ class Simulation:
         """``SimulateCreate::new(params, args)`` (compute/shared/src/lib.rs:42-45)."""
         return cls(params, args)
 
-    def make_species(self, shape: Sequence[int], place_candidates: int = 0) -> Species:
-        """``SimulateBase::make_species`` (lib.rs:33-34)."""
+    def make_species(self, shape: Sequence[int], place_candidates: Optional[int] = None) -> Species:
+        """``SimulateBase::make_species`` (lib.rs:33-34).  ``place_candidates``: None = the backend argument
+        (``HipArgs.place_candidates`` / ``--hip-place-candidates`` / GS_HIP_PLACE_CANDIDATES), 0 = no placement."""
+        if place_candidates is None:
+            place_candidates = self.context.args.place_candidates
         return Species.new(self.context, shape, place_candidates)
 
     def perform_steps(self, species: Species, steps: int) -> None:

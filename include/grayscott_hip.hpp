@@ -73,6 +73,9 @@ struct HipArgs {
     std::vector<int32_t> devices{0};
     int32_t math = GS_MATH_STRICT, kernel = GS_KERNEL_AUTO, rows_per_block = 0, fuse_steps = 0, cols_per_lane = 0;
     int32_t boundary = GS_BOUNDARY_CLIPPED, no_tune = 0, share_taps = 0, general_kernels = 0;
+    // not a gs_options field: every Species of make_species is placed by measurement out of up to 4 + place_candidates
+    // blocks (gs_fields_place; worth it from 2^25 cells on; 0 = planes as hipMalloc hands them out)
+    int32_t place_candidates = 0;
 };
 
 // Concentration::Context: owner of the gs_ctx.
@@ -93,8 +96,10 @@ class HipContext {
         o.share_taps = args.share_taps;
         o.general_kernels = args.general_kernels;
         check(gs_ctx_create(&ctx_, &p, &o, args.devices.data(), (int32_t)args.devices.size(), 0, 1, nullptr));
+        place_candidates_ = args.place_candidates;
     }
     ~HipContext() { gs_ctx_destroy(ctx_); }
+    int32_t place_candidates() const { return place_candidates_; }
     HipContext(const HipContext &) = delete;
     HipContext &operator=(const HipContext &) = delete;
     gs_ctx *get() const { return ctx_; }
@@ -111,8 +116,10 @@ class HipContext {
     }
     void set_pass_timing(int32_t passes) const { check(gs_ctx_set_pass_timing(ctx_, passes)); }
 
+
   private:
     gs_ctx *ctx_ = nullptr;
+    int32_t place_candidates_ = 0;
 };
 using Context = std::shared_ptr<HipContext>;
 
@@ -261,6 +268,13 @@ class Species {
     }
     Context &context() { return context_; }
     Shape shape() const { return u_.shape(); }
+    // placement by measurement (gs_fields_place; not in the reference): the four planes move to the blocks that read
+    // best together, with their contents
+    void place(int32_t candidates)
+    {
+        gs_field *planes[4] = {u_.in().raw(), v_.in().raw(), u_.out().raw(), v_.out().raw()};
+        check(gs_fields_place(context_->get(), planes, candidates, nullptr, nullptr));
+    }
     void flip()
     {
         u_.flip(context_);
@@ -293,7 +307,12 @@ class Simulation {
         return Simulation(std::make_shared<HipContext>(params, args));
     }
     // SimulateBase::make_species
-    Species make_species(Shape shape) const { return Species::new_(context_, shape); }
+    Species make_species(Shape shape) const
+    {
+        Species s = Species::new_(context_, shape);
+        if (context_->place_candidates() > 0) s.place(context_->place_candidates());
+        return s;
+    }
     // Simulate::perform_steps: the steps are DONE on return (as in every backend of the reference:
     // compute/shared/src/gpu/mod.rs:77-91 ends in a fence wait); results end up in the input slots
     void perform_steps(Species &species, std::size_t steps) const

@@ -287,10 +287,12 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
  * stops drawing once it has two of each kind, times the (common, rare, common, rare) arrangements of the clearest
  * members, gives the four planes the best set seen and frees the rest: ~60 probes of four steps each and 16 GiB held for
  * 0.3 s at 16384^2 when the first batch holds both kinds; 1.5 s and 128 GiB at the very most.  Measured
- * (profiles/r05_placement.md, r05_cross_lane.md section 4): first four blocks 0.63-0.74 of 8 TB/s, chosen 0.75.  Call
- * it on FRESHLY CREATED planes, before they are filled: their contents are not kept -- all four are zero-filled on
- * return, as gs_field_create leaves them.  first_ms / best_ms (optional): time per step of the planes' original blocks
- * and of the chosen ones. */
+ * (profiles/r05_placement.md, r05_cross_lane.md section 4): first four blocks 0.63-0.74 of 8 TB/s, chosen 0.75.  The
+ * planes KEEP THEIR CONTENTS (a copy is set aside before the probes write into their blocks, and goes into the blocks
+ * they end up with): the call can follow Species::new -- what the host mirrors' make_species do when asked to
+ * (`--hip-place-candidates N`) -- or come in the middle of a run; it waits for the context's work first.  Without room
+ * for the four copies nothing is done.  first_ms / best_ms (optional): time per step of the planes' original blocks
+ * and of the chosen ones (0 when nothing was done). */
 int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidates, float *first_ms, float *best_ms);
 
 /* Wait for everything enqueued on this context (all local devices and streams). */

@@ -66,6 +66,13 @@ extern "C" {
     pub fn gs_field_destroy(ctx: *mut gs_ctx, f: *mut gs_field) -> i32;
     pub fn gs_field_raw_shape(f: *const gs_field, raw_rows: *mut u64, pitch: *mut u64) -> i32;
     pub fn gs_field_fill(ctx: *mut gs_ctx, f: *mut gs_field, value: f32) -> i32;
+    pub fn gs_fields_place(
+        ctx: *mut gs_ctx,
+        planes: *const *mut gs_field,
+        candidates: i32,
+        first_ms: *mut f32,
+        best_ms: *mut f32,
+    ) -> i32;
     pub fn gs_field_fill_slice(
         ctx: *mut gs_ctx,
         f: *mut gs_field,

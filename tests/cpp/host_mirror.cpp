@@ -17,11 +17,14 @@ int main(int argc, char **argv)
     const std::size_t rows = std::strtoull(argv[1], nullptr, 10), cols = std::strtoull(argv[2], nullptr, 10);
     const std::size_t steps = std::strtoull(argv[3], nullptr, 10);
     try {
-        gs::Simulation sim = gs::Simulation::new_(gs::Parameters());
+        gs::HipArgs args;
+        args.place_candidates = 2; // every Species placed by measurement (gs_fields_place), as a large run would ask for
+        gs::Simulation sim = gs::Simulation::new_(gs::Parameters(), args);
         gs::Species species = sim.make_species({rows, cols});
         // the driver's pattern (simulate/src/main.rs:99-106): steps, asynchronous image, more steps
         const std::size_t first = steps / 2;
         sim.perform_steps(species, first);
+        species.place(3); // ... and again in the middle of the run: the planes keep their contents
         gs::PinnedImage image({rows, cols});
         species.write_result_view_after(image);
         if (steps - first > 0) sim.perform_steps(species, steps - first - 1);
