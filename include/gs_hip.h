@@ -50,6 +50,7 @@
  *     GS_HIP_TRACE_TUNER    1 = print every timing window of gs_run's on-line tuner and what it chose, and every probe
  *                           of gs_fields_place
  *   Launch-policy switches for A/B timing (defaults are the measured best; grayscott_amd/csrc/gs_experiments.h):
+ *     GS_HIP_PLACE_ALL      1 = gs_fields_place draws all its candidates even when it holds two blocks of each kind
  *     GS_HIP_EDGE_KINDS     0 = edge units of the marching kernel all take the general path
  *     GS_HIP_EDGE_SPLIT     0 / 1 = never / always dispatch edge units as two half-height units
  *     GS_HIP_FAIR           0 / 1 = never / always run one-round launches as in-step 16-wave workgroups
