@@ -72,9 +72,9 @@ int32_t gs_field_create(gs_ctx *ctx, gs_field **out, uint64_t rows, uint64_t col
 }
 
 // Placement by measurement (gs_hip.h).  Where an allocation lands in HBM is below what a process controls (physical
-// frames, the channel hash over high address bits), and four 1 GiB planes land on one of three levels for the HBM-bound
-// single-step kernel -- 0.66 / 0.70 / 0.75 of 8 TB/s at 16384^2, from one context to the next (profiles/r04_sweeps.md,
-// section 8).  What a process CAN do is draw more blocks than it needs and keep the four that read best together.
+// frames), and it decides the level at which four 1 GiB planes read -- 0.65 ... 0.75 of 8 TB/s for the HBM-bound
+// single-step kernel at 16384^2, 1.09 ... 1.2 M Mcells x steps/s for the marching kernel.  What a process CAN do is draw
+// more blocks than it needs, find out by timed probes which of the two kinds each is, and keep a set split over both.
 int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidates, float *first_ms, float *best_ms)
 {
     if (!ctx || !planes) return fail(GS_ERR_INVALID, "null argument");
