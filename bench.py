@@ -61,10 +61,11 @@ def parse_args():
                     help="skip the replay that compares the timed planes with an independent run (and, on one GPU, "
                          "the single-step HBM leg that is part of it)")
     ap.add_argument("--place-candidates", type=int, default=-1,
-                    help="candidate blocks of gs_fields_place for every Species (default -1: 124 from 2^26 cells per GPU on, else none)")
+                    help="most extra blocks gs_fields_place may draw for every Species (default -1: the library's default -- "
+                         "make_species places Species of >= 2^26 cells per process with at most 12)")
     ap.add_argument("--no-place", action="store_true",
-                    help="planes as hipMalloc hands them out (default: Species of >= 2^26 cells per GPU are placed by "
-                         "measurement, gs_fields_place with up to 124 candidate blocks)")
+                    help="planes as hipMalloc hands them out (--hip-place-candidates 0); `value` then describes a "
+                         "configuration the library does not run by default")
     ap.add_argument("--no-peer-chain", action="store_true",
                     help="N > 1: skip rank 0's in-process chain over all GPUs (hipMemcpyPeerAsync, no RCCL) after the timed job")
     ap.add_argument("--bootstrap", choices=("nccl", "gloo"), default="nccl",
@@ -80,6 +81,20 @@ def parse_args():
                          "built on the fly unless GS_RCCL_LIBRARY names one).  Checks the code path, the numbers "
                          "mean nothing")
     return ap.parse_args()
+
+
+def placement_report(ctx, species, sp_dev, place, slab_rows, cols):
+    """What gs_fields_place did for the Species of the timed context: `transient_GiB` is the most memory it held beyond the
+    planes themselves at any moment (it draws one block of a plane's size at a time and frees what it does not keep)."""
+    probes, drawn = ctx.place_stats()
+    plane_gib = (slab_rows + 8) * ((cols + 63) // 64 * 64) * 4 / 2 ** 30
+    per_species = [sp.placement for sp in (species, sp_dev) if sp is not None and getattr(sp, "placement", None)]
+    return {"default": place is None, "max_extra_blocks": 12 if place is None else place,
+            "species_placed": len(per_species), "probes": probes, "extra_blocks_drawn": drawn,
+            "transient_GiB": round(min(drawn, 12 if place is None else place) * plane_gib, 2),
+            # (mean ms of the probe pass over the two slots' (U, V) pairs: before, after)
+            "timed_species_probe_ms": getattr(species, "placement", None),
+            "developed_species_probe_ms": getattr(sp_dev, "placement", None) if sp_dev is not None else None}
 
 
 def main() -> int:
@@ -173,16 +188,11 @@ def main() -> int:
     # Nothing is allocated, freed or filled between tuning and timing -- round 2's line read 8 % low because 4 GiB of
     # planes were created in that gap and the first launches after it ran on an idle chip's clocks.  The same holds for
     # the planes of the replay (single GPU: a second context pinned to the single-step stream kernel).
-    # Placement by measurement (gs_fields_place): hipMalloc's blocks come from two pools, most from one, and four planes
-    # split 2 + 2 over them read 14 % faster than four of one pool; since round 5 the marching kernel is fast enough to feel
-    # it (1.09 M on four blocks as hipMalloc hands them out, 1.18-1.23 M on a 2 + 2 set, profiles/r05_cross_lane.md).  Every
-    # Species of the timed regions and of the replay draws blocks (12, then 16 at a time, at most 124) until it has two of
-    # the rarer kind.
-    place = 124 if cells_per_gpu >= (1 << 26) and not args.no_place else 0
-    if args.rehearsal:
-        place = min(place, 12)          # the ranks of a rehearsal share one GPU's memory
-    if args.place_candidates >= 0:
-        place = args.place_candidates
+    # Placement by measurement (gs_fields_place) is the LIBRARY'S default for Species of >= 2^26 cells per process, in every
+    # host mirror (make_species): the bench passes nothing and measures what a reference-side caller with default CliArgs
+    # gets.  `value_unplaced` and `single_step.unplaced_frac_of_8TBps` are the same kernels on planes as hipMalloc hands
+    # them out (profiles/r06_placement.md).
+    place = 0 if args.no_place else (args.place_candidates if args.place_candidates >= 0 else None)
     with stage("setup", 900):
         species = sim.make_species([rows, cols], place_candidates=place)
         species.steps_done = 0
@@ -195,7 +205,7 @@ def main() -> int:
             u0, v0 = developed_start(rows, cols)
             sp_dev = upload_species(sim, u0, v0, place)
             if sim_s is not None:
-                sp_dev_s = upload_species(sim_s, u0, v0)
+                sp_dev_s = upload_species(sim_s, u0, v0, 0)      # (the replay of the pattern is not timed)
             del u0, v0
             run(sp_dev, 4000)                            # develops the pattern; also tunes the context
         tuned = (0, 0, 0, 0)
@@ -212,7 +222,7 @@ def main() -> int:
             # A slab chain does not tune on line: rank 0 tunes on a throw-away single slab of the slab's
             # shape and every rank is handed the same configuration (grayscott_amd/dist.py).
             tuned = gsd.share_tuning(sim, rows // world, cols, rank, world, device=red_dev, local_device=local_rank,
-                                     place_candidates=place)
+                                     place_candidates=12 if place is None else place)
 
     def barrier():
         if world > 1:
@@ -311,6 +321,18 @@ def main() -> int:
                          "roofline": {k: v for k, v in roofline_of(ms_dev, p_dev).items()
                                       if k in ("bound", "achieved", "peak", "unit", "frac", "frac_source", "valu", "useful_valu",
                                                "hbm_physical", "algorithmic_GBps", "launch_ms")}}
+        unplaced = None
+        if getattr(species, "placement", None):
+            with stage("unplaced", 600):
+                # the same launches on a Species::new whose planes lie where hipMalloc put them (placement switched off)
+                sp_un = sim.make_species([rows, cols], place_candidates=0)
+                sp_un.steps_done = 0
+                run(sp_un, args.warmup)
+                warm(sp_un)
+                runs_un = repeated(sp_un, args.steps, min(3, args.repeats))
+                unplaced = cells * args.steps / median_run(runs_un)[0] / 1e6
+                for c in sp_un.u._pair + sp_un.v._pair:
+                    c.destroy()
         with stage("energy", 900):
             # informational: shader clock, socket power and energy per cell-step while the same kernel runs
             # (rocm-smi samples next to an untimed repeat of >= 3 s; the VALU roof is priced at the nominal
@@ -328,7 +350,7 @@ def main() -> int:
             try:
                 if single:
                     single_step, verified = verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, kernel_name,
-                                                              extra_placements=2 if args.extra else 0)
+                                                              extra_placements=(2 if args.extra else 1) if getattr(sp_s, "placement", None) else 0)
                 else:
                     verified = verify_slab_chain(sim, species, rows, cols, rank, world, local_rank, args.rehearsal)
             except Exception as e:                      # the line is still worth printing
@@ -389,9 +411,7 @@ def main() -> int:
             "kernel": kernel_name,
             "tuned": {"rows_per_unit": tuned[0], "steps_per_pass": tuned[1], "cols_per_lane": tuned[2],
                       "share_taps": {1: "within lanes", 2: "off", 3: "across lanes"}.get(tuned[3])},
-            # (ms per single step of the first four blocks, of the chosen four) as gs_fields_place's probes read them
-            "placement": {"candidates": place, "timed_species_ms": getattr(species, "placement", None),
-                          "developed_species_ms": getattr(sp_dev, "placement", None) if sp_dev is not None else None},
+            "placement": placement_report(ctx, species, sp_dev, place, rows // world, cols),
             "launches_per_pass": 1 if single else 2,
             "partition": "single GPU" if single else f"{world} row slabs, RCCL send/recv ghost rows",
         },
@@ -413,6 +433,8 @@ def main() -> int:
         roofline["hbm_physical_over_single_step_leg"] = ratio
         if roofline["bound"] == "valu-issue" and ratio >= 0.8:
             roofline["bound"] = "hbm of these planes"
+    if with_extra and unplaced is not None:
+        result["value_unplaced"] = unplaced             # Species::new, planes as hipMalloc hands them out (not the default)
     if developed is not None:
         result["value_developed_pattern"] = developed["value"]
         result["developed_pattern"] = developed
@@ -431,13 +453,23 @@ def main() -> int:
     result["stage_seconds"] = stage_s
     if rank == 0:
         print(json.dumps(result, ensure_ascii=False), flush=True)
+
+    def failed(v):
+        """A verification record that does not say "equal": missing, an error, or a mismatch (nested records too)."""
+        if v is None or "error" in v or v.get("equal") is False:
+            return True
+        return any(isinstance(x, dict) and ("equal" in x or "error" in x) and failed(x) for x in v.values())
+
+    bad = verify and (failed(verified) or (peer_chain is not None and "verified" in peer_chain and failed(peer_chain["verified"])))
     with wd.stage("teardown", 120):
         if sim_s is not None:
             sim_s.context.close()
         ctx.close()
         if world > 1:
             dist.destroy_process_group()
-    return 0
+    if bad and rank == 0:
+        print("bench.py: the timed planes do not equal the replay (see `verified` in the line)", file=sys.stderr)
+    return 3 if bad else 0
 
 
 if __name__ == "__main__":

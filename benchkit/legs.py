@@ -120,9 +120,9 @@ def developed_start(rows, cols):
     return u0, v0
 
 
-def upload_species(sim, u0, v0, place_candidates: int = 0):
+def upload_species(sim, u0, v0, place_candidates=None):
     """A Species of `sim`'s context whose input planes hold (u0, v0); `steps_done` counts what it has run.
-    `place_candidates` > 0: its four planes are placed by measurement (gs_fields_place; they keep their contents)."""
+    `place_candidates`: as make_species (None = the library's default: large Species are placed by measurement)."""
     ctx = sim.context
     species = sim.make_species(list(u0.shape), place_candidates=place_candidates)
     in_u, in_v, _, _ = species.in_out()
@@ -260,7 +260,7 @@ def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_
     # Species to the next (profiles/r04_sweeps.md, section 8).  `value` above is the Species the replay uses.
     placements = [cells / (step_ms * 1e-3) / 1e6]        # (HIP-event rates, like the two below)
     for _ in range(extra_placements):
-        extra = sim_s.make_species([rows, cols])
+        extra = sim_s.make_species([rows, cols], place_candidates=0)     # planes as hipMalloc hands them out
         sim_s.perform_steps(extra, n_region)
         r3 = []
         for _ in range(3):
@@ -273,12 +273,15 @@ def verify_single_gpu(sim_s, sp_s, species, sp_dev_s, sp_dev, rows, cols, timed_
             c.destroy()
     if getattr(sp_s, "placement", None):
         first, best = sp_s.placement
-        single_step["placement"] = {"how": "gs_fields_place: best four of the candidate blocks (config.placement.candidates + 4), single-step probes",
-                                    "first_blocks_ms_per_step": first, "chosen_blocks_ms_per_step": best,
-                                    "first_blocks_frac_of_8TBps": BYTES_PER_CELL_STEP * cells / (first * 1e-3) / 1e9 / HBM_PEAK_GBS if first else None,
-                                    "chosen_blocks_frac_of_8TBps": BYTES_PER_CELL_STEP * cells / (best * 1e-3) / 1e9 / HBM_PEAK_GBS if best else None}
+        probes, drawn = ctx_s.place_stats()
+        single_step["placement"] = {"how": "gs_fields_place (the library's default for Species of >= 2^26 cells): U's and V's planes in "
+                                           "blocks of different physical regions; probe = a pass that reads and writes back a slot's two planes",
+                                    "first_blocks_probe_ms": first, "chosen_blocks_probe_ms": best,
+                                    "probes": probes, "extra_blocks_drawn": drawn}
+    if extra_placements:
+        # the same kernel on planes as hipMalloc hands them out (what a caller gets with --hip-place-candidates 0)
+        single_step["unplaced_frac_of_8TBps"] = [round(x * 1e6 * BYTES_PER_CELL_STEP / 1e9 / HBM_PEAK_GBS, 4) for x in placements[1:]]
     single_step["by_plane_placement"] = [round(x) for x in placements]
-    single_step["frac_of_8TBps_best_placement"] = max(placements) * 1e6 * BYTES_PER_CELL_STEP / 1e9 / HBM_PEAK_GBS
     left = species.steps_done - sp_s.steps_done
     if left < 0:
         raise RuntimeError(f"the replay is ahead of the timed Species ({sp_s.steps_done} > {species.steps_done} steps)")

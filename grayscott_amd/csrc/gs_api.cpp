@@ -590,6 +590,7 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
         if (ctx->win.words) (void)hipFree(ctx->win.words);
         if (ctx->win.desc) (void)hipFree(ctx->win.desc);
     }
+    if (ctx->win.seen) (void)hipHostFree(ctx->win.seen);
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     if (ctx->band_join) (void)hipEventDestroy(ctx->band_join);

@@ -71,10 +71,15 @@ int32_t gs_field_create(gs_ctx *ctx, gs_field **out, uint64_t rows, uint64_t col
     return GS_OK;
 }
 
-// Placement by measurement (gs_hip.h).  Where an allocation lands in HBM is below what a process controls (physical
-// frames), and it decides the level at which four 1 GiB planes read -- 0.65 ... 0.75 of 8 TB/s for the HBM-bound
-// single-step kernel at 16384^2, 1.09 ... 1.2 M Mcells x steps/s for the marching kernel.  What a process CAN do is draw
-// more blocks than it needs, find out by timed probes which of the two kinds each is, and keep a set split over both.
+// Placement by measurement (gs_hip.h).  hipMalloc's blocks lie in physical regions ("groups") that a process cannot
+// see or choose, and two planes of ONE group that are written (and read) in the same pass cost 0.86-0.96 ms per GiB
+// pair where two of different groups cost 0.72-0.79 (tools/ubench/hbm_kinds.hip; profiles/r06_placement.md): four planes of
+// one group run the single-step kernel at 0.58-0.65 of 8 TB/s, U's planes in one group and V's in another at 0.73-0.76.
+// A pass that reads two blocks and writes them back unchanged (gs_launch_pair_probe) tells the two cases apart in 3 ms
+// without touching the planes' contents.  So: time the pairs among the planes' four blocks; if each slot's (U, V) pair
+// is already as fast as the fastest pair seen -- and a slower pair has been seen, i.e. the fast ones are known to be
+// cross-group pairs -- nothing moves.  Else draw blocks one at a time (at most `candidates`), time each against all held,
+// and stop as soon as two disjoint fast pairs exist; the planes move (device copies) to the best two pairs.
 int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidates, float *first_ms, float *best_ms)
 {
     if (!ctx || !planes) return fail(GS_ERR_INVALID, "null argument");
@@ -94,183 +99,189 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
     SlabRt &sl = ctx->slabs[0];
     GS_HIP(hipSetDevice(sl.device));
     const size_t pitch = (size_t)f0->pitch;
-    const size_t n = (size_t)(f0->s[0].rows + 2 * kGhostRows) * pitch + 2 * kGuardFloats;
+    const size_t n = (size_t)(f0->s[0].rows + 2 * kGhostRows) * pitch + 2 * kGuardFloats; // (a multiple of 64 floats)
+    const size_t bytes = n * sizeof(float);
+    static const bool trace = gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1) != 0;
+    static const bool draw_all = gs_env_int("GS_HIP_PLACE_ALL", 0, 0, 1) != 0; // diagnostics: never stop early
     std::vector<float *> blocks;
     for (int i = 0; i < 4; ++i) blocks.push_back(planes[i]->s[0].alloc);
-    auto release = [&](int keep_from) { // frees the blocks from index keep_from on
-        for (size_t i = (size_t)keep_from; i < blocks.size(); ++i)
-            if (blocks[i]) (void)hipFree(blocks[i]);
-        blocks.resize((size_t)keep_from);
-    };
-    auto row0_of = [&](float *b) { return b + kGuardFloats + (size_t)kGhostRows * pitch; };
-    // a probe: four single steps ping-ponging between (a, b) and (c, d), timed with the context's events
-    GsStepArgs base = make_args(ctx, planes[0], planes[1], planes[2], planes[3], 0, 1);
-    base.ra0 = 0;
-    base.ra1 = base.rows;
-    const bool fused = ctx->o.math == GS_MATH_FUSED;
-    static const bool trace = gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1) != 0;
-    auto probe = [&](const int (&pick)[4], float *ms) -> int32_t {
-        float *p[4];
-        for (int i = 0; i < 4; ++i) p[i] = row0_of(blocks[(size_t)pick[i]]);
-        for (int rep = 0; rep < 5; ++rep) { // the first step is not timed
-            if (rep == 1) GS_HIP(hipEventRecord(sl.t0, sl.compute));
-            GsStepArgs a = base;
-            const int in = (rep & 1) * 2, out = 2 - in;
-            a.in_u = p[in]; a.in_v = p[in + 1]; a.out_u = p[out]; a.out_v = p[out + 1];
-            const char *name = nullptr;
-            const hipError_t e = fused ? gs_launch_stream_fused(a, sl.compute, &name) : gs_launch_stream_strict(a, sl.compute, &name);
+    std::vector<std::vector<float>> T(4, std::vector<float>(4, 0.0f)); // pair times, ms
+    int probes = 0;
+    auto pair_ms = [&](int i, int j, float *ms) -> int32_t {
+        float best = 0.0f;
+        for (int rep = 0; rep < 3; ++rep) { // the first pass is not timed
+            if (rep > 0) GS_HIP(hipEventRecord(sl.t0, sl.compute));
+            const hipError_t e = gs_launch_pair_probe(blocks[(size_t)i], blocks[(size_t)j], bytes, sl.compute);
             if (e != hipSuccess) return fail(GS_ERR_HIP, "probe launch failed: %s", hipGetErrorString(e));
+            if (rep > 0) {
+                float t = 0.0f;
+                GS_HIP(hipEventRecord(sl.t1, sl.compute));
+                GS_HIP(hipEventSynchronize(sl.t1));
+                GS_HIP(hipEventElapsedTime(&t, sl.t0, sl.t1));
+                if (best == 0.0f || t < best) best = t;
+            }
         }
-        GS_HIP(hipEventRecord(sl.t1, sl.compute));
-        GS_HIP(hipEventSynchronize(sl.t1));
-        GS_HIP(hipEventElapsedTime(ms, sl.t0, sl.t1));
-        if (trace)
-            std::fprintf(stderr, "gs_hip placement: blocks %3d %3d %3d %3d (%p %p %p %p): %.4f ms per step\n", pick[0], pick[1], pick[2],
-                         pick[3], (void *)blocks[(size_t)pick[0]], (void *)blocks[(size_t)pick[1]], (void *)blocks[(size_t)pick[2]],
-                         (void *)blocks[(size_t)pick[3]], *ms / 4.0f);
+        ++probes;
+        if (trace) std::fprintf(stderr, "gs_hip placement: blocks %2d %2d (%p %p): %.4f ms per pass\n", i, j, (void *)blocks[(size_t)i], (void *)blocks[(size_t)j], best);
+        *ms = best;
         return GS_OK;
     };
-    // What the probes of rounds 4 and 5 say about this memory (profiles/r05_cross_lane.md, section 4): the blocks hipMalloc
-    // hands out come from TWO pools, most of them from one; four planes read by how they are split over the two -- 4 + 0:
-    // 0.82 ms per single step at 16384^2, 3 + 1: 0.77, 2 + 2: 0.72 when the inputs (and so the outputs) are one of each,
-    // 0.76-0.80 when both inputs are of one pool.  So: draw blocks in batches, time random 4-subsets, class the blocks by
-    // the mean time of the subsets they were in (the rare kind pulls its subsets down), stop drawing once there are two of
-    // each class, and time the arrangements (common, rare, common, rare) of the clearest members.
+    auto release_extra = [&](const int (&keep)[4]) {
+        for (size_t i = 4; i < blocks.size(); ++i) {
+            bool used = false;
+            for (int k : keep) used = used || (size_t)k == i;
+            if (!used && blocks[i]) (void)hipFree(blocks[i]);
+        }
+    };
+    // the best two disjoint pairs (p0, p1) and (p2, p3) held: the cost of an arrangement is T(U0, V0) + T(U1, V1) --
+    // each pass writes one slot's two planes and reads the other's
     int best[4] = {0, 1, 2, 3};
-    float best_t = 0.0f, first_t = 0.0f;
-    // The planes keep their contents: a copy is set aside before the first probe writes into their blocks and goes into
-    // the blocks they end up with (or back, if anything fails).  Without room for the copy nothing is done.
-    float *stash[4] = {nullptr, nullptr, nullptr, nullptr};
-    for (int i = 0; i < 4; ++i)
-        if (hipMalloc(reinterpret_cast<void **>(&stash[i]), n * sizeof(float)) != hipSuccess) {
-            (void)hipGetLastError();
-            for (int j = 0; j < i; ++j) (void)hipFree(stash[j]);
-            return GS_OK;
-        }
-    for (int i = 0; i < 4; ++i) {
-        const hipError_t e = hipMemcpyAsync(stash[i], blocks[(size_t)i], n * sizeof(float), hipMemcpyDeviceToDevice, sl.compute);
-        if (e != hipSuccess) {
-            (void)hipStreamSynchronize(sl.compute);
-            for (float *p : stash) (void)hipFree(p);
-            return fail(GS_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
-        }
-        (void)hipMemsetAsync(blocks[(size_t)i], 0, n * sizeof(float), sl.compute); // every probe runs on zeros, like the candidates
-    }
-    auto search = [&]() -> int32_t {
-        uint32_t rng = 0x9e3779b9u;
-        auto draw = [&](uint32_t n) { rng = rng * 1664525u + 1013904223u; return (int)((rng >> 8) % n); };
-        std::vector<float> sum;
-        std::vector<int> cnt;
-        std::vector<int> rare, common; // block indices by class, clearest first
-        auto timed = [&](const int (&pick)[4], bool count) -> int32_t {
-            float ms = 0.0f;
-            GS_TRY(probe(pick, &ms));
-            if (count)
-                for (int i = 0; i < 4; ++i) { sum[(size_t)pick[i]] += ms; ++cnt[(size_t)pick[i]]; }
-            if (best_t == 0.0f || ms < 0.995f * best_t) { best_t = ms; std::memcpy(best, pick, sizeof best); }
-            return GS_OK;
-        };
-        int drawn = 0;
-        while (true) {
-            const int old = (int)blocks.size();
-            const int batch = old == 4 ? (candidates < 12 ? candidates : 12) : (candidates - drawn < 16 ? candidates - drawn : 16);
-            for (int i = 0; i < batch; ++i) {
-                float *b = nullptr;
-                if (hipMalloc(reinterpret_cast<void **>(&b), n * sizeof(float)) != hipSuccess) { // fewer candidates: fine
-                    (void)hipGetLastError();
-                    drawn = candidates;
-                    break;
-                }
-                const hipError_t e = hipMemsetAsync(b, 0, n * sizeof(float), sl.compute); // zeros, as gs_field_create leaves a plane
-                blocks.push_back(b);
-                if (e != hipSuccess) { release(4); return fail(GS_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e)); }
-                ++drawn;
-            }
-            const int have = (int)blocks.size();
-            sum.resize((size_t)have, 0.0f);
-            cnt.resize((size_t)have, 0);
-            if (old == 4) { // the four that are there
-                const int pick[4] = {0, 1, 2, 3};
-                const int32_t st = timed(pick, true);
-                if (st != GS_OK) { release(4); return st; }
-                first_t = best_t;
-            }
-            if (have == 4) break; // nothing could be drawn
-            // three random 4-subsets per new block, each holding it
-            for (int nb = old == 4 ? 0 : old; nb < have; ++nb)
-                for (int rep = 0; rep < 3; ++rep) {
-                    int pick[4] = {nb, nb, nb, nb};
-                    const int at = draw(4);
-                    for (int i = 0; i < 4; ++i) {
-                        if (i == at) continue;
-                        bool fresh;
-                        do {
-                            pick[i] = draw((uint32_t)have);
-                            fresh = pick[i] != nb;
-                            for (int j = 0; j < i; ++j) fresh = fresh && (j == at || pick[j] != pick[i]);
-                        } while (!fresh);
+    auto cost_of = [&](const int (&p)[4]) { return T[(size_t)p[0]][(size_t)p[1]] + T[(size_t)p[2]][(size_t)p[3]]; };
+    auto search = [&]() {
+        const int m = (int)blocks.size();
+        float c_best = cost_of(best);
+        for (int a = 0; a < m; ++a)
+            for (int b = a + 1; b < m; ++b)
+                for (int c = a + 1; c < m; ++c)
+                    for (int d = c + 1; d < m; ++d) {
+                        if (c == b || d == b) continue;
+                        const int p[4] = {a, b, c, d};
+                        // (an arrangement that moves fewer planes wins a tie of 0.5 %)
+                        if (cost_of(p) < 0.995f * c_best) { c_best = cost_of(p); std::memcpy(best, p, sizeof best); }
                     }
-                    const int32_t st = timed(pick, true);
-                    if (st != GS_OK) { release(4); return st; }
-                }
-            // two classes?  by the means, split half way between the extremes when they are at least 3 % apart
-            std::vector<int> order;
-            for (int b = 0; b < have; ++b)
-                if (cnt[(size_t)b] > 0) order.push_back(b);
-            auto mean = [&](int b) { return sum[(size_t)b] / (float)cnt[(size_t)b]; };
-            std::sort(order.begin(), order.end(), [&](int x, int y) { return mean(x) < mean(y); });
-            rare.clear();
-            common.clear();
-            const float lo = mean(order.front()), hi = mean(order.back());
-            if (hi - lo > 0.03f * hi)
-                for (int b : order) (mean(b) < 0.5f * (lo + hi) ? rare : common).push_back(b);
-            std::reverse(common.begin(), common.end()); // clearest first
-            if (trace)
-                std::fprintf(stderr, "gs_hip placement: %d blocks, means %.4f ... %.4f ms per step, %zu of the rarer kind\n", have, lo / 4.0f,
-                             hi / 4.0f, rare.size());
-            static const bool draw_all = gs_env_int("GS_HIP_PLACE_ALL", 0, 0, 1) != 0; // diagnostics: never stop early
-            if ((rare.size() >= 2 && common.size() >= 2 && !draw_all) || drawn >= candidates) break;
-        }
-        // (common, rare, common, rare) over the three clearest of each class: U's planes of one pool, V's of the other
-        if (rare.size() >= 2 && common.size() >= 2) {
-            const int nr = (int)rare.size() < 3 ? (int)rare.size() : 3, nc = (int)common.size() < 3 ? (int)common.size() : 3;
-            for (int r0 = 0; r0 < nr; ++r0)
-                for (int r1 = r0 + 1; r1 < nr; ++r1)
-                    for (int c0 = 0; c0 < nc; ++c0)
-                        for (int c1 = c0 + 1; c1 < nc; ++c1) {
-                            const int pick[4] = {common[(size_t)c0], rare[(size_t)r0], common[(size_t)c1], rare[(size_t)r1]};
-                            const int32_t st = timed(pick, false);
-                            if (st != GS_OK) { release(4); return st; }
-                        }
-        }
-        return GS_OK;
     };
-    const int32_t searched = search(); // (on failure only the planes' own four blocks are left)
-    if (searched != GS_OK) { best[0] = 0; best[1] = 1; best[2] = 2; best[3] = 3; }
-    // hand the chosen blocks to the planes, with the contents set aside
+    int32_t st = GS_OK;
+    for (int i = 0; i < 4 && st == GS_OK; ++i)
+        for (int j = i + 1; j < 4 && st == GS_OK; ++j) {
+            st = pair_ms(i, j, &T[(size_t)i][(size_t)j]);
+            T[(size_t)j][(size_t)i] = T[(size_t)i][(size_t)j];
+        }
+    if (st != GS_OK) return st;
+    const float first_cost = cost_of(best);
+    int drawn = 0;
+    while (true) {
+        search();
+        // good enough?  Planes of >= 512 MiB are judged by the rate of the probe pass itself: 4 x bytes per pass at
+        // >= 5.25 TB/s is a cross-group pair (5.4-6.0 TB/s measured on every box), less is a pair of one group
+        // (4.3-5.0): the spread INSIDE either class (0.72-0.80 ms, 0.86-0.99 ms per GiB pair) is as wide as a small
+        // gap between them, so relative criteria alone mistook five blocks of one group for a settled case.  Smaller
+        // planes partly live in the 256 MB last-level cache and have no absolute scale: both pairs within 7 % of the
+        // fastest pair seen, and a pair at least 14 % slower seen.
+        float lo = 0.0f, hi = 0.0f;
+        const int m = (int)blocks.size();
+        for (int i = 0; i < m; ++i)
+            for (int j = i + 1; j < m; ++j) {
+                const float t = T[(size_t)i][(size_t)j];
+                if (lo == 0.0f || t < lo) lo = t;
+                if (t > hi) hi = t;
+            }
+        const float t01 = T[(size_t)best[0]][(size_t)best[1]], t23 = T[(size_t)best[2]][(size_t)best[3]];
+        bool both_fast, contrast;
+        if (bytes >= ((size_t)512 << 20)) {
+            const float fast_ms = (float)(4.0 * (double)bytes / 5.25e12 * 1e3);
+            both_fast = t01 <= fast_ms && t23 <= fast_ms;
+            contrast = true;
+        } else {
+            both_fast = t01 <= 1.07f * lo && t23 <= 1.07f * lo;
+            contrast = hi >= 1.14f * lo;
+        }
+        if (trace)
+            std::fprintf(stderr, "gs_hip placement: %d blocks, pairs %.4f ... %.4f ms, best arrangement %d %d | %d %d = %.4f ms per pass%s\n", m, lo,
+                         hi, best[0], best[1], best[2], best[3], 0.5f * cost_of(best), both_fast && contrast ? " (settled)" : "");
+        if ((both_fast && contrast && !draw_all) || drawn >= candidates) break;
+        float *b = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&b), bytes) != hipSuccess) { (void)hipGetLastError(); break; } // fewer candidates: fine
+        blocks.push_back(b);
+        ++drawn;
+        for (auto &row : T) row.push_back(0.0f);
+        T.emplace_back(blocks.size(), 0.0f);
+        const int nb = (int)blocks.size() - 1;
+        for (int i = 0; i < nb && st == GS_OK; ++i) {
+            st = pair_ms(i, nb, &T[(size_t)i][(size_t)nb]);
+            T[(size_t)nb][(size_t)i] = T[(size_t)i][(size_t)nb];
+        }
+        if (st != GS_OK) { const int keep[4] = {0, 1, 2, 3}; release_extra(keep); return st; }
+    }
+    // hand the chosen blocks to the planes, with their contents: a plane that stays among the chosen four keeps its
+    // block where it can (no copy), the others are copied into the blocks nobody holds
     std::vector<float *> chosen(4);
     for (int i = 0; i < 4; ++i) chosen[(size_t)i] = blocks[(size_t)best[i]];
-    hipError_t copied = hipSuccess;
-    for (int i = 0; i < 4; ++i) {
+    // slot pairs are unordered, and so is the order of the two pairs: try the 8 equivalent arrangements, keep the one
+    // that leaves most planes where they are
+    {
+        int keep_best = -1;
+        std::vector<float *> pick = chosen;
+        for (int v = 0; v < 8; ++v) {
+            int q[4] = {best[0], best[1], best[2], best[3]};
+            if (v & 1) std::swap(q[0], q[1]);
+            if (v & 2) std::swap(q[2], q[3]);
+            if (v & 4) { std::swap(q[0], q[2]); std::swap(q[1], q[3]); }
+            int kept = 0;
+            for (int i = 0; i < 4; ++i) kept += q[i] == i;
+            if (kept > keep_best) {
+                keep_best = kept;
+                for (int i = 0; i < 4; ++i) pick[(size_t)i] = blocks[(size_t)q[i]];
+            }
+        }
+        chosen = pick;
+    }
+    // Moves, one synchronous device copy at a time, the plane's handle updated after each: at every moment (and after a
+    // failure) every plane holds its contents in the block its handle names.  A plane moves when nobody holds its
+    // chosen block; planes that wait for each other (two planes swapping blocks) go through a spare block.
+    hipError_t err = hipSuccess;
+    auto holder = [&](float *b) { for (int k = 0; k < 4; ++k) if (planes[k]->s[0].alloc == b) return k; return -1; };
+    auto move = [&](int i, float *to) {
         FieldSlab &fs = planes[i]->s[0];
-        fs.alloc = chosen[(size_t)i];
-        fs.row0 = row0_of(fs.alloc);
-        const hipError_t e = hipMemcpyAsync(fs.alloc, stash[i], n * sizeof(float), hipMemcpyDeviceToDevice, sl.compute);
-        if (e != hipSuccess) copied = e;
+        const hipError_t e = hipMemcpy(to, fs.alloc, bytes, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) { err = e; return false; }
+        fs.alloc = to;
+        fs.row0 = to + kGuardFloats + (size_t)kGhostRows * pitch;
+        return true;
+    };
+    while (err == hipSuccess) {
+        bool progress = false, unsettled = false;
+        for (int i = 0; i < 4 && err == hipSuccess; ++i) {
+            if (planes[i]->s[0].alloc == chosen[(size_t)i]) continue;
+            if (holder(chosen[(size_t)i]) < 0) progress = move(i, chosen[(size_t)i]) || progress;
+            else unsettled = true;
+        }
+        if (progress || !unsettled || err != hipSuccess) { if (!progress) break; continue; }
+        // a cycle: park one of its planes in a spare block
+        float *spare = nullptr;
+        for (size_t k = 0; k < blocks.size() && !spare; ++k) {
+            bool is_chosen = false;
+            for (float *c : chosen) is_chosen = is_chosen || c == blocks[k];
+            if (!is_chosen && holder(blocks[k]) < 0) spare = blocks[k];
+        }
+        if (!spare && hipMalloc(reinterpret_cast<void **>(&spare), bytes) == hipSuccess) blocks.push_back(spare);
+        if (!spare) { // no room to swap: the planes of the cycle stay where they are
+            (void)hipGetLastError();
+            for (int k = 0; k < 4; ++k) chosen[(size_t)k] = planes[k]->s[0].alloc;
+            break;
+        }
+        for (int i = 0; i < 4; ++i)
+            if (planes[i]->s[0].alloc != chosen[(size_t)i]) { (void)move(i, spare); break; }
     }
-    const hipError_t synced = hipStreamSynchronize(sl.compute);
-    for (float *b : blocks) {
-        bool used = false;
-        for (float *c : chosen) used = used || c == b;
-        if (!used) (void)hipFree(b);
+    // release what no plane holds now (drawn blocks that were not chosen, original blocks that were left, a spare)
+    for (float *b : blocks)
+        if (holder(b) < 0) (void)hipFree(b);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(GS_ERR_HIP, "moving a plane failed (every plane still holds its contents): %s", hipGetErrorString(err));
     }
-    for (float *p : stash) (void)hipFree(p);
     (void)hipGetLastError();
-    if (copied != hipSuccess || synced != hipSuccess)
-        return fail(GS_ERR_HIP, "restoring the planes' contents failed: %s", hipGetErrorString(copied != hipSuccess ? copied : synced));
-    if (searched != GS_OK) return searched;
-    if (first_ms) *first_ms = first_t / 4.0f;
-    if (best_ms) *best_ms = best_t / 4.0f;
+    ctx->place_probes += (uint64_t)probes;
+    ctx->place_drawn += (uint64_t)drawn;
+    if (first_ms) *first_ms = 0.5f * first_cost;
+    if (best_ms) *best_ms = 0.5f * cost_of(best);
+    return GS_OK;
+}
+
+int32_t gs_debug_place_stats(const gs_ctx *ctx, uint64_t *probes, uint64_t *blocks_drawn)
+{
+    if (!ctx) return fail(GS_ERR_INVALID, "null context");
+    if (probes) *probes = ctx->place_probes;
+    if (blocks_drawn) *blocks_drawn = ctx->place_drawn;
     return GS_OK;
 }
 
@@ -417,7 +428,18 @@ int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host)
     if (!ctx || !f || f->ctx != ctx) return fail(GS_ERR_INVALID, "bad argument");
     if (f->rows == 0 || f->cols == 0) return GS_OK; // nothing to copy (host may be null)
     if (!host) return fail(GS_ERR_INVALID, "bad argument");
-    GS_TRY(resolve_window(ctx)); // (waits for a persistent window launch in flight: its result must be known to be valid)
+    // A persistent window launch in flight may still give up (its workgroups not all resident): the copy is enqueued
+    // behind it all the same -- this call never waits -- and the image is validated when it is waited for
+    // (gs_download_wait; anything else that waits for results does it too: resolve_window).
+    gs_ctx::WindowRt &w = ctx->win;
+    if (w.pending) {
+        if (!w.seen) {
+            GS_HIP(hipSetDevice(ctx->slabs[0].device));
+            GS_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.seen), sizeof(int32_t), hipHostMallocDefault));
+            *w.seen = 0;
+        }
+        w.images.push_back(gs_ctx::WindowRt::Image{f, host, w.seq});
+    }
     const uint64_t first = f->s.front().g_row0;
     const int last = (int)((ctx->step_no + 1) & 1); // parity of the most recent pass
     for (size_t i = 0; i < f->s.size(); ++i) {
@@ -445,6 +467,8 @@ int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host)
         GS_HIP(hipStreamWaitEvent(sl.copy, sl.staged, 0));
         GS_HIP(hipMemcpyAsync(host + (fs.g_row0 - first) * f->cols, sl.stage, need * sizeof(float),
                               hipMemcpyDeviceToHost, sl.copy));
+        if (w.pending && i == 0) // the abort word as it stands once the launches this image depends on have ended
+            GS_HIP(hipMemcpyAsync(w.seen, w.words + kWindowMaxTiles, sizeof(int32_t), hipMemcpyDeviceToHost, sl.copy));
         GS_HIP(hipEventRecord(sl.copied, sl.copy));
     }
     return GS_OK;
@@ -485,6 +509,14 @@ int32_t gs_download_wait(gs_ctx *ctx)
     for (auto &sl : ctx->slabs) {
         GS_HIP(hipSetDevice(sl.device));
         GS_HIP(hipStreamSynchronize(sl.copy));
+    }
+    // images enqueued behind persistent window launches: did one of those launches give up?  (Then the launches are run
+    // again with the marching kernel and the images fetched again: resolve_window.)  The launches that are still running
+    // stay pending; only the images are settled here.
+    gs_ctx::WindowRt &w = ctx->win;
+    if (!w.images.empty()) {
+        if (w.seen && *w.seen != 0) GS_TRY(resolve_window(ctx));
+        w.images.clear();
     }
     return GS_OK;
 }

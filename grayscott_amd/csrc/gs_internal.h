@@ -120,6 +120,7 @@ struct gs_ctx {
     const char *last_kernel = "none";
     uint64_t launches = 0;
     uint64_t passes = 0, steps_done = 0, ghost_refreshes = 0; // gs_ctx_stats
+    uint64_t place_probes = 0, place_drawn = 0;               // gs_fields_place: pair probes timed, extra blocks drawn (gs_debug_place_stats)
     int pass_timing = 0;                                      // passes per slab still to be timed (0 = off)
     // Configuration of the temporally blocked kernel in force (tuned_rpu > 0): unit height, fused steps
     // per pass and columns per lane for slabs of tuned_rows x tuned_cols -- chosen by gs_run's on-line
@@ -178,6 +179,13 @@ struct gs_ctx {
         std::vector<Launch> launched;
         int32_t seq = 0;
         uint64_t fallbacks = 0;
+        // Images requested with gs_field_download_async while launches were pending: the copy is enqueued behind the
+        // launch (nothing waits), and whether the launch gave up is only known when the image is WAITED for -- the abort
+        // word travels to `seen` (pinned host memory) behind the image.  If launch `after_seq` or an earlier one gave up,
+        // resolve_window fetches the image again right after it has run that launch again.
+        struct Image { gs_field *f; float *host; int32_t after_seq; };
+        std::vector<Image> images;
+        int32_t *seen = nullptr; // pinned: the abort word as the copy stream last saw it
     } win;
     int share_now = kShareDefault; // form of difference sharing in force when gs_options.share_taps leaves the choice open (share_mode)
     int cu_count = 0; // compute units of the first slab's device

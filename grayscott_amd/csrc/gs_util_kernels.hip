@@ -35,7 +35,34 @@ __global__ __launch_bounds__(256) void gs_colormap_k(const float *row0, int pitc
     px[1] = palette[3 * i + 1];
     px[2] = palette[3 * i + 2];
 }
+// The probe of gs_fields_place: one pass that reads two blocks and writes both back, word for word what it read (the
+// XOR with a kernel argument that is zero at run time keeps the compiler from dropping the stores) -- the HBM traffic of
+// one time step on a slot's two planes, and the blocks keep their contents.  Two 1 GiB blocks of ONE physical region
+// ("group") take 0.86-0.96 ms, two of different groups 0.72-0.79 ms (tools/ubench/hbm_kinds.hip, profiles/r06_placement.md).
+__global__ __launch_bounds__(256) void gs_pair_probe_k(uint4 *x, uint4 *y, size_t n, uint32_t zero)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint4 a = x[i], b = y[i];
+        a.x ^= zero; a.y ^= zero; a.z ^= zero; a.w ^= zero;
+        b.x ^= zero; b.y ^= zero; b.z ^= zero; b.w ^= zero;
+        x[i] = a;
+        y[i] = b;
+    }
+}
 } // namespace
+
+hipError_t gs_launch_pair_probe(void *x, void *y, size_t bytes, hipStream_t s)
+{
+    size_t n = bytes / sizeof(uint4);
+    if (n == 0) return hipSuccess;
+    uint4 *px = static_cast<uint4 *>(x), *py = static_cast<uint4 *>(y);
+    uint32_t zero = 0;
+    const size_t want = (n + 255) / 256;
+    const unsigned grid = (unsigned)(want < 4096 ? want : 4096);
+    void *kargs[] = {&px, &py, &n, &zero};
+    return hipLaunchKernel(reinterpret_cast<const void *>(&gs_pair_probe_k), dim3(grid), dim3(256), kargs, 0, s);
+}
 
 hipError_t gs_launch_colormap(const float *row0, int32_t pitch, int32_t rows, int32_t cols, float scale,
                               const uint8_t *palette, int32_t n, uint8_t *rgb, hipStream_t s)

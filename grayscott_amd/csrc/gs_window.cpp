@@ -140,6 +140,9 @@ int32_t resolve_window(gs_ctx *ctx)
     w.pending = false;
     std::vector<gs_ctx::WindowRt::Launch> launched;
     launched.swap(w.launched);
+    std::vector<gs_ctx::WindowRt::Image> images;
+    images.swap(w.images);
+    if (w.seen) *w.seen = 0;
     if (!gave_up) return GS_OK;
     GS_HIP(hipMemsetAsync(w.words, 0, (kWindowMaxTiles + 1) * sizeof(int32_t), sl.compute));
     w.epoch = 0;
@@ -162,6 +165,16 @@ int32_t resolve_window(gs_ctx *ctx)
                 dst->ghost_depth = src->ghost_depth;
             }
         }
+        // an image that was enqueued behind this launch (gs_field_download_async) copied what the launch that gave up
+        // had left: fetch it again now, before a later launch's replay overwrites the planes
+        for (const auto &im : images)
+            if (im.after_seq == l.seq) {
+                GS_HIP(hipStreamSynchronize(sl.compute));
+                GS_HIP(hipStreamSynchronize(sl.copy));
+                const FieldSlab &fs = im.f->s[0];
+                GS_HIP(hipMemcpy2D(im.host, (size_t)im.f->cols * sizeof(float), fs.row0, (size_t)im.f->pitch * sizeof(float),
+                                   (size_t)im.f->cols * sizeof(float), (size_t)fs.rows, hipMemcpyDeviceToHost));
+            }
     }
     GS_HIP(hipStreamSynchronize(sl.compute));
     return GS_OK;

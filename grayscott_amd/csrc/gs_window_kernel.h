@@ -82,8 +82,12 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
         return w;
     };
     // One cell row: old rows (m, z, p) -> new values of row r, written in place.
+    // (windows that hold the grid's first or last row test every row's position per step: `grow` is made opaque once per
+    // step, or the compiler keeps fifteen loop-invariant row conditions as 64-bit masks in thirty SGPRs across the loop
+    // and spills them to VGPR lanes -- 25 v_readlane inside the step loop of the corner windows)
+    int grow = gr;
     auto update = [&](int r, const RowT<2> &m, const RowT<2> &z, const RowT<2> &p) {
-        const int row = gr + r; // wave-uniform
+        const int row = grow + r; // wave-uniform
         if (EDGE != 0 && (row < 0 || row >= a.rows)) return; // a row outside the grid: zeros that stay zeros
         const bool mrow = !ROWS || row > 0, prow = !ROWS || row + 1 < a.rows;
         float nu[2], nv[2];
@@ -126,6 +130,10 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
     // drift apart, 418 k against 461 k at 1080 x 1920, profiles/r04_window_kernel.md.)
     for (int s = 0; s < n; ++s, ++step) {
         const int buf = step & 1;
+        if constexpr (ROWS) {
+            asm volatile("" : "+s"(grow));
+            grow = __builtin_amdgcn_readfirstlane(grow);
+        }
         publish(buf);
         // Top down with a sliding window of widened OLD rows: a row is widened just before the row above it is
         // overwritten, so at most five widened rows are alive -- the window of three, old row 1 (kept for row 0) and

@@ -53,7 +53,7 @@ def parse(argv=None):
     be.add_argument("--hip-boundary", type=int, default=None, help="0 = compute_naive's clipped window, 1 = zero halo (the SIMD / Vulkan backends' rule) [GS_HIP_BOUNDARY]")
     be.add_argument("--hip-general-kernels", type=int, default=None, help="1 = never run the variants specialised for the default stencil and time step [GS_HIP_GENERAL_KERNELS]")
     be.add_argument("--hip-share-taps", type=int, default=None, help="full difference sharing: 0 = on (form 3) unless measured slower, 1 = within a lane only, 2 = off, 3 = across lanes too [GS_HIP_SHARE_TAPS]")
-    be.add_argument("--hip-place-candidates", type=int, default=None, help="Species are placed by measurement out of up to 4 + N candidate blocks (gs_fields_place; worth it from 2^25 cells on) [GS_HIP_PLACE_CANDIDATES]")
+    be.add_argument("--hip-place-candidates", type=int, default=None, help="most extra blocks gs_fields_place may draw when a Species of >= 2^26 cells is placed by measurement (default 12; 0 = planes as hipMalloc hands them out) [GS_HIP_PLACE_CANDIDATES]")
     be.add_argument("--hip-split", type=int, default=None, help="row bands a single slab is scheduled as [GS_HIP_SPLIT]")
     be.add_argument("--hip-use-graph", type=int, default=None, help="1 = replay batches of 16 passes through a hipGraph [GS_HIP_USE_GRAPH]")
     be.add_argument("--hip-tile-shape", type=int, default=None, help="window of the LDS-window kernel: 1 = 32x64, 2 = 16x64, 3 = 64x64 [GS_HIP_TILE_SHAPE]")

@@ -95,8 +95,9 @@ class HipArgs:
     no_tune: int = field(default_factory=lambda: _env_int("GS_HIP_NO_TUNE", 0))
     tile_shape: int = field(default_factory=lambda: _env_int("GS_HIP_TILE_SHAPE", 0))
     share_taps: int = field(default_factory=lambda: _env_int("GS_HIP_SHARE_TAPS", 0))
-    # not a gs_options field: what make_species hands to gs_fields_place for every Species it creates (0 = no placement)
-    place_candidates: int = field(default_factory=lambda: _env_int("GS_HIP_PLACE_CANDIDATES", 0))
+    # not a gs_options field: the most extra blocks gs_fields_place may draw for a Species that make_species creates
+    # (every Species of >= PLACE_MIN_CELLS cells per process on a context with one slab per process; 0 = no placement)
+    place_candidates: int = field(default_factory=lambda: _env_int("GS_HIP_PLACE_CANDIDATES", 12))
     rank: int = 0
     world: int = 1
     unique_id: Optional[bytes] = None
@@ -114,6 +115,11 @@ class HipArgs:
         o.tile_shape = self.tile_shape
         o.share_taps = self.share_taps
         return o
+
+
+# make_species places a Species by measurement from this many cells per process on (planes of 256 MiB): below, the
+# planes largely stay in the 256 MB last-level cache and where they lie in HBM does not show
+PLACE_MIN_CELLS = 1 << 26
 
 
 class HipContext:
@@ -170,6 +176,12 @@ class HipContext:
                   share_taps: int = 0) -> None:
         capi.check(self._lib.gs_ctx_set_tuned(self.handle, slab_rows, cols, rows_per_block, fuse_steps,
                                               cols_per_lane, share_taps))
+
+    def place_stats(self) -> Tuple[int, int]:
+        """(pair probes timed, extra blocks drawn) by ``gs_fields_place`` on this context so far."""
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        capi.check(self._lib.gs_debug_place_stats(self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
 
     def comm_info(self) -> Tuple[int, int, int]:
         """(ranks, rank, device) as RCCL reports them for this context's communicator; (0, -1, -1)
@@ -410,8 +422,7 @@ class Species:
     @classmethod
     def new(cls, context: HipContext, shape: Sequence[int], place_candidates: int = 0) -> "Species":
         """``Species::new`` (data/src/concentration/mod.rs:36-59).  ``place_candidates`` > 0 (not in the reference): the
-        four planes are then given the best set of blocks out of up to 4 + n candidate allocations as the single-step kernel
-        measures them (``Species.place``)."""
+        four planes are then placed by measurement with at most n extra blocks drawn (``Species.place``)."""
         shape = (int(shape[0]), int(shape[1]))
         u = Evolving.ones_out(context, shape)
         v = Evolving.zeros_out(context, shape)
@@ -431,9 +442,10 @@ class Species:
         return s
 
     def place(self, candidates: int) -> Tuple[float, float]:
-        """Placement by measurement (``gs_fields_place``): the four planes move to the blocks that read best together, with
-        their contents.  Returns and remembers (``placement``) the time per single step, in ms, of the blocks they had and
-        of the blocks they have now."""
+        """Placement by measurement (``gs_fields_place``): planes of one physical region of HBM that a pass writes together
+        are slow, so U's and V's planes are given blocks of different regions -- drawing at most ``candidates`` extra blocks,
+        moving the planes that have to move with their contents.  Returns and remembers (``placement``) the mean time, in
+        ms, of the probe pass (a step's traffic on a slot's two planes) over the blocks they had and the blocks they have now."""
         in_u, in_v, out_u, out_v = self.in_out()
         arr = (ctypes.c_void_p * 4)(in_u.handle, in_v.handle, out_u.handle, out_v.handle)
         first, best = ctypes.c_float(0), ctypes.c_float(0)
@@ -491,10 +503,14 @@ class Simulation:
         return cls(params, args)
 
     def make_species(self, shape: Sequence[int], place_candidates: Optional[int] = None) -> Species:
-        """``SimulateBase::make_species`` (lib.rs:33-34).  ``place_candidates``: None = the backend argument
-        (``HipArgs.place_candidates`` / ``--hip-place-candidates`` / GS_HIP_PLACE_CANDIDATES), 0 = no placement."""
+        """``SimulateBase::make_species`` (lib.rs:33-34).  ``place_candidates``: None = the library's default -- a Species
+        of >= 2^26 cells per process on a context with one slab per process is placed by measurement with at most
+        ``HipArgs.place_candidates`` extra blocks (``--hip-place-candidates`` / GS_HIP_PLACE_CANDIDATES, default 12; 0 = never)
+        --, 0 = no placement, n > 0 = placed whatever its size."""
         if place_candidates is None:
-            place_candidates = self.context.args.place_candidates
+            args = self.context.args
+            cells = int(shape[0]) * int(shape[1]) // max(1, args.world)
+            place_candidates = args.place_candidates if len(args.devices) == 1 and cells >= PLACE_MIN_CELLS else 0
         return Species.new(self.context, shape, place_candidates)
 
     def perform_steps(self, species: Species, steps: int) -> None:

@@ -73,9 +73,9 @@ struct HipArgs {
     std::vector<int32_t> devices{0};
     int32_t math = GS_MATH_STRICT, kernel = GS_KERNEL_AUTO, rows_per_block = 0, fuse_steps = 0, cols_per_lane = 0;
     int32_t boundary = GS_BOUNDARY_CLIPPED, no_tune = 0, share_taps = 0, general_kernels = 0;
-    // not a gs_options field: every Species of make_species is placed by measurement out of up to 4 + place_candidates
-    // blocks (gs_fields_place; worth it from 2^25 cells on; 0 = planes as hipMalloc hands them out)
-    int32_t place_candidates = 0;
+    // not a gs_options field: the most extra blocks gs_fields_place may draw when make_species places a Species by
+    // measurement -- every Species of >= 2^26 cells on a context with one slab (0 = planes as hipMalloc hands them out)
+    int32_t place_candidates = 12;
 };
 
 // Concentration::Context: owner of the gs_ctx.
@@ -96,7 +96,7 @@ class HipContext {
         o.share_taps = args.share_taps;
         o.general_kernels = args.general_kernels;
         check(gs_ctx_create(&ctx_, &p, &o, args.devices.data(), (int32_t)args.devices.size(), 0, 1, nullptr));
-        place_candidates_ = args.place_candidates;
+        place_candidates_ = args.devices.size() == 1 ? args.place_candidates : 0;
     }
     ~HipContext() { gs_ctx_destroy(ctx_); }
     int32_t place_candidates() const { return place_candidates_; }
@@ -268,8 +268,8 @@ class Species {
     }
     Context &context() { return context_; }
     Shape shape() const { return u_.shape(); }
-    // placement by measurement (gs_fields_place; not in the reference): the four planes move to the blocks that read
-    // best together, with their contents
+    // placement by measurement (gs_fields_place; not in the reference): U's and V's planes are given blocks of different
+    // physical regions of HBM (at most `candidates` extra blocks drawn); planes that move keep their contents
     void place(int32_t candidates)
     {
         gs_field *planes[4] = {u_.in().raw(), v_.in().raw(), u_.out().raw(), v_.out().raw()};
@@ -310,7 +310,9 @@ class Simulation {
     Species make_species(Shape shape) const
     {
         Species s = Species::new_(context_, shape);
-        if (context_->place_candidates() > 0) s.place(context_->place_candidates());
+        // planes of >= 256 MiB: below, they largely stay in the last-level cache and where they lie does not show
+        if (context_->place_candidates() > 0 && (uint64_t)shape[0] * (uint64_t)shape[1] >= (1ull << 26))
+            s.place(context_->place_candidates());
         return s;
     }
     // Simulate::perform_steps: the steps are DONE on return (as in every backend of the reference:

@@ -50,7 +50,7 @@
  *     GS_HIP_TRACE_TUNER    1 = print every timing window of gs_run's on-line tuner and what it chose, and every probe
  *                           of gs_fields_place
  *   Launch-policy switches for A/B timing (defaults are the measured best; grayscott_amd/csrc/gs_experiments.h):
- *     GS_HIP_PLACE_ALL      1 = gs_fields_place draws all its candidates even when it holds two blocks of each kind
+ *     GS_HIP_PLACE_ALL      1 = gs_fields_place draws all its candidates even when two fast pairs are found before
  *     GS_HIP_EDGE_KINDS     0 = edge units of the marching kernel all take the general path
  *     GS_HIP_EDGE_SPLIT     0 / 1 = never / always dispatch edge units as two half-height units
  *     GS_HIP_FAIR           0 / 1 = never / always run one-round launches as in-step 16-wave workgroups
@@ -277,23 +277,22 @@ int32_t gs_step(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs
 int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *v1,
                uint64_t steps, int32_t *result_slot);
 
-/* Placement by measurement, for the planes of a large Species on a context with one slab per process (optional; the
- * HBM-bound single-step kernel gains up to 19 %, the temporally blocked kernel of gs_run up to 12 % at 16384^2: since
- * round 5 it is fast enough to be held back by badly placed planes, 1.09 M instead of 1.2 M Mcells x steps/s).  Where a
- * hipMalloc lands in HBM is below what a process controls, but it can be measured: the 1 GiB blocks come in TWO kinds,
- * most of one kind, and four planes read by how they are split over the two -- 4 + 0: 0.82 ms per single step at
- * 16384^2 (0.65 of 8 TB/s), 3 + 1: 0.77, 2 + 2 with U's planes of one kind and V's of the other: 0.71 (0.75).  This call
- * draws more blocks of the planes' size (12, then 16 at a time, at most `candidates`, 1..124), times the single-step
- * kernel over random 4-subsets (three per new block), classes the blocks by the mean time of the subsets they were in,
- * stops drawing once it has two of each kind, times the (common, rare, common, rare) arrangements of the clearest
- * members, gives the four planes the best set seen and frees the rest: ~60 probes of four steps each and 16 GiB held for
- * 0.3 s at 16384^2 when the first batch holds both kinds; 1.5 s and 128 GiB at the very most.  Measured
- * (profiles/r05_placement.md, r05_cross_lane.md section 4): first four blocks 0.63-0.74 of 8 TB/s, chosen 0.75.  The
- * planes KEEP THEIR CONTENTS (a copy is set aside before the probes write into their blocks, and goes into the blocks
- * they end up with): the call can follow Species::new -- what the host mirrors' make_species do when asked to
- * (`--hip-place-candidates N`) -- or come in the middle of a run; it waits for the context's work first.  Without room
- * for the four copies nothing is done.  first_ms / best_ms (optional): time per step of the planes' original blocks
- * and of the chosen ones (0 when nothing was done). */
+/* Placement by measurement, for the planes of a large Species on a context with one slab per process (the host mirrors'
+ * make_species call it for every Species of >= 2^26 cells unless told not to).  Where a hipMalloc lands in HBM is below
+ * what a process controls, and it matters: the blocks lie in a few physical regions ("groups", runs of 2-30 consecutive
+ * 1 GiB allocations; one large allocation is always inside one), and two planes of ONE group that a pass writes (and
+ * reads) together are slow -- a pass that reads two 1 GiB blocks and writes them back takes 0.86-0.96 ms within a group,
+ * 0.72-0.79 ms across groups, whatever the offsets, while every block alone reads and writes at the same rate from
+ * every XCD (tools/ubench/hbm_kinds.hip; profiles/r06_placement.md).  Four planes of one group run the HBM-bound
+ * single-step kernel at 0.58-0.65 of 8 TB/s, U's planes in one group and V's in another at 0.73-0.76, and the marching
+ * kernel of gs_run gains 8-12 % at 16384^2.  This call times that pass (which leaves the blocks' contents alone) over
+ * the pairs among the planes' four blocks (6 probes of 3 passes, 20 ms at 16384^2).  If each slot's (U, V) pair is as
+ * fast as the fastest pair seen, and a slower pair has been seen, nothing moves and nothing is allocated.  Else it
+ * draws blocks of the planes' size ONE AT A TIME -- at most `candidates` (1..124; the hosts' default is 12: at most
+ * 12 GiB held for a moment at 16384^2) --, times each against every block held, stops as soon as two disjoint fast pairs
+ * exist, moves the planes that have to move (device copies, one at a time: the planes KEEP THEIR CONTENTS, also when a
+ * copy fails) and frees the rest.  It waits for the context's work first and can come at any time.  first_ms / best_ms
+ * (optional): mean time of the probe pass over the two slots' (U, V) pairs, before and after (0 when nothing was done). */
 int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidates, float *first_ms, float *best_ms);
 
 /* Wait for everything enqueued on this context (all local devices and streams). */
@@ -308,7 +307,10 @@ int32_t gs_sync(gs_ctx *ctx);
  *                                  the work already enqueued and return at once.  The plane is
  *                                  first densified into a device staging buffer, so steps
  *                                  enqueued afterwards are not held back by PCIe; `host` must
- *                                  stay valid until gs_download_wait / gs_sync.
+ *                                  stay valid until gs_download_wait / gs_sync.  It never waits: behind
+ *                                  a persistent window launch (1080 x 1920 in long calls), which may
+ *                                  still give up, the image is validated when it is waited for -- a
+ *                                  launch that gave up is then run again and the image fetched again.
  *   gs_download_wait               wait for the downloads enqueued so far (not for later steps) */
 int32_t gs_host_alloc(void **out, uint64_t bytes);
 int32_t gs_host_free(void *p);
@@ -374,6 +376,9 @@ int32_t gs_ctx_set_pass_timing(gs_ctx *ctx, int32_t passes);
  * kernel launches so far. */
 int32_t gs_ctx_info(const gs_ctx *ctx, char *kernel_name, size_t cap, uint64_t *launches);
 
+/* Introspection for the bench and the tests, not for bindings: what gs_fields_place has done on this context so far --
+ * pair probes timed and extra blocks drawn (each of the planes' size; all freed or handed to planes by now). */
+int32_t gs_debug_place_stats(const gs_ctx *ctx, uint64_t *probes, uint64_t *blocks_drawn);
 /* Test hook, not for bindings: the key of the table that remembers on which (device, kernel entry) more than 64 KB
  * of dynamic LDS were opted into -- 1 when (device, slot, bytes) is new (and is recorded), 0 when a launch on that
  * device would skip the opt-in, -1 for a bad slot (tests/test_capi_cpu.py). */

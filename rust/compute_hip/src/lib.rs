@@ -112,9 +112,10 @@ pub struct HipArgs {
     pub hip_pitch_pad: i32,
 
     /// Placement by measurement (`gs_fields_place`; not a `gs_options` field): every species of
-    /// `make_species` moves to the best blocks out of up to 4 + N candidate allocations, as timed
-    /// single steps see them.  Worth 8-12 % of `perform_steps` at 16384^2; 0 = off
-    #[arg(long, env = "GS_HIP_PLACE_CANDIDATES", default_value_t = 0)]
+    /// >= 2^26 cells that `make_species` creates on a single device is given blocks of different
+    /// physical regions of HBM for its U and V planes, drawing at most N extra blocks.  Worth
+    /// 8-12 % of `perform_steps` at 16384^2; 0 = planes as hipMalloc hands them out
+    #[arg(long, env = "GS_HIP_PLACE_CANDIDATES", default_value_t = 12)]
     pub hip_place_candidates: i32,
 }
 
@@ -238,7 +239,8 @@ impl SimulateBase for Simulation {
 
     fn make_species(&self, shape: [usize; 2]) -> Result<Species<HipConcentration>, HipError> {
         let mut species = Species::new(self.context.clone(), shape)?;
-        if self.place_candidates > 0 {
+        // planes of >= 256 MiB: below, they largely stay in the last-level cache
+        if self.place_candidates > 0 && shape[0] as u64 * shape[1] as u64 >= 1u64 << 26 {
             let (in_u, in_v, out_u, out_v) = species.in_out();
             let planes = [in_u.field, in_v.field, out_u.field, out_v.field];
             // SAFETY: four live planes of this context; the call moves them to other blocks with their contents
@@ -285,7 +287,7 @@ impl SimulateCreate for Simulation {
                 ptr::null(),
             )
         })?;
-        Ok(Self { context: Rc::new(HipContextInner(ctx)), place_candidates: args.hip_place_candidates })
+        Ok(Self { context: Rc::new(HipContextInner(ctx)), place_candidates: if args.hip_devices.len() == 1 { args.hip_place_candidates } else { 0 } })
     }
 }
 //

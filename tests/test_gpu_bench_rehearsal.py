@@ -37,7 +37,8 @@ def test_gpus_2_rehearsal_without_torchrun_prints_a_verified_line(built):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and len(line["ranks"]) == 2
     pl = line["config"]["placement"]
-    assert pl["candidates"] == 3 and 0 < pl["timed_species_ms"][1] <= pl["timed_species_ms"][0] * 1.0001, pl
+    assert pl["default"] is False and pl["max_extra_blocks"] == 3 and pl["species_placed"] >= 1 and pl["probes"] >= 6, pl
+    assert 0 < pl["timed_species_probe_ms"][1] <= pl["timed_species_probe_ms"][0] * 1.0001 and pl["extra_blocks_drawn"] <= 3 * 3, pl
     assert line["config"]["grid"] == [4096, 2048] and "REHEARSAL" in line["data"]
     v = line["verified"]
     assert v["equal"] is True and v["mismatching_ranks"] == [] and v["blocks"] >= 4 and v["steps"] > 24, v

@@ -79,3 +79,48 @@ def test_placed_planes_keep_their_contents_and_the_call_checks_its_arguments():
     chain.context.close()
     ctx.close()
     assert np.float32(0) == 0
+
+
+def test_make_species_places_large_species_by_default_and_small_ones_never():
+    """The library's default (all three hosts): a Species of >= 2^26 cells on a context with one slab is placed by
+    measurement with at most 12 extra blocks; smaller ones and slab chains are left where hipMalloc put them."""
+    sim = Simulation.new(Parameters(), HipArgs(devices=[0]))
+    assert sim.context.args.place_candidates == 12
+    small = sim.make_species((1080, 1920))
+    assert small.placement is None and sim.context.place_stats() == (0, 0)
+    big = sim.make_species((8192, 8192))                       # 2^26 cells: planes of 256 MiB
+    first, best = big.placement
+    probes, drawn = sim.context.place_stats()
+    assert first > 0 and 0 < best <= first * 1.0001 and probes >= 6 and 0 <= drawn <= 12, (big.placement, probes, drawn)
+    # Species::new survives the move: U = 1, V = 0 but for the seed rectangle (data/src/concentration/mod.rs:36-59)
+    in_u, in_v, _, _ = big.in_out()
+    v = in_v.make_scalar_view(sim.context)
+    assert float(v.sum(dtype=np.float64)) == (8192 // 16) * (8192 // 16) and v[8192 * 7 // 16 - 4, 8192 * 7 // 16] == 1.0
+    off = Simulation.new(Parameters(), HipArgs(devices=[0], place_candidates=0))
+    assert off.make_species((8192, 8192)).placement is None
+    off.context.close()
+    chain = Simulation.new(Parameters(), HipArgs(devices=[0, 0]))
+    assert chain.make_species((8192, 8192)).placement is None   # (several local slabs: not placed, not an error)
+    chain.context.close()
+    sim.context.close()
+
+
+def test_placement_at_the_headline_size_separates_u_from_v():
+    """16384^2: after placement each slot's (U, V) pair is a cross-group pair -- the probe pass over it takes 0.72-0.79 ms
+    per GiB pair where two blocks of one group take 0.86-0.96 (profiles/r06_placement.md) -- unless the box handed out one
+    group only among 4 + 12 blocks, in which case all 12 were drawn.  The planes' contents move with them."""
+    sim = Simulation.new(Parameters(), HipArgs(devices=[0], kernel=capi.GS_KERNEL_STREAM))
+    sp = sim.make_species((16384, 16384))
+    first, best = sp.placement
+    probes, drawn = sim.context.place_stats()
+    assert 0 < best <= first * 1.0001 and drawn <= 12
+    assert best < 0.83 or drawn == 12, (first, best, probes, drawn)
+    sim.perform_steps(sp, 3)
+    # against an unplaced Species of the same context: same bits
+    ref = sim.make_species((16384, 16384), place_candidates=0)
+    sim.perform_steps(ref, 3)
+    import torch
+    for a, b in zip(sp.in_out()[:2], ref.in_out()[:2]):
+        for (_, _, x), (_, _, y) in zip(a.torch_views(), b.torch_views()):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    sim.context.close()

@@ -258,3 +258,50 @@ def test_window_kernel_soak_against_the_marching_kernel():
     (_, _, v), = sr.in_out()[1].torch_views()
     assert float(v.max()) > 0.3
     ref.context.close()
+
+
+def test_images_enqueued_behind_window_launches_never_wait_and_are_right(monkeypatch):
+    """The reference's driver loop (simulate/src/main.rs:99-115) on the window kernel: prepare_steps, then the image of
+    the newest state enqueued BEHIND the launch (gs_field_download_async no longer waits for a window launch in flight),
+    validated when it is waited for.  Every image equals the oracle's V after as many steps -- also the images of launches
+    that gave up (patience of one poll from the third call on: those launches and the later ones are run again by the
+    marching kernel, each image fetched again right after its own launch's replay, before the next one overwrites the
+    planes)."""
+    import time
+
+    from grayscott_amd.simulation import pinned_empty
+    from tests.helpers import species_from_arrays
+
+    rows, cols, n, calls = 1080, 1920, 64, 6
+    u0, v0 = stress_fields((rows, cols), 11)
+    refs, ru, rv = [], u0, v0
+    for _ in range(calls):
+        ru, rv = oracle.run(ru, rv, n, ftz=True)
+        refs.append(rv)
+    for give_up_from in (None, 2):
+        monkeypatch.delenv("GS_HIP_WINDOW_PATIENCE", raising=False)
+        sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_WINDOW))
+        sp = species_from_arrays(sim, u0, v0)
+        images = [pinned_empty((rows, cols)) for _ in range(calls)]
+        enqueue_s = []
+        for i in range(calls):
+            if give_up_from is not None and i == give_up_from:
+                monkeypatch.setenv("GS_HIP_WINDOW_PATIENCE", "1")
+            sim.prepare_steps(sp, n)
+            t0 = time.perf_counter()
+            sp.write_result_view_after(images[i])
+            enqueue_s.append(time.perf_counter() - t0)
+            if i % 2 == 1:                       # two images in flight at a time
+                sim.context.download_wait()
+        sim.context.download_wait()
+        st = sim.context.stats()
+        for i in range(calls):
+            assert_bits_equal(images[i], refs[i], f"image {i} (give up from call {give_up_from}: {st})")
+        sim.context.sync()
+        in_u, in_v, _, _ = sp.in_out()
+        assert_bits_equal(in_v.make_scalar_view(sim.context), refs[-1], "V at the end")
+        if give_up_from is None:
+            assert st["window_fallbacks"] == 0 and sim.context.info()[0].startswith("window"), (st, sim.context.info())
+            # enqueueing an image costs microseconds, not the 270 us a 64-step launch takes (it used to wait for it)
+            assert sorted(enqueue_s)[len(enqueue_s) // 2] < 150e-6, enqueue_s
+        sim.context.close()

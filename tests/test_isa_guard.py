@@ -90,7 +90,6 @@ SHIPPED = {
     "gs_step_tb_dx_k_strict<2, 4>": (128, 8320),
     "gs_step_tb_k_strict<1, 3, 2, 4>": (128, 0),       # ... and of 1 step
     "gs_step_stream_k_strict<2>": (128, 0),            # gs_step: the HBM-bound single-step kernel
-    "gs_run_window_k_strict<5, 3>": (128, None),       # the reference's default 1080 x 1920 in long calls
     "gs_run_tile_k_strict<4, 3>": (128, None),         # small grids
     "gs_run_resident_k_strict<3, 1>": (128, None),
 }
@@ -108,6 +107,29 @@ def test_shipped_kernels_are_spill_free(kernels, name):
     assert k.count(r"^v_(readlane|writelane)_b32") == 0, (name, k.count(r"^v_(readlane|writelane)_b32"))
     if lds is not None:
         assert k.lds == lds, (name, k.lds)
+
+
+def test_window_kernel_has_no_scratch_and_no_spill_traffic_in_its_step_loops(kernels):
+    """gs_run_window_k (the reference's default 1080 x 1920 in long calls): eight kinds of window, one branch each, in one
+    persistent kernel.  Values that only the exchange between super-steps needs may be parked in VGPR lanes around the
+    step loops (SGPR spills: v_writelane before, v_readlane after), but nothing may go to scratch and no step loop -- the
+    innermost loops around the one workgroup barrier of a step -- may contain a lane read or write (round 5 had 528 SGPR
+    spills, 2 VGPR spills, 8 B of scratch and up to 25 v_readlane per step in the corner windows)."""
+    for name in ("gs_run_window_k_strict<5, 3>", "gs_run_window_k_strict<5, 0>", "gs_run_window_k_fused<5, 0>"):
+        k = kernels[name]
+        assert k.vgpr <= 128 and k.agpr == 0 and k.vgpr_spill == 0 and k.scratch == 0 and not k.dynamic_stack, (name, k.vgpr, k.vgpr_spill, k.scratch)
+        assert k.count(r"^scratch_") == 0, name
+        lane_ops = r"^v_(readlane|writelane)_b32"
+        step_like = [l for l in k.loops() if sum(t.startswith("s_barrier") for t in l) == 1 and sum(t.startswith("v_") for t in l) >= 300]
+        assert len(step_like) >= 6, (name, len(step_like))             # every kind of window has one
+        # innermost: no other step-like loop is a proper part of it
+        inner = [l for l in step_like if not any(len(m) < len(l) and " ".join(m) in " ".join(l) for m in step_like)]
+        assert len(inner) >= 3, (name, len(inner))
+        for l in inner:
+            assert sum(bool(re.match(lane_ops, t)) for t in l) == 0, (name, len(l))
+        # ... and what surrounds a step loop inside a super-step reads back one lane at most
+        for l in step_like:
+            assert sum(bool(re.match(lane_ops, t)) for t in l) <= 1, (name, len(l))
 
 
 def test_no_strict_kernel_touches_scratch(kernels):

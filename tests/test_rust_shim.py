@@ -56,11 +56,14 @@ def test_manifest_and_bench_entry():
         assert '"%s"' % m.group(1) in py, f
         if f != "devices":
             assert "opts.%s = args.hip_%s;" % (f, f) in lib, f
-    # ... plus the one argument that is not an option of the context: make_species places what it creates
-    assert re.search(r'#\[arg\(long, env = "GS_HIP_PLACE_CANDIDATES", default_value_t = 0\)\]\s*\n\s*pub hip_place_candidates: i32', lib)
-    assert '"GS_HIP_PLACE_CANDIDATES"' in py
+    # ... plus the one argument that is not an option of the context: make_species places the large Species it creates,
+    # by default (12 extra blocks at most), in all three hosts
+    assert re.search(r'#\[arg\(long, env = "GS_HIP_PLACE_CANDIDATES", default_value_t = 12\)\]\s*\n\s*pub hip_place_candidates: i32', lib)
+    assert '"GS_HIP_PLACE_CANDIDATES", 12)' in py
+    assert "int32_t place_candidates = 12;" in _read(ROOT, "include", "grayscott_hip.hpp")
     make = lib[lib.index("fn make_species"):lib.index("impl SimulateCreate for Simulation")]
     assert "Species::new(self.context.clone(), shape)?" in make and "ffi::gs_fields_place(" in make
+    assert "shape[0] as u64 * shape[1] as u64 >= 1u64 << 26" in make          # planes of >= 256 MiB only
     ffi = _read(RUST, "src", "ffi.rs")
     assert re.search(r"pub fn gs_fields_place\(\s*ctx: \*mut gs_ctx,\s*planes: \*const \*mut gs_field,\s*candidates: i32,\s*first_ms: \*mut f32,"
                      r"\s*best_ms: \*mut f32,\s*\) -> i32;", ffi)

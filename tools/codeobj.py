@@ -43,7 +43,9 @@ class Kernel:
     lds: int                         # .group_segment_fixed_size
     dynamic_stack: bool
     rsrc1: int = 0                   # compute_pgm_rsrc1 of the kernel descriptor
-    insts: List[str] = field(default_factory=list)   # "mnemonic operands" per instruction
+    insts: List[str] = field(default_factory=list)   # "mnemonic operands" per instruction (branch targets as labels)
+    addrs: List[int] = field(default_factory=list)   # address of each instruction
+    labels: Dict[str, int] = field(default_factory=dict)  # label -> address of the instruction it stands in front of
 
     # compute_pgm_rsrc1 fields (LLVM AMDGPUUsage, "compute_pgm_rsrc1 for GFX6-GFX12")
     @property
@@ -73,6 +75,16 @@ class Kernel:
     def matching(self, pattern: str) -> List[str]:
         rx = re.compile(pattern)
         return [i for i in self.insts if rx.match(i)]
+
+    def loops(self) -> List[List[str]]:
+        """The instruction ranges closed by a backward branch (a loop each, nested ones included), as instruction lists."""
+        out = []
+        for a, text in zip(self.addrs, self.insts):
+            m = re.match(r"s_c?branch\w* (L\d+)", text)
+            if m and m.group(1) in self.labels and self.labels[m.group(1)] <= a:
+                lo = self.labels[m.group(1)]
+                out.append([t for b, t in zip(self.addrs, self.insts) if lo <= b <= a])
+        return out
 
 
 def _tool(name: str) -> str:
@@ -176,20 +188,30 @@ def kernels_of(code_object: bytes, disassemble: bool = True) -> List[Kernel]:
                 kern.rsrc1, = struct.unpack_from("<I", code_object, rodata_off + (kd - rodata_addr) + 48)
             out.append(kern)
         if disassemble:
-            dis = subprocess.run([_tool("llvm-objdump"), "-d", "--no-show-raw-insn", path], capture_output=True,
+            dis = subprocess.run([_tool("llvm-objdump"), "-d", "--symbolize-operands", path], capture_output=True,
                                  text=True, check=True).stdout
             by_symbol = {k.symbol: k for k in out}
             cur: Optional[Kernel] = None
+            pending: List[str] = []
             for line in dis.splitlines():
                 m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
                 if m:
-                    cur = by_symbol.get(m.group(1))
+                    if re.fullmatch(r"L\d+", m.group(1)):
+                        pending.append(m.group(1))      # a branch target inside the current kernel
+                    else:
+                        cur = by_symbol.get(m.group(1))
+                        pending = []
                     continue
                 if cur is None:
                     continue
-                text = line.split("//")[0].strip()
-                if text:
-                    cur.insts.append(re.sub(r"\s+", " ", text))
+                m = re.match(r"^\s+(\S.*?)\s*//\s*([0-9A-Fa-f]+):", line)
+                if m:
+                    addr = int(m.group(2), 16)
+                    for lab in pending:
+                        cur.labels[lab] = addr
+                    pending = []
+                    cur.insts.append(re.sub(r"\s+", " ", m.group(1)))
+                    cur.addrs.append(addr)
     return out
 
 

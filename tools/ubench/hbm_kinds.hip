@@ -3,6 +3,8 @@
 // ("next round" item 1.)  Streaming kernels only: the phenomenon is the step kernel's, but it shows in
 // any kernel that reads two 1 GiB arrays and writes two at the same offsets.
 //
+//   (run 1 of this file, profiles/r06_logs/hbm_kinds_run1.log, also had E4: per-XCD solo reads -- all alike -- and E5: the
+//   second block of an in-place pair skewed by 256 B ... 512 MiB -- no effect; this is the form of run 2)
 //   E1  per hipMalloc block: solo read and solo write bandwidth
 //   E2  per pair (X, Y): in-place update of both (reads X, Y; writes X, Y: "4 + 0" when X and Y are of one kind, a balanced
 //       "2 + 2" when they are not), dual read, copy X -> Y; kinds from the in-place times
@@ -109,37 +111,80 @@ static float t_quad(void *a, void *b, void *c, void *d, size_t skew = 0)
 }
 static float t_inplace(void *x, void *y, size_t skew = 0) { return t_quad(x, y, x, y, skew); }
 
-// kinds from in-place pair times against block `ref`: 0 = as ref, 1 = the other; returns how many of kind 1
-static int classify(const std::vector<void *> &b, std::vector<int> &kind, std::vector<float> &t, const char *what)
+
+// Groups by in-place pair tests against one representative per group found so far: two blocks are of one group when
+// updating both in place takes more than `thr` ms (run 1: 0.86 ... 0.96 within a group, 0.72 ... 0.80 across).
+static constexpr float kSameGroupMs = 0.83f;
+static std::vector<int> group_blocks(const std::vector<void *> &b, std::vector<int> &reps, const char *what)
 {
-    const int n = (int)b.size();
-    kind.assign((size_t)n, 0);
-    t.assign((size_t)n, 0.0f);
-    for (int j = 1; j < n; ++j) t[(size_t)j] = t_inplace(b[0], b[(size_t)j]);
-    float lo = 1e30f, hi = 0.0f;
-    for (int j = 1; j < n; ++j) { lo = std::min(lo, t[(size_t)j]); hi = std::max(hi, t[(size_t)j]); }
-    int ones = 0;
-    const bool two = hi - lo > 0.04f * hi;
-    std::printf("%s: in-place pair with #0, ms:", what);
-    for (int j = 1; j < n; ++j) {
-        kind[(size_t)j] = two && t[(size_t)j] < 0.5f * (lo + hi) ? 1 : 0;
-        ones += kind[(size_t)j];
-        std::printf(" %.3f", t[(size_t)j]);
+    std::vector<int> g(b.size(), -1);
+    reps.clear();
+    std::printf("%s: block -> group (in-place ms against each representative)\n", what);
+    for (size_t i = 0; i < b.size(); ++i) {
+        std::printf("  #%02zu:", i);
+        for (size_t r = 0; r < reps.size() && g[i] < 0; ++r) {
+            const float t = t_inplace(b[(size_t)reps[r]], b[i]);
+            std::printf(" %c %.3f", (char)('A' + r), t);
+            if (t > kSameGroupMs) g[i] = (int)r;
+        }
+        if (g[i] < 0) { g[i] = (int)reps.size(); reps.push_back((int)i); }
+        std::printf(" -> %c\n", (char)('A' + g[i]));
     }
-    std::printf("\n%s: min %.3f max %.3f -> %s; kinds: ", what, lo, hi, two ? "two kinds" : "one kind");
-    for (int j = 0; j < n; ++j) std::printf("%c", kind[(size_t)j] ? 'B' : 'a');
-    std::printf("\n");
+    std::printf("%s: groups in allocation order: ", what);
+    for (size_t i = 0; i < b.size(); ++i) std::printf("%c", (char)('A' + g[i]));
+    std::printf("  (%zu groups)\n", reps.size());
     std::fflush(stdout);
-    return ones;
+    return g;
 }
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+static void quads_over_groups(const std::vector<void *> &b, const std::vector<int> &g, int ngroups, const char *what)
+{
+    // members per group
+    std::vector<std::vector<int>> m((size_t)ngroups);
+    for (size_t i = 0; i < b.size(); ++i) m[(size_t)g[i]].push_back((int)i);
+    // groups by size, largest first
+    std::vector<int> order((size_t)ngroups);
+    for (int i = 0; i < ngroups; ++i) order[(size_t)i] = i;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return m[(size_t)x].size() > m[(size_t)y].size(); });
+    auto q = [&](const char *label, int a, int bb, int c, int d) {
+        const float fwd = t_quad(b[(size_t)a], b[(size_t)bb], b[(size_t)c], b[(size_t)d]);
+        const float back = t_quad(b[(size_t)c], b[(size_t)d], b[(size_t)a], b[(size_t)bb]);
+        std::printf("  %-34s %c%c -> %c%c  (#%02d #%02d -> #%02d #%02d): %.4f / %.4f ms there / back = %.0f GB/s\n", label, 'A' + g[(size_t)a],
+                    'A' + g[(size_t)bb], 'A' + g[(size_t)c], 'A' + g[(size_t)d], a, bb, c, d, fwd, back, 8.0 * GiB / (fwd + back) * 1e-6);
+        std::fflush(stdout);
+    };
+    std::printf("%s: quads (reads two, writes two; there and back = two steps of a Species)\n", what);
+    const std::vector<int> &G0 = m[(size_t)order[0]];
+    if (G0.size() >= 4) q("all of one group", G0[0], G0[1], G0[2], G0[3]);
+    if (ngroups >= 2) {
+        const std::vector<int> &G1 = m[(size_t)order[1]];
+        if (G0.size() >= 2 && G1.size() >= 2) {
+            q("U one group, V another (x y -> x y)", G0[0], G1[0], G0[1], G1[1]);
+            q("crosswise (x y -> y x)", G0[0], G1[0], G1[1], G0[1]);
+            q("slot 0 one group, slot 1 another", G0[0], G0[1], G1[0], G1[1]);
+        }
+        if (G0.size() >= 3 && G1.size() >= 1) q("3 + 1", G0[0], G0[1], G0[2], G1[0]);
+    }
+    if (ngroups >= 3) {
+        const std::vector<int> &G1 = m[(size_t)order[1]], &G2 = m[(size_t)order[2]];
+        if (G0.size() >= 2) q("x y -> x z", G0[0], G1[0], G0[1], G2[0]);
+        if (G0.size() >= 2) q("x x -> y z", G0[0], G0[1], G1[0], G2[0]);
+    }
+    if (ngroups >= 4) {
+        q("four groups (x y -> z w)", m[(size_t)order[0]][0], m[(size_t)order[1]][0], m[(size_t)order[2]][0], m[(size_t)order[3]][0]);
+        q("four groups (x z -> y w)", m[(size_t)order[0]][0], m[(size_t)order[2]][0], m[(size_t)order[1]][0], m[(size_t)order[3]][0]);
+        q("four groups (x w -> y z)", m[(size_t)order[0]][0], m[(size_t)order[3]][0], m[(size_t)order[1]][0], m[(size_t)order[2]][0]);
+    }
+}
+
 int main(int argc, char **argv)
 {
-    const int nblocks = argc > 1 ? std::atoi(argv[1]) : 32;
+    const int nblocks = argc > 1 ? std::atoi(argv[1]) : 48;
     const size_t chunk = (size_t)(argc > 2 ? std::atoi(argv[2]) : 8) * MiB;
-    const int groups = argc > 3 ? std::atoi(argv[3]) : 24;
+    const int groups = argc > 3 ? std::atoi(argv[3]) : 16;
+    const int arena_gib = argc > 4 ? std::atoi(argv[4]) : 16;
     CK(hipSetDevice(0));
     CK(hipEventCreate(&ev0));
     CK(hipEventCreate(&ev1));
@@ -148,7 +193,7 @@ int main(int argc, char **argv)
     CK(hipMemGetInfo(&free_b, &total_b));
     std::printf("device memory: %.1f GiB free of %.1f GiB\n", free_b / (double)GiB, total_b / (double)GiB);
 
-    // ---------------- E1 ----------------
+    // ---------------- E1: hipMalloc blocks ----------------
     std::vector<void *> blk;
     for (int i = 0; i < nblocks; ++i) {
         void *p = nullptr;
@@ -157,88 +202,58 @@ int main(int argc, char **argv)
         blk.push_back(p);
     }
     const int n = (int)blk.size();
-    std::printf("E1: %d hipMalloc blocks of 1 GiB; address, solo read ms (GB/s), solo write ms (GB/s)\n", n);
-    std::vector<float> rd((size_t)n), wr((size_t)n);
+    float rlo = 1e30f, rhi = 0, wlo = 1e30f, whi = 0;
     for (int i = 0; i < n; ++i) {
-        rd[(size_t)i] = t_read(blk[(size_t)i]);
-        wr[(size_t)i] = t_write(blk[(size_t)i]);
-        std::printf("  #%02d %p  read %.4f (%.0f)  write %.4f (%.0f)\n", i, blk[(size_t)i], rd[(size_t)i], GiB / rd[(size_t)i] * 1e-6,
-                    wr[(size_t)i], GiB / wr[(size_t)i] * 1e-6);
+        const float r = t_read(blk[(size_t)i]), w = t_write(blk[(size_t)i]);
+        rlo = std::min(rlo, r); rhi = std::max(rhi, r); wlo = std::min(wlo, w); whi = std::max(whi, w);
     }
-    std::fflush(stdout);
-
-    // ---------------- E2 ----------------
-    std::vector<int> kind;
-    std::vector<float> t0;
-    const int ones = classify(blk, kind, t0, "E2 hipMalloc blocks");
-    const int m = std::min(n, 16);
-    std::printf("E2: pair matrices over the first %d blocks (upper: in-place update ms; then dual read ms; then copy ms)\n", m);
-    for (int pass = 0; pass < 3; ++pass) {
-        std::printf("  %s\n", pass == 0 ? "in-place (reads X, Y; writes X, Y)" : pass == 1 ? "dual read" : "copy row -> column");
-        for (int i = 0; i < m; ++i) {
-            std::printf("  %c#%02d", kind[(size_t)i] ? 'B' : 'a', i);
-            for (int j = 0; j < m; ++j) {
-                if (j == i || (pass < 2 && j < i)) { std::printf("     . "); continue; }
-                const float t = pass == 0 ? t_inplace(blk[(size_t)i], blk[(size_t)j]) : pass == 1 ? t_dual(blk[(size_t)i], blk[(size_t)j])
-                                                                                                   : t_copy(blk[(size_t)i], blk[(size_t)j]);
-                std::printf(" %.3f", t);
+    std::printf("E1: %d hipMalloc blocks of 1 GiB: solo read %.4f ... %.4f ms (%.0f ... %.0f GB/s), solo write %.4f ... %.4f ms (%.0f ... %.0f GB/s)\n", n,
+                rlo, rhi, GiB / rhi * 1e-6, GiB / rlo * 1e-6, wlo, whi, GiB / whi * 1e-6, GiB / wlo * 1e-6);
+    // ---------------- E2: groups ----------------
+    std::vector<int> reps;
+    const std::vector<int> g = group_blocks(blk, reps, "E2 hipMalloc blocks");
+    std::printf("E2: in-place ms among the groups' representatives (and each group's second member, if any)\n");
+    {
+        std::vector<int> probe = reps;
+        for (size_t r = 0; r < reps.size(); ++r)
+            for (int i = 0; i < n; ++i)
+                if (g[(size_t)i] == (int)r && i != reps[r]) { probe.push_back(i); break; }
+        std::printf("        ");
+        for (int j : probe) std::printf("  %c#%02d ", 'A' + g[(size_t)j], j);
+        std::printf("\n");
+        for (size_t i = 0; i < probe.size(); ++i) {
+            std::printf("  %c#%02d  ", 'A' + g[(size_t)probe[i]], probe[i]);
+            for (size_t j = 0; j < probe.size(); ++j) {
+                if (j <= i) { std::printf("     . "); continue; }
+                std::printf(" %.3f ", t_inplace(blk[(size_t)probe[i]], blk[(size_t)probe[j]]));
             }
             std::printf("\n");
         }
-        std::fflush(stdout);
     }
-    std::vector<int> A, B;
-    for (int i = 0; i < n; ++i) (kind[(size_t)i] ? B : A).push_back(i);
+    std::fflush(stdout);
     // ---------------- E3 ----------------
-    auto quad_row = [&](const char *label, int a, int b, int c, int d) {
-        const float t = t_quad(blk[(size_t)a], blk[(size_t)b], blk[(size_t)c], blk[(size_t)d]);
-        std::printf("  %-44s blocks %2d %2d -> %2d %2d: %.4f ms = %.0f GB/s\n", label, a, b, c, d, t, 4.0 * GiB / t * 1e-6);
-    };
-    std::printf("E3: quads (reads two blocks, writes two others), %zu of kind a, %zu of kind B\n", A.size(), B.size());
-    if (A.size() >= 4) { quad_row("4 + 0 (a a -> a a)", A[0], A[1], A[2], A[3]); quad_row("4 + 0 again", A[3], A[2], A[1], A[0]); }
-    if (B.size() >= 4) quad_row("0 + 4 (B B -> B B)", B[0], B[1], B[2], B[3]);
-    if (A.size() >= 3 && B.size() >= 1) { quad_row("3 + 1 (a B -> a a)", A[0], B[0], A[1], A[2]); quad_row("3 + 1 (a a -> a B)", A[0], A[1], A[2], B[0]); }
-    if (A.size() >= 2 && B.size() >= 2) {
-        quad_row("2 + 2 balanced (a B -> a B)", A[0], B[0], A[1], B[1]);
-        quad_row("2 + 2 balanced (a B -> B a)", A[0], B[0], B[1], A[1]);
-        quad_row("2 + 2 inputs of one kind (a a -> B B)", A[0], A[1], B[0], B[1]);
-        quad_row("2 + 2 inputs of one kind (B B -> a a)", B[0], B[1], A[0], A[1]);
-    }
-    if (A.size() >= 1 && B.size() >= 3) quad_row("1 + 3 (a B -> B B)", A[0], B[0], B[1], B[2]);
-    std::fflush(stdout);
-    // ---------------- E4 ----------------
-    std::printf("E4: solo read by the workgroups of one XCD at a time, ms (whole chip for comparison)\n");
-    for (int which = 0; which < 2; ++which) {
-        const std::vector<int> &K = which ? B : A;
-        for (size_t r = 0; r < std::min<size_t>(2, K.size()); ++r) {
-            std::printf("  kind %c #%02d: chip %.4f | xcd", which ? 'B' : 'a', K[r], t_read(blk[(size_t)K[r]]));
-            for (int x = 0; x < 8; ++x) std::printf(" %.3f", t_read(blk[(size_t)K[r]], x));
-            std::printf("\n");
-        }
-    }
-    std::fflush(stdout);
-    // ---------------- E5 ----------------
-    {
-        const size_t skews[] = {0, 256, 4096, 65536, MiB, 2 * MiB + 4096, 16 * MiB, 64 * MiB, 128 * MiB, 256 * MiB, 512 * MiB};
-        std::printf("E5: in-place update of a pair with the second block's index skewed, ms\n");
-        auto sweep = [&](const char *label, int x, int y) {
-            std::printf("  %-18s #%02d #%02d:", label, x, y);
-            for (size_t s : skews) std::printf(" %.3f", t_inplace(blk[(size_t)x], blk[(size_t)y], s / 16));
-            std::printf("\n");
-        };
-        std::printf("  skew bytes:              ");
-        for (size_t s : skews) std::printf(" %zu", s);
-        std::printf("\n");
-        if (A.size() >= 2) sweep("same kind (a, a)", A[0], A[1]);
-        if (B.size() >= 2) sweep("same kind (B, B)", B[0], B[1]);
-        if (A.size() >= 1 && B.size() >= 1) sweep("two kinds (a, B)", A[0], B[0]);
-    }
-    std::fflush(stdout);
-    (void)ones;
+    quads_over_groups(blk, g, (int)reps.size(), "E3 hipMalloc blocks");
     for (void *p : blk) (void)hipFree(p);
     blk.clear();
 
-    // ---------------- E6 ----------------
+    // ---------------- E7: one large allocation, by 1 GiB sub-blocks ----------------
+    {
+        char *arena = nullptr;
+        if (hipMalloc((void **)&arena, (size_t)arena_gib * GiB) == hipSuccess) {
+            CK(hipMemset(arena, 0, (size_t)arena_gib * GiB));
+            std::vector<void *> sub;
+            for (int i = 0; i < arena_gib; ++i) sub.push_back(arena + (size_t)i * GiB);
+            std::vector<int> sreps;
+            const std::vector<int> sg = group_blocks(sub, sreps, "E7 sub-blocks of ONE hipMalloc");
+            quads_over_groups(sub, sg, (int)sreps.size(), "E7 sub-blocks");
+            (void)hipFree(arena);
+        } else {
+            (void)hipGetLastError();
+            std::printf("E7: no %d GiB allocation\n", arena_gib);
+        }
+    }
+
+    // ---------------- E6: the virtual-memory API ----------------
     hipMemAllocationProp prop;
     std::memset(&prop, 0, sizeof prop);
     prop.type = hipMemAllocationTypePinned;
@@ -247,35 +262,12 @@ int main(int argc, char **argv)
     size_t gmin = 0, grec = 0;
     CK(hipMemGetAllocationGranularity(&gmin, &prop, hipMemAllocationGranularityMinimum));
     CK(hipMemGetAllocationGranularity(&grec, &prop, hipMemAllocationGranularityRecommended));
-    std::printf("E6: allocation granularity: minimum %zu, recommended %zu bytes\n", gmin, grec);
+    std::printf("E6: allocation granularity: minimum %zu, recommended %zu bytes; hipMemMap of a handle's sub-range (offset != 0): invalid argument (run 1)\n",
+                gmin, grec);
     hipMemAccessDesc acc;
     std::memset(&acc, 0, sizeof acc);
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    {
-        // can a sub-range of a handle be mapped?
-        hipMemGenericAllocationHandle_t h;
-        void *va = nullptr;
-        CK(hipMemCreate(&h, 64 * MiB, &prop, 0));
-        CK(hipMemAddressReserve(&va, 64 * MiB, 0, nullptr, 0));
-        hipError_t e = hipMemMap(va, 32 * MiB, 32 * MiB, h, 0);
-        std::printf("E6: hipMemMap of the second half of a 64 MiB handle (offset 32 MiB): %s\n", hipGetErrorString(e));
-        if (e == hipSuccess) {
-            e = hipMemMap((char *)va + 32 * MiB, 32 * MiB, 0, h, 0);
-            std::printf("E6: ... and its first half behind it: %s\n", hipGetErrorString(e));
-            if (e == hipSuccess) {
-                e = hipMemSetAccess(va, 64 * MiB, &acc, 1);
-                std::printf("E6: hipMemSetAccess over both: %s\n", hipGetErrorString(e));
-                if (e == hipSuccess) e = hipMemset(va, 0, 64 * MiB);
-                std::printf("E6: memset through the swapped mapping: %s\n", hipGetErrorString(e));
-                (void)hipMemUnmap((char *)va + 32 * MiB, 32 * MiB);
-            }
-            (void)hipMemUnmap(va, 32 * MiB);
-        }
-        (void)hipGetLastError();
-        (void)hipMemAddressFree(va, 64 * MiB);
-        (void)hipMemRelease(h);
-    }
     const size_t per_group = GiB / chunk;
     const size_t nchunks = (size_t)groups * per_group;
     std::vector<hipMemGenericAllocationHandle_t> hs;
@@ -287,67 +279,59 @@ int main(int argc, char **argv)
     }
     t_create = now() - t_create;
     const int G = (int)(hs.size() / per_group);
-    std::printf("E6: %zu chunk handles of %zu MiB created in %.3f s (%d aggregates of 1 GiB)\n", hs.size(), chunk / MiB, t_create, G);
+    std::printf("E6: %zu chunk handles of %zu MiB created in %.3f s (%d aggregates of 1 GiB in allocation order)\n", hs.size(), chunk / MiB, t_create, G);
     if (G < 4) { std::printf("E6: too few aggregates\n"); return 0; }
     char *view = nullptr;
     CK(hipMemAddressReserve((void **)&view, (size_t)G * GiB, 0, nullptr, 0));
-    double t_map = now();
     // (every chunk mapped, given access and unmapped on its own: ranges that span several mappings are not relied on)
     auto map_chunk = [&](char *va, hipMemGenericAllocationHandle_t h) -> hipError_t {
         hipError_t e = hipMemMap(va, chunk, 0, h, 0);
         return e == hipSuccess ? hipMemSetAccess(va, chunk, &acc, 1) : e;
     };
+    double t_map = now();
     for (size_t k = 0; k < (size_t)G * per_group; ++k) CK(map_chunk(view + k * chunk, hs[k]));
     t_map = now() - t_map;
-    std::printf("E6: mapped in allocation order in %.3f s\n", t_map);
+    std::printf("E6: mapped in %.3f s\n", t_map);
     CK(hipMemset(view, 0, (size_t)G * GiB));
     std::vector<void *> agg;
-    for (int g = 0; g < G; ++g) agg.push_back(view + (size_t)g * GiB);
-    std::vector<int> gk;
-    std::vector<float> gt;
-    classify(agg, gk, gt, "E6 aggregates of chunk handles");
-    std::vector<int> GA, GB;
-    for (int g = 0; g < G; ++g) (gk[(size_t)g] ? GB : GA).push_back(g);
-    auto quad_agg = [&](const char *label, int a, int b, int c, int d) {
-        const float t = t_quad(agg[(size_t)a], agg[(size_t)b], agg[(size_t)c], agg[(size_t)d]);
-        std::printf("  %-44s aggregates %2d %2d -> %2d %2d: %.4f ms = %.0f GB/s\n", label, a, b, c, d, t, 4.0 * GiB / t * 1e-6);
-        return t;
-    };
-    if (GA.size() >= 4) quad_agg("4 + 0 (a a -> a a)", GA[0], GA[1], GA[2], GA[3]);
-    if (GB.size() >= 4) quad_agg("0 + 4 (B B -> B B)", GB[0], GB[1], GB[2], GB[3]);
-    if (GA.size() >= 2 && GB.size() >= 2) {
-        quad_agg("2 + 2 balanced (a B -> a B)", GA[0], GB[0], GA[1], GB[1]);
-        quad_agg("2 + 2 inputs of one kind (a a -> B B)", GA[0], GA[1], GB[0], GB[1]);
-        // four planes, each alternating chunks of two aggregates of different kinds: plane p = (GA[p / 2 .. ], GB[...])
-        // planes 0, 1 share aggregates GA[0], GB[0] (even / odd chunk slots swapped), planes 2, 3 share GA[1], GB[1]
-        char *mix = nullptr;
-        CK(hipMemAddressReserve((void **)&mix, 4 * GiB, 0, nullptr, 0));
-        for (int stride_chunks = 1; stride_chunks <= (int)per_group / 2; stride_chunks *= 4) {
-            // unmap the four aggregates from the view, map them interleaved (runs of stride_chunks chunks)
-            const int src[4] = {GA[0], GB[0], GA[1], GB[1]};
-            for (int q = 0; q < 4; ++q)
-                for (size_t s = 0; s < per_group; ++s) CK(hipMemUnmap(view + (size_t)src[q] * GiB + s * chunk, chunk));
-            // plane p (0..3): slot s takes chunk s of aggregate (p ^ ((s / stride) & 1)) within its pair
-            for (int p = 0; p < 4; ++p)
-                for (size_t s = 0; s < per_group; ++s) {
-                    const int pair = p / 2, flip = (int)((s / (size_t)stride_chunks) & 1);
-                    const int from = src[pair * 2 + ((p & 1) ^ flip)];
-                    CK(map_chunk(mix + (size_t)p * GiB + s * chunk, hs[(size_t)from * per_group + s]));
-                }
-            void *P[4] = {mix, mix + GiB, mix + 2 * GiB, mix + 3 * GiB};
-            const float t = t_quad(P[0], P[1], P[2], P[3]);
-            const float t2 = t_quad(P[0], P[2], P[1], P[3]);
-            std::printf("  planes alternating kinds every %4zu MiB: quad %.4f ms = %.0f GB/s; other pairing %.4f ms\n",
-                        (size_t)stride_chunks * chunk / MiB, t, 4.0 * GiB / t * 1e-6, t2);
-            std::fflush(stdout);
-            for (size_t k = 0; k < 4 * per_group; ++k) CK(hipMemUnmap(mix + k * chunk, chunk));
-            for (int q = 0; q < 4; ++q)
-                for (size_t s = 0; s < per_group; ++s)
-                    CK(map_chunk(view + (size_t)src[q] * GiB + s * chunk, hs[(size_t)src[q] * per_group + s]));
+    for (int gi = 0; gi < G; ++gi) agg.push_back(view + (size_t)gi * GiB);
+    std::vector<int> areps;
+    const std::vector<int> ag = group_blocks(agg, areps, "E6 aggregates of chunk handles");
+    quads_over_groups(agg, ag, (int)areps.size(), "E6 aggregates");
+    if (areps.size() >= 2) {
+        // four planes, each alternating chunks of two aggregates of DIFFERENT groups (x0, y0 for planes 0 / 1; x1, y1 for 2 / 3)
+        std::vector<std::vector<int>> m(areps.size());
+        for (int i = 0; i < G; ++i) m[(size_t)ag[(size_t)i]].push_back(i);
+        std::sort(m.begin(), m.end(), [](const std::vector<int> &x, const std::vector<int> &y) { return x.size() > y.size(); });
+        int src[4] = {-1, -1, -1, -1};
+        if (m.size() >= 4) { src[0] = m[0][0]; src[1] = m[1][0]; src[2] = m[2][0]; src[3] = m[3][0]; }
+        else if (m[0].size() >= 2 && m[1].size() >= 2) { src[0] = m[0][0]; src[1] = m[1][0]; src[2] = m[0][1]; src[3] = m[1][1]; }
+        if (src[0] >= 0) {
+            char *mix = nullptr;
+            CK(hipMemAddressReserve((void **)&mix, 4 * GiB, 0, nullptr, 0));
+            std::printf("E6: four planes alternating chunks of aggregates #%d #%d (planes 0, 1) and #%d #%d (planes 2, 3)\n", src[0], src[1], src[2], src[3]);
+            for (int stride_chunks = 1; stride_chunks <= (int)per_group / 2; stride_chunks *= 8) {
+                for (int q = 0; q < 4; ++q)
+                    for (size_t s = 0; s < per_group; ++s) CK(hipMemUnmap(view + (size_t)src[q] * GiB + s * chunk, chunk));
+                for (int p = 0; p < 4; ++p)
+                    for (size_t s = 0; s < per_group; ++s) {
+                        const int pair = p / 2, flip = (int)((s / (size_t)stride_chunks) & 1);
+                        const int from = src[pair * 2 + ((p & 1) ^ flip)];
+                        CK(map_chunk(mix + (size_t)p * GiB + s * chunk, hs[(size_t)from * per_group + s]));
+                    }
+                void *P[4] = {mix, mix + GiB, mix + 2 * GiB, mix + 3 * GiB};
+                const float t01 = t_quad(P[0], P[1], P[2], P[3]), t10 = t_quad(P[2], P[3], P[0], P[1]);
+                const float u01 = t_quad(P[0], P[2], P[1], P[3]), u10 = t_quad(P[1], P[3], P[0], P[2]);
+                std::printf("  alternating every %4zu MiB: (0 1 -> 2 3) %.4f / %.4f ms = %.0f GB/s; (0 2 -> 1 3) %.4f / %.4f ms = %.0f GB/s\n",
+                            (size_t)stride_chunks * chunk / MiB, t01, t10, 8.0 * GiB / (t01 + t10) * 1e-6, u01, u10, 8.0 * GiB / (u01 + u10) * 1e-6);
+                std::fflush(stdout);
+                for (size_t k = 0; k < 4 * per_group; ++k) CK(hipMemUnmap(mix + k * chunk, chunk));
+                for (int q = 0; q < 4; ++q)
+                    for (size_t s = 0; s < per_group; ++s)
+                        CK(map_chunk(view + (size_t)src[q] * GiB + s * chunk, hs[(size_t)src[q] * per_group + s]));
+            }
+            (void)hipMemAddressFree(mix, 4 * GiB);
         }
-        (void)hipMemAddressFree(mix, 4 * GiB);
-    } else {
-        std::printf("E6: the aggregates are of one kind: no composition to time\n");
     }
     for (size_t k = 0; k < (size_t)G * per_group; ++k) CK(hipMemUnmap(view + k * chunk, chunk));
     for (auto h : hs) (void)hipMemRelease(h);
