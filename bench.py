@@ -88,10 +88,11 @@ def placement_report(ctx, species, sp_dev, place, slab_rows, cols):
     planes themselves at any moment (it draws one block of a plane's size at a time and frees what it does not keep)."""
     probes, drawn = ctx.place_stats()
     plane_gib = (slab_rows + 8) * ((cols + 63) // 64 * 64) * 4 / 2 ** 30
-    per_species = [sp.placement for sp in (species, sp_dev) if sp is not None and getattr(sp, "placement", None)]
+    placed = [sp for sp in (species, sp_dev) if sp is not None and getattr(sp, "placement", None)]
     return {"default": place is None, "max_extra_blocks": 12 if place is None else place,
-            "species_placed": len(per_species), "probes": probes, "extra_blocks_drawn": drawn,
-            "transient_GiB": round(min(drawn, 12 if place is None else place) * plane_gib, 2),
+            "species_placed": len(placed), "probes": probes, "extra_blocks_drawn": drawn,
+            "extra_blocks_drawn_per_species": [sp.placement_drawn for sp in placed],
+            "transient_GiB": round(max([sp.placement_drawn for sp in placed] or [0]) * plane_gib, 2),
             # (mean ms of the probe pass over the two slots' (U, V) pairs: before, after)
             "timed_species_probe_ms": getattr(species, "placement", None),
             "developed_species_probe_ms": getattr(sp_dev, "placement", None) if sp_dev is not None else None}
@@ -301,8 +302,12 @@ def main() -> int:
     pmc = measured_counters(kernel_name, int(rows // world), cols, tuned)
     valu_insts, valu_how = scaled_valu_insts(pmc, tuned)
 
-    def roofline_of(ms, n_passes):
-        return roofline_object(ms, n_passes, steps_per_launch, cells_per_gpu, pmc, valu_insts, valu_how, kernel_name)
+    def roofline_of(ms, n_passes, data="Species::new"):
+        if data == "Species::new":
+            return roofline_object(ms, n_passes, steps_per_launch, cells_per_gpu, pmc, valu_insts, valu_how, kernel_name)
+        pmc_d = measured_counters(kernel_name, int(rows // world), cols, tuned, data)      # the profile of this input, if committed
+        insts_d, how_d = scaled_valu_insts(pmc_d, tuned)
+        return roofline_object(ms, n_passes, steps_per_launch, cells_per_gpu, pmc_d, insts_d, how_d, kernel_name)
 
     roofline = roofline_of(event_ms, passes)
     fused, developed, clocks, clocks_dev = None, None, None, None
@@ -318,9 +323,9 @@ def main() -> int:
                          "value_min": cells * args.steps / max(r[0] for r in runs_dev) / 1e6,
                          "value_max": cells * args.steps / min(r[0] for r in runs_dev) / 1e6,
                          "repeats": len(runs_dev),
-                         "roofline": {k: v for k, v in roofline_of(ms_dev, p_dev).items()
-                                      if k in ("bound", "achieved", "peak", "unit", "frac", "frac_source", "valu", "useful_valu",
-                                               "hbm_physical", "algorithmic_GBps", "launch_ms")}}
+                         "roofline": {k: v for k, v in roofline_of(ms_dev, p_dev, "developed").items()
+                                      if k in ("bound", "achieved", "peak", "unit", "frac", "frac_source", "valu", "valu_source", "useful_valu",
+                                               "hbm_physical", "traffic", "algorithmic_GBps", "launch_ms", "counters_source")}}
         unplaced = None
         if getattr(species, "placement", None):
             with stage("unplaced", 600):
@@ -439,6 +444,7 @@ def main() -> int:
         result["value_developed_pattern"] = developed["value"]
         result["developed_pattern"] = developed
         if clocks_dev:
+            developed["roofline"]["frac_at_sustained_clock"] = developed["roofline"]["frac"] / (clocks_dev["sclk_MHz"] / NOMINAL_SCLK_MHZ)
             developed["sclk_MHz_under_load"] = clocks_dev["sclk_MHz"]
             developed["socket_power_W_under_load"] = clocks_dev["power_W"]
             developed["energy_pJ_per_cell_step"] = clocks_dev.get("energy_pJ_per_cell_step")

@@ -1,5 +1,6 @@
 // gs_rccl.cpp -- RCCL, loaded on first use (single-process users never touch it), the one-rank self-test of the
 // ghost-row exchange's call pattern, which libraries the process is bound to, and the error message of the last failure.
+#include <chrono>
 #include "gs_internal.h"
 
 namespace gsi {
@@ -121,6 +122,109 @@ int32_t gs_rccl_selftest(int32_t device, uint64_t floats)
     R->CommDestroy(comm);
     (void)hipGetLastError();
     return st;
+}
+
+// The ghost-row exchange's transport UNDER LOAD, as far as one GPU can show it (gs_hip.h: gs_debug_exchange_probe_*): a
+// one-rank communicator, a high-priority stream like a slab's halo stream, `messages` send / receive pairs to itself
+// in one group per exchange -- or, mode 1, the same bytes as device-to-device copies, the route of in-process chains.
+// The caller decides what else the chip is doing (tools/rccl_under_load.py: nothing, or the interior kernel of a
+// 2^28-cell slab on the compute stream of a context).
+struct gs_exchange_probe {
+    int device = 0, mode = 0, messages = 0;
+    uint64_t floats = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float *src = nullptr, *dst = nullptr;
+};
+
+int32_t gs_debug_exchange_probe_destroy(gs_exchange_probe *p)
+{
+    if (!p) return GS_OK;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->e0) (void)hipEventDestroy(p->e0);
+    if (p->e1) (void)hipEventDestroy(p->e1);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    if (p->src) (void)hipFree(p->src);
+    if (p->dst) (void)hipFree(p->dst);
+    if (p->comm) {
+        Rccl *R = rccl();
+        if (R) R->CommDestroy(p->comm);
+    }
+    (void)hipGetLastError();
+    delete p;
+    return GS_OK;
+}
+
+int32_t gs_debug_exchange_probe_create(int32_t device, int32_t mode, int32_t messages, uint64_t floats, gs_exchange_probe **out)
+{
+    if (!out) return fail(GS_ERR_INVALID, "null output");
+    *out = nullptr;
+    if (mode < 0 || mode > 1 || messages < 1 || messages > 8 || floats == 0 || floats > (1ull << 26))
+        return fail(GS_ERR_INVALID, "mode 0 / 1, 1 to 8 messages of at most 2^26 floats");
+    gs_exchange_probe *p = new (std::nothrow) gs_exchange_probe();
+    if (!p) return fail(GS_ERR_NOMEM, "out of host memory");
+    p->device = device; p->mode = mode; p->messages = messages; p->floats = floats;
+    int32_t st = GS_OK;
+    auto step = [&](hipError_t e, const char *what) {
+        if (st == GS_OK && e != hipSuccess) st = fail(GS_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    };
+    step(hipSetDevice(device), "hipSetDevice");
+    if (st == GS_OK && mode == 0) {
+        Rccl *R = rccl();
+        if (!R) st = fail(GS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+        ncclUniqueId id;
+        ncclResult_t r = st == GS_OK ? R->GetUniqueId(&id) : ncclSuccess;
+        if (st == GS_OK && r == ncclSuccess) r = R->CommInitRank(&p->comm, 1, id, 0);
+        if (st == GS_OK && r != ncclSuccess) st = fail(GS_ERR_RCCL, "one-rank communicator: %s", R->GetErrorString(r));
+    }
+    int least = 0, greatest = 0;
+    step(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+    step(hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
+    step(hipEventCreate(&p->e0), "hipEventCreate");
+    step(hipEventCreate(&p->e1), "hipEventCreate");
+    const size_t bytes = (size_t)messages * floats * sizeof(float);
+    step(hipMalloc(reinterpret_cast<void **>(&p->src), bytes), "hipMalloc");
+    step(hipMalloc(reinterpret_cast<void **>(&p->dst), bytes), "hipMalloc");
+    step(hipMemset(p->src, 0x3c, bytes), "hipMemset");
+    step(hipMemset(p->dst, 0, bytes), "hipMemset");
+    step(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    if (st != GS_OK) { gs_debug_exchange_probe_destroy(p); return st; }
+    *out = p;
+    return GS_OK;
+}
+
+// One exchange: enqueued now, waited for.  host_ms: from the first enqueue call to the end of the wait (what a pass's
+// boundary has to hide); device_ms: between two events around the exchange on its stream (start of its first kernel or
+// copy to the end of the last); the difference is how long the exchange waited for a place on the chip.
+int32_t gs_debug_exchange_probe_run(gs_exchange_probe *p, float *host_ms, float *device_ms)
+{
+    if (!p) return fail(GS_ERR_INVALID, "null probe");
+    GS_HIP(hipSetDevice(p->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    GS_HIP(hipEventRecord(p->e0, p->stream));
+    if (p->mode == 0) {
+        Rccl *R = rccl();
+        ncclResult_t r = R->GroupStart();
+        for (int m = 0; m < p->messages && r == ncclSuccess; ++m) {
+            r = R->Send(p->src + (size_t)m * p->floats, (size_t)p->floats, ncclFloat, 0, p->comm, p->stream);
+            if (r == ncclSuccess) r = R->Recv(p->dst + (size_t)m * p->floats, (size_t)p->floats, ncclFloat, 0, p->comm, p->stream);
+        }
+        const ncclResult_t e = R->GroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) return fail(GS_ERR_RCCL, "grouped ncclSend / ncclRecv to self failed: %s", R->GetErrorString(r));
+    } else {
+        for (int m = 0; m < p->messages; ++m)
+            GS_HIP(hipMemcpyAsync(p->dst + (size_t)m * p->floats, p->src + (size_t)m * p->floats, (size_t)p->floats * sizeof(float),
+                                  hipMemcpyDeviceToDevice, p->stream));
+    }
+    GS_HIP(hipEventRecord(p->e1, p->stream));
+    GS_HIP(hipEventSynchronize(p->e1));
+    const auto t1 = std::chrono::steady_clock::now();
+    if (host_ms) *host_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    if (device_ms) GS_HIP(hipEventElapsedTime(device_ms, p->e0, p->e1));
+    return GS_OK;
 }
 
 // Which HIP runtime and which RCCL this process's libgs_hip.so is bound to (dladdr of an entry point of each), with

@@ -436,7 +436,7 @@ class Species:
         v.out().fill_slice(context, sl, 1.0)
         s = cls(context, u, v)
         s.flip()
-        s.placement = None
+        s.placement, s.placement_drawn = None, 0
         if place_candidates > 0:
             s.place(place_candidates)
         return s
@@ -450,8 +450,10 @@ class Species:
         arr = (ctypes.c_void_p * 4)(in_u.handle, in_v.handle, out_u.handle, out_v.handle)
         first, best = ctypes.c_float(0), ctypes.c_float(0)
         ctx = self._context
+        drawn0 = ctx.place_stats()[1]
         capi.check(ctx._lib.gs_fields_place(ctx.handle, arr, int(candidates), ctypes.byref(first), ctypes.byref(best)))
         self.placement = (float(first.value), float(best.value))
+        self.placement_drawn = ctx.place_stats()[1] - drawn0      # extra blocks held for a moment by THIS call
         return self.placement
 
     def context(self) -> HipContext:

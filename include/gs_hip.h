@@ -376,6 +376,15 @@ int32_t gs_ctx_set_pass_timing(gs_ctx *ctx, int32_t passes);
  * kernel launches so far. */
 int32_t gs_ctx_info(const gs_ctx *ctx, char *kernel_name, size_t cap, uint64_t *launches);
 
+/* Measurement hook, not for bindings (tools/rccl_under_load.py): the ghost-row exchange's transport on ONE GPU while the
+ * caller keeps the chip busy or idle.  mode 0: a one-rank RCCL communicator, `messages` ncclSend / ncclRecv pairs of
+ * `floats` f32 to itself in one group; mode 1: the same bytes as device-to-device copies (the in-process chain's route);
+ * both on a high-priority stream created like a slab's halo stream.  _run enqueues one exchange and waits for it:
+ * host_ms from the first enqueue to the end of the wait, device_ms between events around it on its stream. */
+typedef struct gs_exchange_probe gs_exchange_probe;
+int32_t gs_debug_exchange_probe_create(int32_t device, int32_t mode, int32_t messages, uint64_t floats, gs_exchange_probe **out);
+int32_t gs_debug_exchange_probe_run(gs_exchange_probe *p, float *host_ms, float *device_ms);
+int32_t gs_debug_exchange_probe_destroy(gs_exchange_probe *p);
 /* Introspection for the bench and the tests, not for bindings: what gs_fields_place has done on this context so far --
  * pair probes timed and extra blocks drawn (each of the planes' size; all freed or handed to planes by now). */
 int32_t gs_debug_place_stats(const gs_ctx *ctx, uint64_t *probes, uint64_t *blocks_drawn);

@@ -38,6 +38,17 @@ def main():
         sims[name] = (sim, sp)
     image = np.empty((a.rows, a.cols), np.float32)
     pinned = [pinned_empty((a.rows, a.cols)) for _ in range(2)]
+    # the floor a download per call sets: images back to back through the overlapped path, no steps in between
+    sim0, sp0 = sims["marching"]
+    for _ in range(2):
+        t0 = time.perf_counter()
+        for i in range(100):
+            sp0.write_result_view_after(pinned[i & 1])
+            sim0.context.download_wait()
+        per_image = (time.perf_counter() - t0) / 100
+    print(f"an image alone (staging copy + {cells * 4 / 1e6:.1f} MB over PCIe into pinned memory + wait), back to back: {per_image * 1e6:.0f} us = "
+          f"{cells * 4 / per_image / 1e9:.1f} GB/s: a call of n steps with a download each cannot beat {cells / per_image / 1e6:,.0f} x n Mcells x steps / s "
+          f"(n = 32: {32 * cells / per_image / 1e6:,.0f})")
     print(f"grid {a.rows} x {a.cols}, {a.calls} calls per figure, median of 3; Mcells x steps / s")
     print("| steps per call | kernel (label) | steps only | + blocking V download | + overlapped V download |")
     print("|---|---|---|---|---|")

@@ -20,10 +20,17 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--calls", type=int, default=5)
     ap.add_argument("--tune-steps", type=int, default=4000)
+    ap.add_argument("--developed", action="store_true",
+                    help="a developed spot pattern instead of Species::new (bench.py's co-headline input: developed_start + 4000 steps)")
     a = ap.parse_args()
     sim = Simulation.new(Parameters(), HipArgs())
-    sp = sim.make_species([a.rows, a.cols])
-    sim.perform_steps(sp, a.tune_steps)
+    if a.developed:
+        from benchkit.legs import developed_start, upload_species
+        sp = upload_species(sim, *developed_start(a.rows, a.cols))
+        sim.perform_steps(sp, max(a.tune_steps, 4000))
+    else:
+        sp = sim.make_species([a.rows, a.cols])
+        sim.perform_steps(sp, a.tune_steps)
     ctx = sim.context
     l0 = ctx.stats()["launches"]
     ctx.timer_start()
@@ -32,10 +39,14 @@ def main():
     ms = ctx.timer_stop()
     ctx.sync()
     st = ctx.stats()
-    print(json.dumps({"kernel": ctx.info()[0], "rows": a.rows, "cols": a.cols, "steps_per_call": a.steps, "calls": a.calls,
+    print(json.dumps({"kernel": ctx.info()[0], "input": "developed" if a.developed else "Species::new", "placement": sp.placement, "rows": a.rows, "cols": a.cols, "steps_per_call": a.steps, "calls": a.calls,
                       "Mcells_steps_per_s": a.rows * a.cols * a.steps * a.calls / (ms * 1e-3) / 1e6,
                       "launches_per_call": (st["launches"] - l0) / a.calls, "ms_per_call": ms / a.calls,
-                      "window_fallbacks": st["window_fallbacks"], "tuned": ctx.get_tuned(a.rows, a.cols)}), flush=True)
+                      "window_fallbacks": st["window_fallbacks"],
+                      # the layout that ran: chosen by gs_run's tuner, or pinned through GS_HIP_ROWS_PER_BLOCK / _FUSE_STEPS / _COLS_PER_LANE
+                      "tuned": ctx.get_tuned(a.rows, a.cols) if ctx.get_tuned(a.rows, a.cols)[0] else
+                      (ctx.args.rows_per_block, ctx.args.fuse_steps, ctx.args.cols_per_lane, ctx.args.share_taps),
+                      "pinned": bool(ctx.args.rows_per_block)}), flush=True)
     ctx.close()
     return 0
 

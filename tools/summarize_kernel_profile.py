@@ -54,9 +54,11 @@ def main():
     launches = max(1.0, line["launches_per_call"])
     steps_per_launch = line["steps_per_call"] / launches
     cell_steps = cells * steps_per_launch
-    out = [f"# rocprofv3 summary `{tag}` — `{line['kernel']}` on {line['rows']} x {line['cols']}", "",
+    inp = line.get("input", "Species::new")
+    out = [f"# rocprofv3 summary `{tag}` — `{line['kernel']}` on {line['rows']} x {line['cols']}, input: {inp}", "",
            f"Program: `python3 tools/run_steps.py --rows {line['rows']} --cols {line['cols']} --steps {line['steps_per_call']} "
-           f"--calls {line['calls']}` ({launches:g} launch(es) of `{needle}` per call, {steps_per_launch:g} time steps per launch); "
+           f"--calls {line['calls']}{' --developed' if inp == 'developed' else ''}` (planes placed by the library's default: probe pass "
+           f"{line.get('placement')} ms before / after; {launches:g} launch(es) of `{needle}` per call, {steps_per_launch:g} time steps per launch); "
            f"un-profiled: **{line['Mcells_steps_per_s']:,.0f} Mcells×steps/s**, under `--kernel-trace --stats`: {prof['Mcells_steps_per_s']:,.0f}.", "",
            "| kernel | calls | avg ms | min ms | max ms | % of GPU time |", "|---|---|---|---|---|---|"]
     for r in rows:
@@ -66,7 +68,7 @@ def main():
             f"{cell_steps / avg_ms / 1e3:,.0f} Mcells×steps/s under the profiler):", ""]
     entry = {"kernel": line["kernel"].split("@")[0], "rows": line["rows"], "cols": line["cols"], "launch_ms": avg_ms,
              "steps_per_pass": steps_per_launch, "rows_per_unit": (line.get("tuned") or [0])[0], "cols_per_lane": (line.get("tuned") or [0, 0, 0])[2],
-             "traffic": None, "valu_insts": None, "source": f"profiles/{tag}_summary.md"}
+             "traffic": None, "valu_insts": None, "source": f"profiles/{tag}_summary.md", "input": inp}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         rd, wr = 2.0 * c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
         entry["traffic"] = rd + wr
@@ -107,9 +109,10 @@ def main():
         except (OSError, ValueError):
             data = []
         data = [e for e in data if not (e.get("kernel") == entry["kernel"] and e.get("rows") == entry["rows"] and e.get("cols") == entry["cols"]
-                                        and e.get("rows_per_unit") == entry["rows_per_unit"])]
+                                        and e.get("rows_per_unit") == entry["rows_per_unit"]
+                                        and e.get("input", "Species::new") == entry["input"])]
         data.append(entry)
-        data.sort(key=lambda e: (e["kernel"], e["rows"], e["cols"], e.get("rows_per_unit") or 0))
+        data.sort(key=lambda e: (e["kernel"], e["rows"], e["cols"], e.get("rows_per_unit") or 0, e.get("input", "Species::new")))
         json.dump(data, open(cpath, "w"), indent=1, sort_keys=True)
 
 
