@@ -444,6 +444,9 @@ def main() -> int:
         result["value_developed_pattern"] = developed["value"]
         result["developed_pattern"] = developed
         if clocks_dev:
+            cap_d, pw_d = clocks_dev.get("power_cap_W"), clocks_dev.get("energy_W") or clocks_dev["power_W"]
+            if cap_d and pw_d and pw_d >= 0.96 * cap_d and developed["roofline"]["bound"] == "valu-issue":
+                developed["roofline"]["bound"] = "power-capped valu"
             developed["roofline"]["frac_at_sustained_clock"] = developed["roofline"]["frac"] / (clocks_dev["sclk_MHz"] / NOMINAL_SCLK_MHZ)
             developed["sclk_MHz_under_load"] = clocks_dev["sclk_MHz"]
             developed["socket_power_W_under_load"] = clocks_dev["power_W"]
@@ -466,7 +469,8 @@ def main() -> int:
             return True
         return any(isinstance(x, dict) and ("equal" in x or "error" in x) and failed(x) for x in v.values())
 
-    bad = verify and (failed(verified) or (peer_chain is not None and "verified" in peer_chain and failed(peer_chain["verified"])))
+    # (rank 0 holds the records; the other ranks of a chain report through it)
+    bad = rank == 0 and verify and (failed(verified) or (peer_chain is not None and "verified" in peer_chain and failed(peer_chain["verified"])))
     with wd.stage("teardown", 120):
         if sim_s is not None:
             sim_s.context.close()

@@ -1,5 +1,6 @@
 // gs_rccl.cpp -- RCCL, loaded on first use (single-process users never touch it), the one-rank self-test of the
 // ghost-row exchange's call pattern, which libraries the process is bound to, and the error message of the last failure.
+#include <atomic>
 #include <chrono>
 #include "gs_internal.h"
 
@@ -17,6 +18,10 @@ int32_t fail(int32_t code, const char *fmt, ...)
     g_last_error = buf;
     return code;
 }
+
+static std::atomic<Rccl *> g_rccl_loaded{nullptr}; // what rccl() found, for callers that must not trigger the load
+
+Rccl *rccl_if_loaded() { return g_rccl_loaded.load(); }
 
 Rccl *rccl()
 {
@@ -54,6 +59,7 @@ Rccl *rccl()
         r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.handle, "ncclCommCount"));
         r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.handle, "ncclCommUserRank"));
         r.CommCuDevice = reinterpret_cast<decltype(r.CommCuDevice)>(dlsym(r.handle, "ncclCommCuDevice"));
+        g_rccl_loaded.store(&r);
         return &r;
     }();
     return instance;
@@ -238,18 +244,31 @@ int32_t gs_runtime_info(int32_t load_rccl, char *out, size_t cap)
     int hip_version = 0, rccl_version = 0;
     (void)dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &hip_so);
     if (hipRuntimeGetVersion(&hip_version) != hipSuccess) { hip_version = 0; (void)hipGetLastError(); }
-    Rccl *R = load_rccl ? rccl() : nullptr;
+    Rccl *R = load_rccl ? rccl() : rccl_if_loaded(); // load_rccl = 0: reported if this process has loaded it already
     if (R) {
         (void)dladdr(reinterpret_cast<const void *>(R->Send), &rccl_so);
         auto get_version = reinterpret_cast<ncclResult_t (*)(int *)>(dlsym(R->handle, "ncclGetVersion"));
         if (get_version) (void)get_version(&rccl_version);
     }
+    // paths go into JSON strings: quotes and backslashes escaped, control characters dropped
+    auto json_string = [](const char *p) {
+        std::string o;
+        for (; p && *p; ++p) {
+            if (*p == '"' || *p == '\\') o += '\\';
+            if ((unsigned char)*p >= 0x20) o += *p;
+        }
+        return o;
+    };
     const char *user = std::getenv("GS_RCCL_LIBRARY");
-    std::snprintf(out, cap, "{\"hip\": \"%s\", \"hip_runtime_version\": %d, \"rccl\": %s%s%s, \"rccl_version\": %d, "
-                            "\"rccl_named_by_GS_RCCL_LIBRARY\": %s}",
-                  hip_so.dli_fname ? hip_so.dli_fname : "", hip_version, rccl_so.dli_fname ? "\"" : "",
-                  rccl_so.dli_fname ? rccl_so.dli_fname : "null", rccl_so.dli_fname ? "\"" : "", rccl_version,
-                  user && *user ? "true" : "false");
+    const std::string hip_path = json_string(hip_so.dli_fname), rccl_path = json_string(rccl_so.dli_fname);
+    const int n = std::snprintf(out, cap, "{\"hip\": \"%s\", \"hip_runtime_version\": %d, \"rccl\": %s%s%s, \"rccl_version\": %d, "
+                                          "\"rccl_named_by_GS_RCCL_LIBRARY\": %s}",
+                                hip_path.c_str(), hip_version, rccl_so.dli_fname ? "\"" : "", rccl_so.dli_fname ? rccl_path.c_str() : "null",
+                                rccl_so.dli_fname ? "\"" : "", rccl_version, user && *user ? "true" : "false");
+    if (n < 0 || (size_t)n >= cap) {
+        out[0] = '\0';
+        return fail(GS_ERR_INVALID, "gs_runtime_info: the object needs %d bytes, the buffer holds %zu", n + 1, cap);
+    }
     return GS_OK;
 }
 

@@ -221,6 +221,9 @@ void recall_tuned(gs_ctx *ctx, const gs_field *f, int fuse)
             ctx->share_now = t.share;
             return;
         }
+    // nothing chosen for this shape yet: its untuned passes and its tuning start from the default form, not from the
+    // form another shape of this context was tuned to (share_now is the context's, the choices are per shape)
+    ctx->share_now = kShareDefault;
 }
 
 void remember_tuned(gs_ctx *ctx, const gs_ctx::Tuned &t)
@@ -524,7 +527,13 @@ int32_t gs_ctx_get_tuned(const gs_ctx *ctx, uint64_t slab_rows, uint64_t cols, i
     if (!ctx) return fail(GS_ERR_INVALID, "null context");
     int rpu = 0, k = 0, cpl = 0, share = 0;
     for (const gs_ctx::Tuned &t : ctx->tuned_cache)
-        if (t.rows == slab_rows && t.cols == cols) { rpu = t.rpu; k = t.k; cpl = t.cpl; share = t.share == 1 ? 1 : (t.share ? 3 : 2); } // the newest entry wins
+        if (t.rows == slab_rows && t.cols == cols) { // the newest entry wins
+            rpu = t.rpu; k = t.k; cpl = t.cpl;
+            // the EFFECTIVE form: only 2 columns per lane with 2 to 4 fused steps, strict math and a stencil whose diagonal
+            // weights pair up have a sharing variant -- everything else runs without, whatever the entry carries
+            const bool has_variant = t.cpl == 2 && t.k >= 2 && (fast_possible(ctx) & 4);
+            share = !has_variant ? 2 : (t.share == 1 ? 1 : (t.share ? 3 : 2));
+        }
     if (rows_per_block) *rows_per_block = rpu;
     if (fuse_steps) *fuse_steps = k;
     if (cols_per_lane) *cols_per_lane = cpl;

@@ -91,7 +91,7 @@ def bootstrap(backend: Optional[str] = None, id_source: Optional[Callable[[], by
 
 
 def share_tuning(sim, slab_rows: int, cols: int, rank: int, world: int, device: str = "cpu",
-                 tune_steps: int = 400, local_device: int = 0, place_candidates: int = 0) -> Tuple[int, int, int]:
+                 tune_steps: int = 400, local_device: int = 0, place_candidates: int = 0) -> Tuple[int, int, int, int]:
     """Give every process of a slab chain the same tuned kernel configuration.
 
     Multi-process contexts do not tune on line (a timing window would have to be collective).

@@ -31,7 +31,33 @@ def test_recorded_bench_line_has_the_contract_keys():
         assert 0 < r["useful_valu"] < 1
         if r["bound"] in ("valu-issue", "power-capped valu", "hbm of these planes"):
             assert r["steps_per_launch"] >= 3 and r["unit"] == "T lane-ops/s" and abs(r["peak"] - 78.6432) < 1e-3
-            if r["valu_insts_per_launch"]:
+            if "frac_definition" in r:
+                # round 6 on: `frac` is the rate priced in the reference's form of the update (53 operations per cell-step)
+                # against the VALU roof -- recomputable from the line alone, and it does not fall when the kernel issues
+                # fewer instructions for the same update; the issued fraction (`valu`, from the committed profile of the
+                # layout that ran) and the kernel's own arithmetic (`useful_valu`) stand beside it
+                cell_steps = b["config"]["cells_per_gpu"] * r["steps_per_launch"]
+                assert abs(r["achieved"] - 53 * cell_steps / (r["launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+                assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and abs(r["frac"] - r["reference_form_valu"]) < 1e-9
+                assert 0 < r["useful_valu"] <= r["valu"] < r["frac"] < 1
+                assert abs(r["valu"] - r["valu_insts_per_launch"] * 64 / (r["launch_ms"] * 1e-3) / 1e12 / r["peak"]) < 1e-9
+                # the counters are those of the layout that ran: nothing is scaled from another unit height
+                assert r["valu_source"] == "measured (profile of this layout)", r["valu_source"]
+                assert r["counters_layout"]["rows_per_unit"] == b["config"]["tuned"]["rows_per_unit"]
+                assert abs(r["peak_at_sustained_clock"] - r["peak"] * r["sclk_MHz_under_load"] / 2400.0) < 1e-6
+                assert abs(r["frac_at_sustained_clock"] - r["frac"] * 2400.0 / r["sclk_MHz_under_load"]) < 1e-9
+                # `value` is what the library's defaults give (placement by measurement included); the same launches on
+                # planes as hipMalloc hands them out stand beside it
+                pl = b["config"]["placement"]
+                assert pl["default"] is True and pl["max_extra_blocks"] == 12 and pl["transient_GiB"] <= 16
+                assert 0.8 * b["value"] < b["value_unplaced"] < 1.05 * b["value"]
+                ss_pl = b["single_step"]["placement"]
+                assert 0 < ss_pl["chosen_blocks_probe_ms"] <= ss_pl["first_blocks_probe_ms"] * 1.0001
+                assert b["single_step"]["frac_of_8TBps"] >= 0.70, b["single_step"]["frac_of_8TBps"]      # north_star's target on the HBM-bound leg
+                assert len(b["single_step"]["unplaced_frac_of_8TBps"]) >= 1
+                d_r = b["developed_pattern"]["roofline"]
+                assert d_r["counters_source"] != r["counters_source"] and d_r["valu_source"] == "measured (profile of this layout)"
+            elif r["valu_insts_per_launch"]:
                 assert abs(r["achieved"] - r["valu_insts_per_launch"] * 64 / (r["launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
                 assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["frac"] == r["valu"] and 0 < r["frac"] < 1
                 assert r["useful_valu"] <= r["valu"]
@@ -84,8 +110,9 @@ def test_recorded_bench_line_has_the_contract_keys():
                         assert rt["rccl"] is None and rt["bootstrap"] is None          # N = 1: nothing loads RCCL
                         assert b["stage_seconds"]["timed"] > 0 and sum(b["stage_seconds"].values()) < 120
                         pl = ss["placement"]
-                        assert 0 < pl["chosen_blocks_ms_per_step"] <= pl["first_blocks_ms_per_step"] * 1.0001
-                        assert abs(ss["frac_of_8TBps"] - pl["chosen_blocks_frac_of_8TBps"]) < 0.03
+                        if "chosen_blocks_ms_per_step" in pl:      # round 5's form (single-step probes over 4-subsets)
+                            assert 0 < pl["chosen_blocks_ms_per_step"] <= pl["first_blocks_ms_per_step"] * 1.0001
+                            assert abs(ss["frac_of_8TBps"] - pl["chosen_blocks_frac_of_8TBps"]) < 0.03
                         assert r["useful_valu_per_cell_step"] == (41 if ".dx" in b["config"]["kernel"] else 46 if ".ds" in b["config"]["kernel"] else 53)
                         assert abs(r["reference_form_valu"] - r["useful_valu"] * 53 / r["useful_valu_per_cell_step"]) < 1e-9
                         assert b["config"]["tuned"]["share_taps"] in (True, False, "within lanes", "across lanes", "off")

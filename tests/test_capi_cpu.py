@@ -216,3 +216,16 @@ def test_window_tilings_cover_the_grid_and_name_every_neighbour():
                         if j != i and p0 < a1 + k and p1 > a0 - k and q0 < b1 + k and q1 > b0 - k}
                 got = set(d[i, 6:6 + d[i, 5]].tolist())
                 assert got == want and d[i, 5] <= 14, (rows, cols, i, got, want)
+
+
+def test_runtime_info_refuses_a_buffer_that_is_too_small(built):
+    from grayscott_amd import capi
+
+    """ADVICE round 5: a truncated object used to come back with GS_OK (and then failed in json.loads)."""
+    import ctypes
+
+    lib = capi.load()
+    small = ctypes.create_string_buffer(16)
+    assert lib.gs_runtime_info(0, small, 16) == capi.GS_ERR_INVALID and small.value == b""
+    info = capi.runtime_info(load_rccl=False)
+    assert info["hip"] and info["rccl"] is None            # nothing has loaded RCCL in this process

@@ -31,7 +31,7 @@ def gpu_rows():
         rates = []
         for _ in range(5):
             # (large Species: planes placed by measurement, as bench.py does -- profiles/r05_cross_lane.md, section 4)
-            sp = sim.make_species([rows, cols], place_candidates=124 if rows * cols >= (1 << 25) else 0)
+            sp = sim.make_species([rows, cols])     # (the library default: Species of >= 2^26 cells are placed by measurement)
             sim.perform_steps(sp, 100)
             sim.context.sync()
             t0 = time.perf_counter()

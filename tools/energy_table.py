@@ -54,7 +54,7 @@ def main():
                                                    cols_per_lane=2, **kw))
         sims[name] = [sim, {}]
     start = bench.developed_start(rows, cols) if "developed" in datas else None
-    place = 124 if cells >= (1 << 26) else 0
+    place = None                     # the library default: Species of >= 2^26 cells are placed by measurement
     for name, (sim, species) in sims.items():
         if "new" in datas:
             # (planes placed by measurement: unplaced, the flavours would be compared on different draws of blocks)
