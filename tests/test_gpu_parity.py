@@ -542,7 +542,8 @@ def test_no_tune_option_and_handed_in_configuration():
         slab_rows = shape[0] // len(kw.get("devices", [0]))
         assert sim.context.get_tuned(slab_rows, shape[1]) == (0, 0, 0, 0)
         sim.context.set_tuned(slab_rows, shape[1], 16, 3, 1)
-        assert sim.context.get_tuned(slab_rows, shape[1]) == (16, 3, 1, 3)      # (share_taps 0 = the default form: across lanes too)
+        # (the EFFECTIVE form is reported: 1 column per lane has no sharing variant, whatever was handed in -- ADVICE round 5)
+        assert sim.context.get_tuned(slab_rows, shape[1]) == (16, 3, 1, 2)
         sim.perform_steps(sp, 17)
         label = sim.context.info()[0]
         assert label.startswith("tb-k3c1/") and "@16x" in label, label
