@@ -268,7 +268,7 @@ def main() -> int:
         """At least 120 ms of untimed steps right before a warm-up, no host gap: the timed launches meet the
         clocks and caches of a running simulation, which is what the number claims to describe.  (A chip that
         comes out of an idle stretch -- the tuning's waits, a clock sample -- needs ~50 ms of load before its rate
-        settles: with 18 ms here the first five 5-ms regions read 1-4 % low, profiles/r03_sweeps.md section 6.)"""
+        settles: with 18 ms here the first five 5-ms regions read 1-4 % low, profiles/archive/r03_sweeps.md section 6.)"""
         rate = 1.2e12 if cells_per_gpu >= (1 << 24) else 5.0e11        # cell-steps per second, a high guess
         n = (max(24, int(0.12 * rate / cells_per_gpu)) + 11) // 12 * 12
         run(sp, n)                                      # whole passes only, whatever the tuner fuses (2, 3 or 4 steps)
@@ -281,7 +281,7 @@ def main() -> int:
     # The W warm-up steps come first and the long untimed phase after them, directly before the timed regions: a W
     # that is not a whole number of passes (the driver's 5) ends in a single-step launch of another kernel, and the
     # chip, which sits on its power limit, answers that 0.7 ms change of load with a 20 ms dip -- the first four
-    # 5-ms regions read 1-5 % low with W = 5 and not with W = 0, 4 or 8 (profiles/r03_sweeps.md, section 6).
+    # 5-ms regions read 1-5 % low with W = 5 and not with W = 0, 4 or 8 (profiles/archive/r03_sweeps.md, section 6).
     with stage("timed", 600):
         timed_run(species, args.steps)
         run(species, args.warmup)

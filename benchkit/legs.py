@@ -106,7 +106,7 @@ def scaled_valu_insts(pmc, tuned):
 
 def developed_start(rows, cols):
     """Start of a pattern-forming run instead of the reference's benchmark input: U = 1, V = 0 with one
-    12 x 12 seed (U = 0.5, V = 0.25) per 40 000 cells and 1 % noise (tools/pattern_rate.py, profiles/r01_soak.md:
+    12 x 12 seed (U = 0.5, V = 0.25) per 40 000 cells and 1 % noise (tools/pattern_rate.py, profiles/archive/r01_soak.md:
     4000 steps later spots fill the grid).  Returns dense host arrays (u0, v0)."""
     import numpy as np
 

@@ -29,7 +29,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-ffp-contract
 EXTRA = os.environ.get("GS_HIP_EXTRA_FLAGS", "").split()
 
 # The step kernels are built without the SLP vectoriser: v_pk_*_f32 has the lane throughput of the
-# plain ops on gfx950 and the packing costs ~10 % extra v_mov (profiles/r01_sweeps.md, runs 49-57).
+# plain ops on gfx950 and the packing costs ~10 % extra v_mov (profiles/archive/r01_sweeps.md, runs 49-57).
 KERNEL_FLAGS = ["-fno-slp-vectorize"]
 STRICT = ["-DGS_MATH_FUSED=0", "-Xclang", "-fdenormal-fp-math-f32=preserve-sign,ieee"]
 

@@ -277,7 +277,7 @@ int bands_for(const gs_ctx *ctx, const gs_field *f, int fuse)
     if (ctx->total_slabs() != 1 || fuse < 2) return 1;
     // Opt-in (gs_options.split >= 2).  Bands reach +3 % on the 16384^2 grid on a good day, but how
     // the four streams of two bands share the chip varies from box to box and run to run (845 k to
-    // 936 k for one configuration, profiles/r01_sweeps.md runs 58-61); one launch per pass does not.
+    // 936 k for one configuration, profiles/archive/r01_sweeps.md runs 58-61); one launch per pass does not.
     int V = ctx->o.split;
     if (V == 0) V = 1;
     if (V > 8) V = 8;
@@ -798,7 +798,7 @@ int32_t run_steps(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_fiel
     // Mid-size grids (single slab): K <= 8 steps per launch on LDS-resident windows (gs_run_tile_k), where a
     // pass of the temporally blocked kernel is bound by the length of a wave's march and a launch per <= 4
     // steps.  kernel = auto picks it between the resident kernel's 1536 cells and 1.5 M cells when nothing
-    // is pinned, with the window and steps per launch of pick_tile_config (profiles/r02_sweeps.md, section
+    // is pinned, with the window and steps per launch of pick_tile_config (profiles/archive/r02_sweeps.md, section
     // 10: 2.2x at 64 x 128 and 128 x 256, 1.8x at 256 x 512, 1.4x at 512 x 1024; at 1080 x 1920 the marching
     // kernel is ahead again); GS_KERNEL_TILE forces it (tile_shape and fuse_steps then choose the window
     // and the steps per launch).

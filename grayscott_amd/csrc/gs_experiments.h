@@ -27,7 +27,7 @@
 #endif
 // GS_TB_AUX_LOAD / GS_TB_AUX_STORE  cache-policy bits of every plane access of the marching kernel (gfx950:
 //                  1 = sc0, 2 = nt, 16 = sc1).  16 / 16 was the timing experiment "what would accesses that other
-//                  CUs can observe inside a launch cost" (profiles/r03_sweeps.md, section 3).
+//                  CUs can observe inside a launch cost" (profiles/archive/r03_sweeps.md, section 3).
 #ifndef GS_TB_AUX_LOAD
 #define GS_TB_AUX_LOAD 0
 #endif

@@ -9,7 +9,7 @@
 #include <stdint.h>
 
 // Largest grid (cells) gs_launch_resident_* takes (4 planes of (rows + 2) x (cols + 2) floats in LDS: at most
-// 74 KB).  Above, the LDS-window kernel with its many workgroups is faster (profiles/r02_sweeps.md, section 10).
+// 74 KB).  Above, the LDS-window kernel with its many workgroups is faster (profiles/archive/r02_sweeps.md, section 10).
 constexpr int kGsResidentCells = 1536;
 // gs_launch_tile_*: the most time steps one launch advances its tiles by.
 constexpr int kGsTileMaxSteps = 8;

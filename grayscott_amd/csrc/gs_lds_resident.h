@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kResidentThreads) void GS_SUFFIX(gs_run_resident_k)
 // Between the single-workgroup resident kernel (<= 1536 cells) and grids that fill the chip with
 // marching waves (~1 M cells and up), a pass of gs_step_tb_k is bound by the LENGTH of a wave's march
 // (unit height + 2K ticks of K levels, one wave per SIMD issuing every 4th cycle) plus a dependent
-// launch per K <= 4 steps: 2.3-3.4 us per step whatever the grid (profiles/r02_criterion_grid.md).
+// launch per K <= 4 steps: 2.3-3.4 us per step whatever the grid (profiles/archive/r02_criterion_grid.md).
 // Here a workgroup of 16 waves owns a window of 16 * RPW rows x 64 columns: wave w holds rows
 // w * RPW ... in registers, one column per lane.  Per step every wave publishes its rows in LDS
 // (double-buffered: one workgroup barrier per step), reads the rows above and below its own and the
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kResidentThreads) void GS_SUFFIX(gs_run_resident_k)
 // outside are zeros and stay zeros: that is the zero-halo rule as it stands, and for the clipped-window rule
 // every cell of such a window carries its own eight weights (cell_border: the table shifted as the
 // reference's corner-anchored indexing shifts it, 0 for a neighbour that does not exist).
-// The first form of this kernel (4-cell strips, 2-8 waves per tile; profiles/r02_sweeps.md, section 4)
+// The first form of this kernel (4-cell strips, 2-8 waves per tile; profiles/archive/r02_sweeps.md, section 4)
 // spent 3.3-5.5 us per step on a 16 x 40 window: a wave alone on its SIMD issues one instruction per 4
 // cycles and a strip was a chain of ~250 of them.  With 16 waves per window every SIMD has 4 waves to
 // issue from and a step is ~55 * RPW instructions per wave.

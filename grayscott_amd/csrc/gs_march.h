@@ -47,7 +47,7 @@ struct RowT { // [0] = column c-1, [1..CPL] = own columns, [CPL+1] = column c+CP
 };
 
 // Neighbour-lane reads of the temporally blocked kernel, whose outermost lanes are sacrificial (they
-// may receive anything).  Measured on MI355X (tools/ubench/valu_rate2.hip, profiles/r02_sweeps.md): a
+// may receive anything).  Measured on MI355X (tools/ubench/valu_rate2.hip, profiles/archive/r02_sweeps.md): a
 // DPP instruction issues at half the VALU rate and, mixed into ordinary VALU code, costs the wave 3-5
 // issue slots; ds_bpermute_b32 goes through the LDS crossbar (no LDS memory, ~6 cycles per CU and
 // wave-instruction) and takes no VALU slot at all.  At 4 exchanges per row and level the crossbar is
@@ -253,7 +253,7 @@ __device__ __forceinline__ void cells_xshare(const GsStepArgs &a, const RowQ<2> 
 // with the widest record count: the units never step outside their planes, so nothing relies on the
 // range check.  With them, the late fetch (GS_TB_LATE_FETCH, gs_experiments.h) and the edge path's column
 // masks kept as lane masks in SGPRs, the whole kernel entry -- general path included -- fits 126
-// registers: 4 waves per SIMD instead of 3, +9 % at 16384^2 (profiles/r02_sweeps.md, section 8).
+// registers: 4 waves per SIMD instead of 3, +9 % at 16384^2 (profiles/archive/r02_sweeps.md, section 8).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
@@ -293,7 +293,7 @@ __device__ __forceinline__ void store_cols_buf(__amdgpu_buffer_rsrc_t r, int vof
 // Fair progress in launches of about one round of wave slots (FAIR, 16-wave workgroups).  The SIMD's issue
 // arbitration is priority, then AGE: of four waves with equal work the two oldest take nearly every slot, and
 // the four finish one after the other -- the last one alone on its SIMD for 15-20 % of the launch, where a
-// lone wave issues at most every 4th cycle, half the SIMD's rate (tools/wave_timeline.py, profiles/r03_sweeps.md
+// lone wave issues at most every 4th cycle, half the SIMD's rate (tools/wave_timeline.py, profiles/archive/r03_sweeps.md
 // section 1).  With all 16 waves of a CU in one workgroup every wave publishes its progress (256ths of its
 // ticks) in an LDS word per tick and reads the words of the waves that share its SIMD: whoever is ahead of
 // another runs at priority 0, the others at 3, so the four stay within a tick of each other and end together.

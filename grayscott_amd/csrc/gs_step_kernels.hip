@@ -247,7 +247,7 @@ hipError_t GS_SUFFIX(gs_launch_stream)(const GsStepArgs &a, hipStream_t s, const
     // XCD-aware order, as in gs_launch_tb: this kernel IS bound by HBM, so the re-reads the XCDs' L2s absorb are
     // time -- 16384^2 365 k -> 376 k (6.0 TB/s algorithmic), 4096^2 323 k -> 347 k, 1080 x 1920 171 k -> 186 k; 8192^2
     // unchanged on average (265-333 k from one context to the next either way: the four planes' placement decides).
-    // Groups of 8 x 64 workgroups lose 6 % (profiles/r03_sweeps.md, section 12).  GS_HIP_XCD_M_STREAM = 0 / n: off / 8 n.
+    // Groups of 8 x 64 workgroups lose 6 % (profiles/archive/r03_sweeps.md, section 12).  GS_HIP_XCD_M_STREAM = 0 / n: off / 8 n.
     static const int xcd_env = gs_env_int("GS_HIP_XCD_M_STREAM", -1, 0, kGsXcdGroupMax);
     args.xcd_m = xcd_env >= 0 ? xcd_env : 16;
     void *kargs[] = {&args};
@@ -318,7 +318,7 @@ static int tb_waves_of(const void *f)
 static int tb_reduce_fast(int fast, int k = 0, int cpl = 0, int wg = 4)
 {
     // The fused build has no use for bit 0 (its taps are sub + fma already) and measured slower
-    // with bit 1 (profiles/r01_sweeps.md, runs 48/49): it always runs the general variant.  dt == 1
+    // with bit 1 (profiles/archive/r01_sweeps.md, runs 48/49): it always runs the general variant.  dt == 1
     // alone (fast == 2) is not worth a variant either, and bit 2 means nothing without the other two.
     fast &= GS_MATH_FUSED ? 0 : 15;
     if (!(fast & 1)) return 0;
@@ -378,7 +378,7 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // Tapered tail (consecutive passes are dependent launches that cannot overlap, so the drain phase
     // of a launch is idle time): when the launch is at least two rounds of the chip's wave slots, the
     // last round of units is an eighth as tall as the others and the round before it half as tall.
-    // Measured at 16384^2 (profiles/r02_sweeps.md, section 7): +1...2 % over round 1's single level
+    // Measured at 16384^2 (profiles/archive/r02_sweeps.md, section 7): +1...2 % over round 1's single level
     // (the last two rounds at a quarter), and unit heights of 128-192 rows become usable.
     const long slots = 1024L * waves; // 256 CUs x 4 SIMDs x waves per SIMD
     long big_chunks = rows_a > 0 ? rows_a / rpu : 0, small = rpu, mid_chunks = -1, tiny = rpu;
@@ -425,7 +425,7 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // Edge units as two halves each when the launch is about one round of wave slots (every unit starts at
     // once, so the slow edge units would finish last: 1080 x 1920 +5.7 %, 2048 x 4096 +1.6 %; from two rounds
     // up the edge-first order does the job and halves only add recomputed rows: 8192^2 -1 %;
-    // profiles/r02_sweeps.md, section 11).  The kernel's dispatch order: the outer strips of every chunk, then all strips of the
+    // profiles/archive/r02_sweeps.md, section 11).  The kernel's dispatch order: the outer strips of every chunk, then all strips of the
     // bottom `bot` and the top chunk row of range a, then the rest.
     static const int split_env = gs_env_int("GS_HIP_EDGE_SPLIT", -1, 0, 1);
     const long er = ((strips - 1) * W + tb_sacrificial_lanes(k, cpl) * cpl >= a.cols && strips >= 2) ? 2 : 1, ne = 1 + er;
@@ -449,7 +449,7 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // SIMDs' oldest-first arbitration, the waves of a SIMD finish one after the other, the last one alone.
     // Not for short marches of the 1-column layout: there most of a unit's ticks are the memory-bound filling
     // of the level pipeline, and waves left out of phase by the oldest-first arbitration hide each other's
-    // waits.  Free-running / in step, same box (profiles/r03_sweeps.md, section 2): 1 column per lane, 10-row
+    // waits.  Free-running / in step, same box (profiles/archive/r03_sweeps.md, section 2): 1 column per lane, 10-row
     // units 430 k / 390 k, 12 rows 465 k / 443 k, 16 rows 524 k / 514 k, 20 rows 565 k / 573 k, 40 rows 677 k / 705 k;
     // 2 columns per lane, 10 rows 523 k / 537 k, 15 rows 615 k / 633 k, 19 rows 687 k / 738 k, 38 rows 782 k / 865 k.
     // GS_HIP_FAIR = 0 / 1 forces it off / on.
@@ -469,11 +469,11 @@ hipError_t GS_SUFFIX(gs_launch_tb)(const GsStepArgs &a, int k, hipStream_t s, co
     // XCD-aware unit order (GsStepArgs::xcd_m): the dispatcher deals workgroups over the 8 XCDs round-robin, so
     // four-strip neighbours in the grid land on eight different L2s and each fetches the columns and rows their
     // windows share for itself.  With every XCD taking 16 consecutive workgroups of each group of 128, the HBM
-    // reads of a 16384^2 launch fall from 2.376 to 2.239 GiB (minimum 2.0; FETCH_SIZE, tools/fetch_ab.sh) and the
+    // reads of a 16384^2 launch fall from 2.376 to 2.239 GiB (minimum 2.0; FETCH_SIZE, tools/archive/fetch_ab.sh) and the
     // launch gains 0.3-0.5 % (8192^2 +0.8 %, 4 / 8 slabs on one GPU +1.4 / +0.6 %).  Larger groups read no less
     // (68: 2.226 GiB) and run slower (-2 %, 136: -6 %: an XCD's share of the last groups is all tall or all short
     // units).  Launches of about one round keep the plain order: 1080 x 1920 loses 1.2 % with the renumbering
-    // (profiles/r03_sweeps.md, section 12).  GS_HIP_XCD_M = 0 / n forces it off / to groups of 8 n.
+    // (profiles/archive/r03_sweeps.md, section 12).  GS_HIP_XCD_M = 0 / n forces it off / to groups of 8 n.
     static const int xcd_env = gs_env_int("GS_HIP_XCD_M", -1, 0, kGsXcdGroupMax);
     args.xcd_m = xcd_env >= 0 ? xcd_env : (units >= 2 * slots ? 16 : 0);
     // the edge units at the head of the dispatch order stay dealt over all XCDs (they are the slow ones)

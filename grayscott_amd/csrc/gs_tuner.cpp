@@ -51,7 +51,7 @@ int fast_of(const gs_ctx *ctx)
 // slots (256 CUs x 4 SIMDs x the kernel entry's waves per SIMD): strips x chunks <= r x slots with the
 // chunks as short as that allows.  A launch that misses such a height by one chunk runs a nearly empty
 // extra round: at 4096^2 with 2 columns per lane 36 rows give 749 k Mcells x steps/s, 32 rows 677 k, 40
-// rows 687 k (profiles/r02_sweeps.md, section 9).  From two rounds up the launcher tapers the last two
+// rows 687 k (profiles/archive/r02_sweeps.md, section 9).  From two rounds up the launcher tapers the last two
 // rounds (an eighth and a half as tall: 0.625 rounds' worth of rows), which the formula accounts for.
 // Writes up to `max` heights (the single-round one first); returns their number.
 int fit_heights(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse, int cpl, int fast, int *out, int max, bool partial)
@@ -104,7 +104,7 @@ bool tuned_for(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse)
 }
 
 // Columns per lane of the temporally blocked kernel when nothing was tuned on line: 2 (measured
-// fastest from 4096^2 up, profiles/r01_sweeps.md runs 54-57) unless that cannot give every SIMD a
+// fastest from 4096^2 up, profiles/archive/r01_sweeps.md runs 54-57) unless that cannot give every SIMD a
 // wave at a unit height of 8 * fuse rows, then 1.
 int32_t pick_cols_per_lane(const gs_ctx *ctx, int32_t rows, int32_t cols, int fuse)
 {
@@ -125,7 +125,7 @@ int32_t pick_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int fu
     // fill two rounds), the height follows the rows the device holds instead.  16384^2 as N slabs on one GPU,
     // own / device-wide height: 8 slabs (76 / 122 rows) 865-885 k / 1000-1030 k = 0.94-0.98 of the single slab,
     // 4 slabs (152 / 122) 935-970 k / 1007-1015 k; 2 slabs keep their own 142 rows = two rounds each: 1019-1077 k
-    // against 1000-1008 k with 122 (profiles/r03_sweeps.md, section 5).
+    // against 1000-1008 k with 122 (profiles/archive/r03_sweeps.md, section 5).
     if (ctx->slabs.size() > 1 && fuse > 1) {
         int fit[2];
         const int nf = fit_heights(ctx, rows, cols, fuse, cpl, fast_of(ctx), fit, 2);
@@ -168,7 +168,7 @@ int32_t model_rows_per_unit(const gs_ctx *ctx, int32_t rows, int32_t cols, int f
 }
 
 // Window shape and steps per launch of the LDS-window kernel (gs_run_tile_k) for a grid, from a cost model
-// fitted to the measured launches (profiles/r02_sweeps.md, section 10): a launch costs T0 = 3.4 / 2.6 / 3.7 us
+// fitted to the measured launches (profiles/archive/r02_sweeps.md, section 10): a launch costs T0 = 3.4 / 2.6 / 3.7 us
 // (launch gap, weights, window load and store) plus K steps of 0.74 / 0.585 / 1.38 us for the 32 / 16 / 64-row
 // window while every workgroup has a CU to itself; beyond 256 workgroups they run in rounds (two share a CU
 // at 0.87 of the time of two turns).  The model is within ~15 % of the measured rates from 64 x 128 to 1024 x
@@ -466,7 +466,7 @@ int32_t tune_online(Run &r, int fuse)
             }
             // short calls get shorter windows rather than no tuning at all, but not shorter than two
             // passes per window: single-pass windows are noise, and a mis-tuned configuration is worse
-            // than the untuned default (criterion grid, 16-step calls: profiles/r02_criterion_grid.md).
+            // than the untuned default (criterion grid, 16-step calls: profiles/archive/r02_criterion_grid.md).
             // With less than 5 passes left the candidate waits for the next gs_run.
             const uint64_t passes_left = (r.steps - r.n) / (uint64_t)t.k;
             while (t.reps > 2 && passes_left < (uint64_t)(2 * t.reps + 1)) --t.reps;

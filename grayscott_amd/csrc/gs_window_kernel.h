@@ -12,7 +12,7 @@ namespace {
 //
 // At these sizes a pass of the marching kernel is 19 us for 4 steps of which ~9 are fixed (launch gap, dispatch,
 // first-rows burst, level-pipeline fill on memory latency) and its 10-row units recompute 30 % of their rows
-// (profiles/r03_sweeps.md, sections 1-4).  Here a workgroup of 16 waves owns a window of 16 * RPW rows x 128
+// (profiles/archive/r03_sweeps.md, sections 1-4).  Here a workgroup of 16 waves owns a window of 16 * RPW rows x 128
 // columns for the whole run: a wave keeps RPW whole rows in registers, two columns per lane (10 cells per lane at
 // RPW = 5).  Per step the columns next to a lane's two come from the adjacent lanes (DPP wave shifts), only the
 // first and the last row of a wave's band go through LDS for the waves above and below (double-buffered by the

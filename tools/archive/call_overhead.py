@@ -2,7 +2,7 @@
 """Host-side cost of the reference's benchmark iteration on small grids: `perform_steps(1)` = gs_run + gs_sync
 (compute/shared/src/benchmark.rs:77-83 calls it once per criterion iteration, starting at 8 x 16 cells).
 
-    python tools/call_overhead.py
+    python tools/archive/call_overhead.py
 
 Per grid: microseconds per call of (a) gs_run + gs_sync, (b) gs_run alone, enqueued 200 deep and synchronised once,
 (c) gs_sync on an idle context, (d) the ctypes call overhead itself (gs_abi_version).

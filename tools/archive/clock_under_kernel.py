@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Shader clock, socket power and energy per cell-step while ONE kernel choice runs for a few seconds on a grid:
 
-    python tools/clock_under_kernel.py ROWS COLS SECONDS VARIANT [VARIANT ...]     (VARIANT = key=value,key=value over HipArgs)
+    python tools/archive/clock_under_kernel.py ROWS COLS SECONDS VARIANT [VARIANT ...]     (VARIANT = key=value,key=value over HipArgs)
 """
 import json
 import os

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM read traffic (FETCH_SIZE) of the headline launches under two settings of one environment variable:
-#   tools/fetch_ab.sh VAR VALUE_A VALUE_B      (run through gpurun; layout pinned as tools/profile_sq_detail.sh)
+#   tools/archive/fetch_ab.sh VAR VALUE_A VALUE_B      (run through gpurun; layout pinned as tools/profile_sq_detail.sh)
 set -eo pipefail
 VAR=$1; A=$2; B=$3
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A few hundred launches of the LDS-window kernel on one mid-size grid, for rocprofv3 (kernel trace or PMC pass):
-    rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES -- python3 tools/tile_probe.py 128 256
+    rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES -- python3 tools/archive/tile_probe.py 128 256
 """
 import os
 import sys

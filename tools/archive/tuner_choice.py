@@ -2,7 +2,7 @@
 """What gs_run's on-line tuner chooses (unit height, steps per pass, columns per lane, form of difference sharing) on
 Species::new and on a developed pattern, several fresh contexts each, and the rate each choice then sustains.
 
-    GS_HIP_TRACE_TUNER=1 python tools/tuner_choice.py [--rows 16384 --cols 16384] [--contexts 3] [--seconds 3]
+    GS_HIP_TRACE_TUNER=1 python tools/archive/tuner_choice.py [--rows 16384 --cols 16384] [--contexts 3] [--seconds 3]
 One JSON line per context: input, tuned configuration, kernel label, Mcells x steps/s over `--seconds` (HIP events)."""
 import argparse
 import json

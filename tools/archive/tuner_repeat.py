@@ -2,7 +2,7 @@
 """How often does the on-line tuner settle on the same layout?  N fresh contexts on one grid, each tuned inside one
 long call and timed afterwards.
 
-    python tools/tuner_repeat.py ROWS COLS [contexts=8] [steps=4000] [calls=1]
+    python tools/archive/tuner_repeat.py ROWS COLS [contexts=8] [steps=4000] [calls=1]
 
 Prints per context the layout the tuner kept after `calls` calls of `steps` steps (short calls never wait for the
 tuner's windows: a driver loop of 34-step calls is tuned over its first few hundred calls) and the rate of three

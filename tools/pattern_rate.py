@@ -2,7 +2,7 @@
 """Is the throughput data-independent?  Times 1000-step runs of the 16384^2 grid on two states in
 one context: the reference's benchmark input (Species::new: one seed in a uniform field) and a
 field with many seeds that develops into a full spot pattern.  (It is not: see
-profiles/r01_soak.md.)"""
+profiles/archive/r01_soak.md.)"""
 import os
 import sys
 

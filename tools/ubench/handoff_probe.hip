@@ -1,6 +1,6 @@
 // handoff_probe.hip -- what would trading aprons between workgroups INSIDE a launch cost?
 //
-// Emulates the exchange of a persistent window kernel for a 1080 x 1920 grid (profiles/r03_sweeps.md, section 3):
+// Emulates the exchange of a persistent window kernel for a 1080 x 1920 grid (profiles/archive/r03_sweeps.md, section 3):
 // 15 x 16 workgroups of 1024 threads, one per CU, each owning a 72 x 120 tile of two f32 planes.  Per iteration a
 // workgroup "computes" for a fixed time (a spin on s_memtime), stores the 4-cell ring of its tile (sc1 stores, 8 B
 // per lane), drains (s_waitcnt vmcnt(0) in every storing wave, workgroup barrier), publishes a flag (one lane, sc1
