@@ -42,13 +42,20 @@ def main():
     ap.add_argument("--data", default="new,developed")
     ap.add_argument("--flavours", default="strict.op.dx,strict.op.ds,strict.op,strict,fused", help="comma- or plus-separated")
     ap.add_argument("--profile", action="store_true", help="under rocprofv3: 40 steps per flavour, no sampling")
+    ap.add_argument("--heights", default="", help="comma-separated unit heights: the FIRST flavour of --flavours at each of them instead of the "
+                                                  "flavours side by side (rows recomputed at unit seams against launch rounds and tail)")
     a = ap.parse_args()
     rows, cols = a.rows, a.cols
     cells = rows * cols
     datas = a.data.split(",")
     sims = {}
+    wanted = a.flavours.replace("+", ",").split(",")
+    if a.heights:
+        name, kw = next((n, k) for n, k in FLAVOURS if n == wanted[0])
+        for h in (int(x) for x in a.heights.split(",")):
+            sims[f"{name}@{h}"] = [Simulation.new(Parameters(), HipArgs(devices=[0], rows_per_block=h, fuse_steps=4, cols_per_lane=2, **kw)), {}]
     for name, kw in FLAVOURS:
-        if name not in a.flavours.replace("+", ",").split(","):
+        if name not in wanted or a.heights:
             continue
         sim = Simulation.new(Parameters(), HipArgs(devices=[0], rows_per_block=a.rows_per_unit, fuse_steps=4,
                                                    cols_per_lane=2, **kw))

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
@@ -114,26 +115,29 @@ static void run(const char *name, K kernel, double lane_ops_per_lane_iter, doubl
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     iters = (int)(iters * 40.0 / ms);
-    const int launches = (int)(seconds * 1000.0 / 40.0);
-    // warm: half a second of load before the window (clocks, power state)
-    for (int i = 0; i < 12; ++i) hipLaunchKernelGGL(kernel, grid, block, 0, 0, d, iters, 1.0f);
-    hipDeviceSynchronize();
-    for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(kernel, grid, block, 0, 0, d, iters, 1.0f); // keeps the chip busy while rocm-smi starts
-    const double j0 = energy_uj();
-    const auto t0 = std::chrono::steady_clock::now();
+    // rate: a few launches between events
+    hipEventRecord(e0);
+    for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(kernel, grid, block, 0, 0, d, iters, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    const double rate = (double)grid.x * 256.0 * (double)iters * lane_ops_per_lane_iter * 8.0 / (ms * 1e-3);
+    // power: the slope of the card's energy counter between two readings taken WHILE a queue of launches that outlasts
+    // both keeps the chip under the same load (each reading is stamped with the middle of its rocm-smi call)
+    const int launches = (int)((seconds + 2.5) * 1000.0 / 40.0);
     for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(kernel, grid, block, 0, 0, d, iters, 1.0f);
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto reading = [&](double *t, double *uj) { const double a = now(); *uj = energy_uj(); *t = 0.5 * (a + now()); };
+    std::this_thread::sleep_for(std::chrono::milliseconds(600));
+    double ta, ea, tb, eb;
+    reading(&ta, &ea);
+    std::this_thread::sleep_for(std::chrono::milliseconds((int)(seconds * 1000)));
+    reading(&tb, &eb);
+    const bool busy = hipStreamQuery(0) == hipErrorNotReady; // the queue is still running
     hipDeviceSynchronize();
-    const auto t1 = std::chrono::steady_clock::now();
-    for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(kernel, grid, block, 0, 0, d, iters, 1.0f);
-    const double j1 = energy_uj();
-    hipDeviceSynchronize();
-    const double s = std::chrono::duration<double>(t1 - t0).count();
-    // the energy window is a little longer than the timed one (the reads bracket it with the chip kept busy): scale by the
-    // launches it covered -- 4 + launches + ~2 of the trailing 4 -- conservatively: report both bounds
-    const double ops = (double)grid.x * 256.0 * (double)iters * lane_ops_per_lane_iter * launches;
-    const double joules = (j1 - j0) * 1e-6;
-    std::printf("%-58s %8.2f T lane-ops/s  %7.1f W (window %.2f s)  %6.2f ... %6.2f pJ per lane-op\n", name, ops / s / 1e12, joules / (s * (launches + 6.0) / launches),
-                s, joules / (ops * (launches + 8.0) / launches) * 1e12, joules / (ops * (launches + 4.0) / launches) * 1e12);
+    const double watts = (eb - ea) * 1e-6 / (tb - ta);
+    std::printf("%-62s %8.2f T lane-ops/s  %7.1f W over %.2f s%s  %6.2f pJ per lane-op\n", name, rate / 1e12, watts, tb - ta, busy ? "" : " (QUEUE DRAINED EARLY)",
+                watts / rate * 1e12);
     std::fflush(stdout);
 }
 
