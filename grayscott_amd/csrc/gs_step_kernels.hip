@@ -207,19 +207,22 @@ hipError_t GS_SUFFIX(gs_launch_window)(const GsStepArgs &a, const GsWindowArgs &
 {
     // (5 rows per wave: 80-row windows.  The 96-row form of round 4 -- 6 rows per wave, 12 cells per lane -- spilled 43
     // registers in the strict build and tied with the marching kernel where it applied; it is gone.)
-    static const char *const names[2] = {"window-r5/" GS_MATH_NAME, "window-r5/" GS_MATH_NAME ".op"};
+    static const char *const names[3] = {"window-r5/" GS_MATH_NAME, "window-r5/" GS_MATH_NAME ".op", "window-r5/" GS_MATH_NAME ".op.ds"};
     if (a.rows <= 0 || a.cols <= 0 || a.top_present || a.bottom_present || rpw != 5 || x.steps < 1 || x.k < 2 ||
         x.k > 8 || (x.k & 1) || 2 * x.k >= win_rows(rpw) || 2 * x.k + 2 > kWinCols || !x.flags || !x.abort || !x.xu[0] || !x.xu[1] || !x.xv[0] || !x.xv[1])
         return hipErrorInvalidValue;
     if (!x.desc || x.n_windows < 1 || x.seq < 1) return hipErrorInvalidValue;
     // byte offsets inside a plane are 32-bit in the kernel
     if ((long)(a.rows + 8) * a.pitch * 4 > 0x7fffffffL) return hipErrorInvalidValue;
-    int fast = a.fast & (GS_MATH_FUSED ? 0 : 3);
-    if (fast != 3) fast = 0; // only the variant for the default parameters is built besides the general one
-    if (name) *name = names[fast ? 1 : 0];
+    int fast = a.fast & (GS_MATH_FUSED ? 0 : 7);
+    // only the variants for the default parameters are built besides the general one: .op, and .op.ds with full
+    // difference sharing inside a wave's band (gs_options.share_taps = 2 switches it off)
+    if ((fast & 3) != 3) fast = 0;
+    if (name) *name = names[fast == 7 ? 2 : (fast ? 1 : 0)];
     const void *fn = nullptr;
-#define GS_WIN_FN(R) (fast ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_window_k)<R, GS_MATH_FUSED ? 0 : 3>) \
-                           : reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_window_k)<R, 0>))
+#define GS_WIN_FN(R) (fast == 7 ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_window_k)<R, GS_MATH_FUSED ? 0 : 7>) \
+                      : fast    ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_window_k)<R, GS_MATH_FUSED ? 0 : 3>) \
+                                : reinterpret_cast<const void *>(&GS_SUFFIX(gs_run_window_k)<R, 0>))
     fn = GS_WIN_FN(5);
 #undef GS_WIN_FN
     const size_t lds = win_lds_bytes();

@@ -43,6 +43,21 @@ __host__ __device__ constexpr int win_rows(int rpw) { return kWinWaves * rpw; }
 // 2 buffers x 2 species x 16 waves x (first row, last row) x pitch
 __host__ __device__ constexpr size_t win_lds_bytes() { return (size_t)2 * 2 * kWinWaves * 2 * kWinPitch * sizeof(float); }
 
+// The S / SE / SW taps of the cells of row `z` with respect to the row `p` below it, in the slots cells_vshare (gs_march.h)
+// keeps them in: what that function leaves in its carry after the row z -- here for a row that is not updated at this
+// point (the row above a wave's band, which another wave owns; the band's first row, whose own update waits for the barrier).
+__device__ __forceinline__ TapCarry<2> win_carry_of(const GsStepArgs &a, const RowT<2> &z, const RowT<2> &p)
+{
+    TapCarry<2> c;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        c.s_u[i] = half_diff(p.u[i + 1], z.u[i + 1]);          c.s_v[i] = half_diff(p.v[i + 1], z.v[i + 1]);          // S of cell i + 1
+        c.se_u[i] = a.w[2][2] * (p.u[i + 1] - z.u[i]);         c.se_v[i] = a.w[2][2] * (p.v[i + 1] - z.v[i]);         // SE of cell i
+        c.sw_u[i] = a.w[2][0] * (p.u[i + 1] - z.u[i + 2]);     c.sw_v[i] = a.w[2][0] * (p.v[i + 1] - z.v[i + 2]);     // SW of cell i + 2
+    }
+    return c;
+}
+
 // `n` time steps of a window.  EDGE: 0 = window inside the grid; 1 = general path for every cell; 2 / 3 = window on the
 // grid's left / right edge, touching neither top nor bottom (cell<2> / cell<3>); 4 = window on the top or bottom edge
 // only (interior code but for the grid's first / last row, which take the general cell); 5 / 6 = corner windows,
@@ -128,6 +143,12 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
     // rows above and below from LDS, the band's first and last row.  (Reads first and the publish for the next step
     // right before the barrier -- the LDS latency behind the middle rows -- was measured: the waves of a workgroup
     // drift apart, 418 k against 461 k at 1080 x 1920, profiles/r04_window_kernel.md.)
+    // Full difference sharing inside a wave's band (windows inside the grid, FAST & 4: the stencil's diagonal weights pair
+    // up, strict build): the three taps a row takes from the row above it are, negated, the three taps that row took from
+    // this one -- cells_vshare, the marching kernel's form (gs_march.h), whose carry walks down the band.  Only the band's
+    // first row forms its N taps afresh (from the row another wave published), and the last row its S taps: 5 instead of
+    // 10 three-tap sets per species and band, 440 instead of 520 arithmetic instructions per wave and step.
+    constexpr bool SHARE = EDGE == 0 && (FAST & 5) == 5 && !GS_MATH_FUSED && RPW >= 3;
     for (int s = 0; s < n; ++s, ++step) {
         const int buf = step & 1;
         if constexpr (ROWS) {
@@ -135,6 +156,36 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
             grow = __builtin_amdgcn_readfirstlane(grow);
         }
         publish(buf);
+        if constexpr (SHARE) {
+            const RowT<2> first = widen(u[0], v[0]), second = widen(u[1], v[1]); // old rows 0 and 1: row 0 waits for the barrier
+            TapCarry<2> c = win_carry_of(a, first, second);                     // row 0's S / SE / SW taps: row 1's N / NW / NE
+            RowT<2> cur = second;
+            float nu[2], nv[2];
+#pragma unroll
+            for (int r = 1; r < RPW - 1; ++r) {
+                const RowT<2> next = widen(u[r + 1], v[r + 1]);                 // old row r + 1 (not overwritten yet)
+                cells_vshare<FAST, 2>(a, cur, next, c, nu, nv);
+                u[r][0] = nu[0]; u[r][1] = nu[1]; v[r][0] = nv[0]; v[r][1] = nv[1];
+                cur = next;
+            }
+            __syncthreads();
+            RowT<2> above, below;
+            {
+                auto get = [](const float *p, float (&w)[4]) { w[1] = p[0]; w[3] = p[1]; w[0] = p[kWinHalf - 1]; w[2] = p[kWinHalf]; };
+                get(row_of(buf, 0, wa, 1), above.u);
+                get(row_of(buf, 1, wa, 1), above.v);
+                get(row_of(buf, 0, wb, 0), below.u);
+                get(row_of(buf, 1, wb, 0), below.v);
+            }
+            // the band's last row: its N taps from the carry, its S taps from the row below it (another wave's)
+            cells_vshare<FAST, 2>(a, cur, below, c, nu, nv);
+            u[RPW - 1][0] = nu[0]; u[RPW - 1][1] = nu[1]; v[RPW - 1][0] = nv[0]; v[RPW - 1][1] = nv[1];
+            // the band's first row: the taps of the row above it (another wave's) formed here, its own S taps once more
+            TapCarry<2> ca = win_carry_of(a, above, first);
+            cells_vshare<FAST, 2>(a, first, second, ca, nu, nv);
+            u[0][0] = nu[0]; u[0][1] = nu[1]; v[0][0] = nv[0]; v[0][1] = nv[1];
+            continue;
+        }
         // Top down with a sliding window of widened OLD rows: a row is widened just before the row above it is
         // overwritten, so at most five widened rows are alive -- the window of three, old row 1 (kept for row 0) and
         // old row RPW - 2 (for the last row) -- instead of all RPW + 2.

@@ -34,11 +34,14 @@ def test_window_kernel_bit_exact(boundary, window_rows, k):
         u0, v0 = stress_fields(shape, 4)
         for steps in (1, 3, 8, 9, 22):
             ref_u, ref_v = oracle.run(u0, v0, steps, ftz=True, boundary=boundary)
-            got_u, got_v, info = gpu_run(u0, v0, steps, args=args(kernel=capi.GS_KERNEL_WINDOW, boundary=boundary,
-                                                                  rows_per_block=window_rows, fuse_steps=k))
-            assert info[0] == f"window-r{(window_rows or 80) // 16}/strict.op" and info[1] == 1, info    # ONE launch
-            assert_bits_equal(got_u, ref_u, f"window U {shape} steps {steps} k {k}")
-            assert_bits_equal(got_v, ref_v, f"window V {shape} steps {steps} k {k}")
+            # share_taps 0: the default form, full difference sharing inside a wave's band in the windows inside the grid
+            # (".op.ds", round 6); 2: without (".op", what ran until round 5) -- both against the oracle
+            for share, suffix in ((0, ".op.ds"), (2, ".op")) if k in (0, 4) else ((0, ".op.ds"),):
+                got_u, got_v, info = gpu_run(u0, v0, steps, args=args(kernel=capi.GS_KERNEL_WINDOW, boundary=boundary,
+                                                                      rows_per_block=window_rows, fuse_steps=k, share_taps=share))
+                assert info[0] == f"window-r{(window_rows or 80) // 16}/strict{suffix}" and info[1] == 1, info    # ONE launch
+                assert_bits_equal(got_u, ref_u, f"window U {shape} steps {steps} k {k} {suffix}")
+                assert_bits_equal(got_v, ref_v, f"window V {shape} steps {steps} k {k} {suffix}")
 
 
 def test_window_kernel_variants():
@@ -49,7 +52,8 @@ def test_window_kernel_variants():
             ref_u, ref_v = oracle.run(u0, v0, 19, params=oracle_params(params), ftz=True, boundary=boundary)
             got_u, got_v, info = gpu_run(u0, v0, 19, params=params, args=args(kernel=capi.GS_KERNEL_WINDOW, boundary=boundary))
             assert info[0].startswith("window-r5/strict"), info
-            assert info[0].endswith(".op") == (params.weights == Parameters().weights and params.time_step == 1.0), info
+            assert info[0].endswith(".op.ds") == (params.weights == Parameters().weights and params.time_step == 1.0), info
+            assert ".op" not in info[0] or info[0].endswith(".op.ds"), info
             assert_bits_equal(got_u, ref_u, f"window U {params}")
             assert_bits_equal(got_v, ref_v, f"window V {params}")
     ref_u, ref_v = oracle.run(u0, v0, 19, ftz=False)
@@ -89,7 +93,7 @@ def test_window_kernel_species_new_uneven_calls_and_single_steps():
     total = 0
     for steps in (1, 7, 256, 333, 403):
         sim.perform_steps(species, steps)
-        assert sim.context.info()[0] == "window-r5/strict.op"
+        assert sim.context.info()[0] == "window-r5/strict.op.ds"
         sim.perform_step(species)          # gs_step: the stream kernel, then back
         total += steps + 1
     u, v = oracle.run(u, v, total, ftz=True)
@@ -106,7 +110,7 @@ def test_config1_1080x1920_1000_steps_through_the_window_kernel():
     sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_WINDOW))
     species = sim.make_species([rows, cols])
     sim.perform_steps(species, steps)
-    assert sim.context.info() == ("window-r5/strict.op", 1)
+    assert sim.context.info() == ("window-r5/strict.op.ds", 1)
     u, v = oracle.run(*oracle.init_species(rows, cols), steps, ftz=True)
     in_u, in_v, _, _ = species.in_out()
     assert_bits_equal(in_u.make_scalar_view(sim.context), u, "config 1 U")
@@ -248,7 +252,7 @@ def test_window_kernel_soak_against_the_marching_kernel():
         sp = bench.upload_species(sim, u0, v0)
         for n in calls:
             sim.perform_steps(sp, n)
-        assert sim.context.info()[0] == "window-r5/strict.op"
+        assert sim.context.info()[0] == "window-r5/strict.op.ds"
         torch.cuda.synchronize()
         for name, a, b in (("U", sp.in_out()[0], sr.in_out()[0]), ("V", sp.in_out()[1], sr.in_out()[1])):
             (_, _, x), = a.torch_views()
