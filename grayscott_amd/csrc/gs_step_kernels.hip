@@ -272,8 +272,15 @@ static const void *tb_entry(int k, int fast, int cpl, int wg = 4)
             return gs_tb_op_kernel_strict(k, fast, cpl, 16);
 #endif
         }
+#if GS_MATH_FUSED
+        // (2 columns per lane need 129 registers in the fused flavour, one more than a wave of a 16-wave workgroup may have:
+        // the variant spilled a register to scratch; one-round launches of the fused flavour run as 4-wave workgroups)
+        if (cpl == 2) return nullptr;
+        return reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 0, 1, 16>);
+#else
         return cpl == 1 ? reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 0, 1, 16>)
                         : reinterpret_cast<const void *>(&GS_SUFFIX(gs_step_tb_k)<4, 0, 2, 16>);
+#endif
     }
     if (fast) {
 #if !GS_MATH_FUSED
