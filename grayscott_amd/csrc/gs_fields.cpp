@@ -159,7 +159,31 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
     if (st != GS_OK) return st;
     const float first_cost = cost_of(best);
     int drawn = 0;
+    // Test hook (tests/test_gpu_placement.py): GS_HIP_PLACE_FORCE="a,b,c,d" draws `candidates` blocks and then moves the
+    // planes to blocks a, b, c, d of those held (0-3: the planes' own, 4 and up: drawn), whatever the probes say -- every
+    // shape of move (a plane into a drawn block, chains, two planes swapping, a cycle through all four) on demand.
+    int forced[4] = {-1, -1, -1, -1};
+    if (const char *e = std::getenv("GS_HIP_PLACE_FORCE")) {
+        if (std::sscanf(e, "%d,%d,%d,%d", &forced[0], &forced[1], &forced[2], &forced[3]) != 4) forced[0] = -1;
+    }
     while (true) {
+        if (forced[0] >= 0) {
+            while (drawn < candidates) {
+                float *b = nullptr;
+                if (hipMalloc(reinterpret_cast<void **>(&b), bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+                blocks.push_back(b);
+                ++drawn;
+            }
+            bool ok = true;
+            for (int i = 0; i < 4; ++i) {
+                ok = ok && forced[i] >= 0 && forced[i] < (int)blocks.size();
+                for (int j = 0; j < i; ++j) ok = ok && forced[i] != forced[j];
+            }
+            if (!ok) { const int keep[4] = {0, 1, 2, 3}; release_extra(keep); return fail(GS_ERR_INVALID, "GS_HIP_PLACE_FORCE: four distinct blocks of those held"); }
+            std::memcpy(best, forced, sizeof best);
+            T.assign(blocks.size(), std::vector<float>(blocks.size(), T[0][1])); // (no probes: every pair reads alike)
+            break;
+        }
         search();
         // good enough?  Planes of >= 512 MiB are judged by the rate of the probe pass itself: 4 x bytes per pass at
         // >= 5.25 TB/s is a cross-group pair (5.4-6.0 TB/s measured on every box), less is a pair of one group
@@ -208,7 +232,7 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
     for (int i = 0; i < 4; ++i) chosen[(size_t)i] = blocks[(size_t)best[i]];
     // slot pairs are unordered, and so is the order of the two pairs: try the 8 equivalent arrangements, keep the one
     // that leaves most planes where they are
-    {
+    if (forced[0] < 0) {
         int keep_best = -1;
         std::vector<float *> pick = chosen;
         for (int v = 0; v < 8; ++v) {

@@ -51,6 +51,8 @@
  *                           of gs_fields_place
  *   Launch-policy switches for A/B timing (defaults are the measured best; grayscott_amd/csrc/gs_experiments.h):
  *     GS_HIP_PLACE_ALL      1 = gs_fields_place draws all its candidates even when two fast pairs are found before
+ *     GS_HIP_PLACE_FORCE    "a,b,c,d" = test hook: gs_fields_place draws its candidates and moves the planes to blocks a, b, c, d
+ *                           of those it holds (0-3 the planes' own, 4 and up drawn), without probes
  *     GS_HIP_EDGE_KINDS     0 = edge units of the marching kernel all take the general path
  *     GS_HIP_EDGE_SPLIT     0 / 1 = never / always dispatch edge units as two half-height units
  *     GS_HIP_FAIR           0 / 1 = never / always run one-round launches as in-step 16-wave workgroups

@@ -124,3 +124,31 @@ def test_placement_at_the_headline_size_separates_u_from_v():
         for (_, _, x), (_, _, y) in zip(a.torch_views(), b.torch_views()):
             assert torch.equal(x.view(torch.int32), y.view(torch.int32))
     sim.context.close()
+
+
+@pytest.mark.parametrize("force", ["1,0,3,2", "1,2,3,0", "4,0,1,2", "0,1,3,2", "5,4,1,0", "3,2,1,0", "0,1,2,3", "2,3,0,4"])
+def test_every_shape_of_move_keeps_every_plane(force, monkeypatch):
+    """The planes' moves are device copies one at a time, a plane moving when nobody holds its chosen block: chains resolve in
+    order, planes that wait for each other (swaps, a cycle through all four) go through a spare block.  GS_HIP_PLACE_FORCE
+    dictates the arrangement (0-3: the planes' own blocks, 4 and up: drawn ones); four planes with four different contents,
+    ghost rows included, must come out as they went in, and a simulation on them must go on bit for bit."""
+    monkeypatch.setenv("GS_HIP_PLACE_FORCE", force)
+    shape = (130, 257)
+    sim = Simulation.new(Parameters(), HipArgs(devices=[0]))
+    ctx = sim.context
+    u0, v0 = np.random.default_rng(7).random(shape, dtype=np.float32), np.random.default_rng(8).random(shape, dtype=np.float32) * np.float32(0.5)
+    from tests.helpers import species_from_arrays
+    sp = species_from_arrays(sim, u0, v0)
+    sim.perform_steps(sp, 6)                     # both slots hold a state, ghost rows are in use
+    before = [p.make_scalar_view(ctx).copy() for p in sp.in_out()]
+    first, best = sp.place(2)
+    assert first > 0 and best > 0
+    after = [p.make_scalar_view(ctx) for p in sp.in_out()]
+    for i, (a, b) in enumerate(zip(after, before)):
+        assert a.tobytes() == b.tobytes(), f"plane {i} changed under GS_HIP_PLACE_FORCE={force}"
+    sim.perform_steps(sp, 9)
+    ref_u, ref_v = oracle.run(u0, v0, 15, ftz=True)
+    in_u, in_v, _, _ = sp.in_out()
+    assert_bits_equal(in_u.make_scalar_view(ctx), ref_u, f"U after moves {force}")
+    assert_bits_equal(in_v.make_scalar_view(ctx), ref_v, f"V after moves {force}")
+    ctx.close()
