@@ -40,7 +40,7 @@ EXPORTS = (
     "gs_ctx_stats", "gs_ctx_set_pass_timing", "gs_field_mark_written", "gs_rccl_selftest",
     "gs_runtime_info", "gs_fields_place", "gs_debug_dyn_lds_key", "gs_debug_window_plan",
     "gs_debug_place_stats", "gs_debug_exchange_probe_create", "gs_debug_exchange_probe_run",
-    "gs_debug_exchange_probe_destroy",
+    "gs_debug_exchange_probe_destroy", "gs_download_wait_but",
 )
 
 
@@ -159,6 +159,7 @@ def load() -> ctypes.CDLL:
         "gs_runtime_info": (i32, [i32, ctypes.c_char_p, ctypes.c_size_t]),
         "gs_fields_place": (i32, [vp, P(vp), i32, P(f32), P(f32)]),
         "gs_debug_place_stats": (i32, [vp, P(u64), P(u64)]),
+        "gs_download_wait_but": (i32, [vp, i32]),
         "gs_debug_exchange_probe_create": (i32, [i32, i32, i32, u64, P(vp)]),
         "gs_debug_exchange_probe_run": (i32, [vp, P(f32), P(f32)]),
         "gs_debug_exchange_probe_destroy": (i32, [vp]),

@@ -566,12 +566,14 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
         if (sl.t0) (void)hipEventDestroy(sl.t0);
         if (sl.t1) (void)hipEventDestroy(sl.t1);
         if (sl.staged) (void)hipEventDestroy(sl.staged);
-        if (sl.copied) (void)hipEventDestroy(sl.copied);
+        for (auto e : sl.copied)
+            if (e) (void)hipEventDestroy(e);
         for (auto *v : {&sl.th0, &sl.th1, &sl.tc0, &sl.tc1})
             for (auto e : *v)
                 if (e) (void)hipEventDestroy(e);
         if (sl.copy) { (void)hipStreamSynchronize(sl.copy); (void)hipStreamDestroy(sl.copy); }
-        if (sl.stage) (void)hipFree(sl.stage);
+        for (auto p : sl.stage)
+            if (p) (void)hipFree(p);
         if (sl.halo) (void)hipStreamDestroy(sl.halo);
         if (sl.compute) (void)hipStreamDestroy(sl.compute);
     }
@@ -685,7 +687,8 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
         GS_HIP_B(hipStreamCreateWithPriority(&sl.halo, hipStreamNonBlocking, greatest));
         GS_HIP_B(hipStreamCreateWithFlags(&sl.copy, hipStreamNonBlocking));
         GS_HIP_B(hipEventCreateWithFlags(&sl.staged, hipEventDisableTiming));
-        GS_HIP_B(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+        GS_HIP_B(hipEventCreateWithFlags(&sl.copied[0], hipEventDisableTiming));
+        GS_HIP_B(hipEventCreateWithFlags(&sl.copied[1], hipEventDisableTiming));
         for (int k = 0; k < 2; ++k) {
             GS_HIP_B(hipEventCreateWithFlags(&sl.done[k], hipEventDisableTiming));
             GS_HIP_B(hipEventCreateWithFlags(&sl.halod[k], hipEventDisableTiming));

@@ -466,35 +466,38 @@ int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host)
     }
     const uint64_t first = f->s.front().g_row0;
     const int last = (int)((ctx->step_no + 1) & 1); // parity of the most recent pass
+    const int k = (int)(ctx->downloads & 1);        // the staging buffer of this image
     for (size_t i = 0; i < f->s.size(); ++i) {
         SlabRt &sl = ctx->slabs[i];
         const FieldSlab &fs = f->s[i];
         GS_HIP(hipSetDevice(sl.device));
         const size_t need = (size_t)fs.rows * f->cols;
-        if (sl.stage_floats < need) {
+        if (sl.stage_floats[k] < need) {
             GS_HIP(hipStreamSynchronize(sl.copy));
-            if (sl.stage) GS_HIP(hipFree(sl.stage));
-            sl.stage = nullptr;
-            sl.stage_floats = 0;
-            hipError_t e = hipMalloc(reinterpret_cast<void **>(&sl.stage), need * sizeof(float));
+            if (sl.stage[k]) GS_HIP(hipFree(sl.stage[k]));
+            sl.stage[k] = nullptr;
+            sl.stage_floats[k] = 0;
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&sl.stage[k]), need * sizeof(float));
             if (e != hipSuccess) return fail(GS_ERR_NOMEM, "staging buffer: %s", hipGetErrorString(e));
-            sl.stage_floats = need;
+            sl.stage_floats[k] = need;
         }
-        // the previous image must have left the staging buffer; on a slab chain the boundary
-        // rows of the newest plane come from the halo stream
-        GS_HIP(hipStreamWaitEvent(sl.compute, sl.copied, 0));
+        // the image before the previous one must have left this staging buffer (a wait on the GPU, not on the host: the
+        // previous image's host copy goes on meanwhile); on a slab chain the boundary rows of the newest plane come from
+        // the halo stream
+        GS_HIP(hipStreamWaitEvent(sl.compute, sl.copied[k], 0));
         if (ctx->total_slabs() > 1 && ctx->step_no > 0) GS_HIP(hipStreamWaitEvent(sl.compute, sl.halod[last], 0));
         if (i == 0) GS_TRY(join_bands(ctx, sl.compute));
-        GS_HIP(hipMemcpy2DAsync(sl.stage, (size_t)f->cols * sizeof(float), fs.row0, (size_t)f->pitch * sizeof(float),
+        GS_HIP(hipMemcpy2DAsync(sl.stage[k], (size_t)f->cols * sizeof(float), fs.row0, (size_t)f->pitch * sizeof(float),
                                 (size_t)f->cols * sizeof(float), (size_t)fs.rows, hipMemcpyDeviceToDevice, sl.compute));
         GS_HIP(hipEventRecord(sl.staged, sl.compute));
         GS_HIP(hipStreamWaitEvent(sl.copy, sl.staged, 0));
-        GS_HIP(hipMemcpyAsync(host + (fs.g_row0 - first) * f->cols, sl.stage, need * sizeof(float),
+        GS_HIP(hipMemcpyAsync(host + (fs.g_row0 - first) * f->cols, sl.stage[k], need * sizeof(float),
                               hipMemcpyDeviceToHost, sl.copy));
         if (w.pending && i == 0) // the abort word as it stands once the launches this image depends on have ended
             GS_HIP(hipMemcpyAsync(w.seen, w.words + kWindowMaxTiles, sizeof(int32_t), hipMemcpyDeviceToHost, sl.copy));
-        GS_HIP(hipEventRecord(sl.copied, sl.copy));
+        GS_HIP(hipEventRecord(sl.copied[k], sl.copy));
     }
+    ctx->downloads++;
     return GS_OK;
 }
 
@@ -527,22 +530,31 @@ int32_t gs_field_colormap(gs_ctx *ctx, gs_field *f, float scale, const uint8_t *
     return GS_OK;
 }
 
-int32_t gs_download_wait(gs_ctx *ctx)
+// Wait until at most `in_flight` (0 or 1) of the images enqueued so far are still on their way.  1 is what a driver
+// loop with two images in flight calls (the reference's writer thread takes images through a channel two deep,
+// simulate/src/main.rs:29-43, 73-87): the host copy of the newest image goes on while the one before it is handed on, so the
+// PCIe link never idles between two images.
+int32_t gs_download_wait_but(gs_ctx *ctx, int32_t in_flight)
 {
     if (!ctx) return fail(GS_ERR_INVALID, "null context");
+    if (in_flight < 0 || in_flight > 1) return fail(GS_ERR_INVALID, "0 or 1 images may stay in flight, not %d", in_flight);
+    if (in_flight == 1 && ctx->downloads < 2) return GS_OK; // nothing older than the newest
     for (auto &sl : ctx->slabs) {
         GS_HIP(hipSetDevice(sl.device));
-        GS_HIP(hipStreamSynchronize(sl.copy));
+        if (in_flight == 0) GS_HIP(hipStreamSynchronize(sl.copy));
+        else GS_HIP(hipEventSynchronize(sl.copied[(ctx->downloads - 2) & 1])); // the image before the newest
     }
     // images enqueued behind persistent window launches: did one of those launches give up?  (Then the launches are run
     // again with the marching kernel and the images fetched again: resolve_window.)  The launches that are still running
-    // stay pending; only the images are settled here.
+    // stay pending; only the images waited for are settled here.
     gs_ctx::WindowRt &w = ctx->win;
     if (!w.images.empty()) {
         if (w.seen && *w.seen != 0) GS_TRY(resolve_window(ctx));
-        w.images.clear();
+        if (w.images.size() > (size_t)in_flight) w.images.erase(w.images.begin(), w.images.end() - in_flight);
     }
     return GS_OK;
 }
+
+int32_t gs_download_wait(gs_ctx *ctx) { return gs_download_wait_but(ctx, 0); }
 
 } // extern "C"

@@ -92,9 +92,11 @@ struct SlabRt {
     hipStream_t compute = nullptr, halo = nullptr, copy = nullptr;
     hipEvent_t done[2] = {nullptr, nullptr}, halod[2] = {nullptr, nullptr};
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    hipEvent_t staged = nullptr, copied = nullptr; // asynchronous downloads
-    float *stage = nullptr;                        // dense device staging buffer
-    size_t stage_floats = 0;
+    // asynchronous downloads: two dense device staging buffers used in turn, so that the host copy of one image and the
+    // staging copy of the next overlap (copied[k]: the host copy that last read stage[k] is done)
+    hipEvent_t staged = nullptr, copied[2] = {nullptr, nullptr};
+    float *stage[2] = {nullptr, nullptr};
+    size_t stage_floats[2] = {0, 0};
     // gs_ctx_set_pass_timing: per timed pass, events around the halo stream's work (boundary-band kernel +
     // ghost-row exchange: th0, th1) and around the interior kernel on the compute stream (tc0, tc1)
     std::vector<hipEvent_t> th0, th1, tc0, tc1;
@@ -120,6 +122,7 @@ struct gs_ctx {
     const char *last_kernel = "none";
     uint64_t launches = 0;
     uint64_t passes = 0, steps_done = 0, ghost_refreshes = 0; // gs_ctx_stats
+    uint64_t downloads = 0;                                   // images enqueued with gs_field_download_async so far
     uint64_t place_probes = 0, place_drawn = 0;               // gs_fields_place: pair probes timed, extra blocks drawn (gs_debug_place_stats)
     int pass_timing = 0;                                      // passes per slab still to be timed (0 = off)
     // Configuration of the temporally blocked kernel in force (tuned_rpu > 0): unit height, fused steps

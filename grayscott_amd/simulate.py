@@ -104,7 +104,7 @@ def run(args, hip_args: HipArgs | None = None, out=None) -> dict:
     # I/O thread: writes images down and recycles their buffers (main.rs:73-87)
     full: "queue.Queue" = queue.Queue(maxsize=args.output_buffer)
     free: "queue.Queue" = queue.Queue()
-    for _ in range(args.output_buffer + 1):            # +1: the image being downloaded
+    for _ in range(args.output_buffer + 2):            # +2: the two images on their way from the device
         free.put(pinned_empty(shape))
     errors = []
     failed = threading.Event()
@@ -132,21 +132,24 @@ def run(args, hip_args: HipArgs | None = None, out=None) -> dict:
     thread = threading.Thread(target=writer, daemon=True)
     thread.start()
     t0 = time.perf_counter()
-    pending = None
+    pending = []                                            # images on their way from the device, oldest first (at most 2)
     try:
         for _ in range(args.nbimage):
             image = free.get()
             if failed.is_set() or image is None:
                 break
-            sim.prepare_steps(species, steps_per_image)     # enqueued behind the previous staging copy
-            if pending is not None:
-                ctx.download_wait()                         # previous image is complete ...
-                full.put(pending)                           # ... hand it to the I/O thread
-            species.write_result_view_after(image)          # this image: staged + copied while we go on
-            pending = image
-        if pending is not None and not failed.is_set():
+            sim.prepare_steps(species, steps_per_image)     # enqueued; nothing here waits for the device
+            species.write_result_view_after(image)          # this image: staged + copied behind those steps while we go on
+            pending.append(image)
+            if len(pending) == 2:
+                # two images in flight (the library stages them in two buffers in turn): the host copy of the newer one
+                # overlaps the next steps AND the hand-over of the older one, so the PCIe link never idles between images
+                ctx.download_wait(in_flight=1)              # the older image is complete ...
+                full.put(pending.pop(0))                    # ... hand it to the I/O thread
+        if pending and not failed.is_set():
             ctx.download_wait()
-            full.put(pending)
+            for image in pending:
+                full.put(image)
     finally:
         full.put(None)
         thread.join()

@@ -152,9 +152,10 @@ class HipContext:
     def sync(self) -> None:
         capi.check(self._lib.gs_sync(self.handle))
 
-    def download_wait(self) -> None:
-        """Wait for the asynchronous downloads enqueued so far (not for later steps)."""
-        capi.check(self._lib.gs_download_wait(self.handle))
+    def download_wait(self, in_flight: int = 0) -> None:
+        """Wait for the asynchronous downloads enqueued so far (not for later steps); ``in_flight=1``: for all but the
+        newest (``gs_download_wait_but``: two images on their way, the PCIe link never idles between them)."""
+        capi.check(self._lib.gs_download_wait_but(self.handle, int(in_flight)))
 
     def timer_start(self) -> None:
         capi.check(self._lib.gs_timer_start(self.handle))

@@ -106,6 +106,8 @@ class HipContext {
     void sync() const { check(gs_sync(ctx_)); }
     // waits for the asynchronous downloads enqueued so far (not for later steps)
     void download_wait() const { check(gs_download_wait(ctx_)); }
+    // ... for all but the newest `in_flight` (0 or 1): two images on their way, the PCIe link never idles between them
+    void download_wait_but(int32_t in_flight) const { check(gs_download_wait_but(ctx_, in_flight)); }
     // counters of the context (passes, steps, launches, blocking ghost refreshes) and, on slab chains, the
     // halo-stream / interior times of the passes timed with set_pass_timing (gs_ctx_stats)
     gs_stats stats() const

@@ -313,11 +313,15 @@ int32_t gs_sync(gs_ctx *ctx);
  *                                  a persistent window launch (1080 x 1920 in long calls), which may
  *                                  still give up, the image is validated when it is waited for -- a
  *                                  launch that gave up is then run again and the image fetched again.
- *   gs_download_wait               wait for the downloads enqueued so far (not for later steps) */
+ *   gs_download_wait               wait for the downloads enqueued so far (not for later steps)
+ *   gs_download_wait_but           ... for all but the newest `in_flight` (0 or 1) of them: with two images in flight
+ *                                  (two staging buffers are used in turn) the host copy of one image overlaps the
+ *                                  staging of the next and the hand-over of the one before: the PCIe link stays busy */
 int32_t gs_host_alloc(void **out, uint64_t bytes);
 int32_t gs_host_free(void *p);
 int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host);
 int32_t gs_download_wait(gs_ctx *ctx);
+int32_t gs_download_wait_but(gs_ctx *ctx, int32_t in_flight);
 
 /* The per-pixel work of data-to-pics (data-to-pics/src/main.rs:139-144, ui/src/lib.rs:113-123): paint this
  * process's rows of `f` (the reference paints the V plane) into dense RGB8 [rows, cols, 3] through a

@@ -103,6 +103,7 @@ extern "C" {
     pub fn gs_sync(ctx: *mut gs_ctx) -> i32;
     pub fn gs_field_download_async(ctx: *mut gs_ctx, f: *mut gs_field, host: *mut f32) -> i32;
     pub fn gs_download_wait(ctx: *mut gs_ctx) -> i32;
+    pub fn gs_download_wait_but(ctx: *mut gs_ctx, in_flight: i32) -> i32;
     pub fn gs_field_colormap(
         ctx: *mut gs_ctx,
         f: *mut gs_field,

@@ -335,6 +335,13 @@ impl Simulation {
     pub fn download_wait(&self) -> Result<(), HipError> {
         check(unsafe { ffi::gs_download_wait(self.context.0) })
     }
+
+    /// ... for all but the newest `in_flight` (0 or 1) of them: with two images on their way (the library stages
+    /// them in two buffers in turn) the PCIe link never idles between images -- what `simulate`'s image channel
+    /// of depth 2 (simulate/src/main.rs:29-43) allows
+    pub fn download_wait_but(&self, in_flight: i32) -> Result<(), HipError> {
+        check(unsafe { ffi::gs_download_wait_but(self.context.0, in_flight) })
+    }
 }
 
 impl HipConcentration {

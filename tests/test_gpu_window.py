@@ -295,8 +295,9 @@ def test_images_enqueued_behind_window_launches_never_wait_and_are_right(monkeyp
             t0 = time.perf_counter()
             sp.write_result_view_after(images[i])
             enqueue_s.append(time.perf_counter() - t0)
-            if i % 2 == 1:                       # two images in flight at a time
-                sim.context.download_wait()
+            sim.context.download_wait(in_flight=1)   # two images in flight: the one before this is complete on return
+            if i:
+                assert_bits_equal(images[i - 1], refs[i - 1], f"image {i - 1} when handed over (give up from call {give_up_from})")
         sim.context.download_wait()
         st = sim.context.stats()
         for i in range(calls):

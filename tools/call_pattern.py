@@ -37,7 +37,7 @@ def main():
         sim.perform_steps(sp, 4000)                       # on-line tuning done
         sims[name] = (sim, sp)
     image = np.empty((a.rows, a.cols), np.float32)
-    pinned = [pinned_empty((a.rows, a.cols)) for _ in range(2)]
+    pinned = [pinned_empty((a.rows, a.cols)) for _ in range(3)]
     # the floor a download per call sets: images back to back through the overlapped path, no steps in between
     sim0, sp0 = sims["marching"]
     for _ in range(2):
@@ -46,9 +46,15 @@ def main():
             sp0.write_result_view_after(pinned[i & 1])
             sim0.context.download_wait()
         per_image = (time.perf_counter() - t0) / 100
-    print(f"an image alone (staging copy + {cells * 4 / 1e6:.1f} MB over PCIe into pinned memory + wait), back to back: {per_image * 1e6:.0f} us = "
-          f"{cells * 4 / per_image / 1e9:.1f} GB/s: a call of n steps with a download each cannot beat {cells / per_image / 1e6:,.0f} x n Mcells x steps / s "
-          f"(n = 32: {32 * cells / per_image / 1e6:,.0f})")
+        t0 = time.perf_counter()
+        for i in range(100):
+            sp0.write_result_view_after(pinned[i % 3])
+            sim0.context.download_wait(in_flight=1)
+        sim0.context.download_wait()
+        per_image_2 = (time.perf_counter() - t0) / 100
+    print(f"an image alone (staging copy + {cells * 4 / 1e6:.1f} MB over PCIe into pinned memory + wait), back to back, one at a time: {per_image * 1e6:.0f} us = "
+          f"{cells * 4 / per_image / 1e9:.1f} GB/s; two in flight: {per_image_2 * 1e6:.0f} us = {cells * 4 / per_image_2 / 1e9:.1f} GB/s: a call of n steps "
+          f"with a download each cannot beat {cells / per_image_2 / 1e6:,.0f} x n Mcells x steps / s (n = 32: {32 * cells / per_image_2 / 1e6:,.0f})")
     print(f"grid {a.rows} x {a.cols}, {a.calls} calls per figure, median of 3; Mcells x steps / s")
     print("| steps per call | kernel (label) | steps only | + blocking V download | + overlapped V download |")
     print("|---|---|---|---|---|")
@@ -67,11 +73,12 @@ def main():
                     sp.write_result_view(image)
 
             def overlapped():
+                # the driver loop of grayscott_amd/simulate.py: two images in flight
                 for i in range(calls):
                     sim.prepare_steps(sp, n)
+                    sp.write_result_view_after(pinned[i % 3])
                     if i:
-                        ctx.download_wait()
-                    sp.write_result_view_after(pinned[i & 1])
+                        ctx.download_wait(in_flight=1)
                 ctx.download_wait()
                 ctx.sync()
 
