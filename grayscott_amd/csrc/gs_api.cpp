@@ -858,7 +858,7 @@ int32_t run_steps(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_fiel
         const bool forced = ctx->o.kernel == GS_KERNEL_WINDOW;
         const bool automatic = ctx->o.kernel == GS_KERNEL_AUTO && ctx->o.fuse_steps == 0 && ctx->o.rows_per_block == 0 &&
                                ctx->o.cols_per_lane == 0 && ctx->o.split <= 1 && !ctx->o.use_graph && cells >= kTileAutoCells &&
-                               steps >= 64;
+                               steps >= 32; // (from the reference's 32 steps per image on: profiles/r06_window_kernel.md)
         if (forced || automatic) {
             int32_t launched = 0;
             GS_TRY(run_window(ctx, r, steps, forced, &launched, result_slot));

@@ -111,7 +111,7 @@ typedef enum gs_math { GS_MATH_STRICT = 0, GS_MATH_FUSED = 1 } gs_math;
 
 /* Which step kernel runs.  AUTO = STREAM for a single gs_step; inside gs_run, by grid size when nothing
  * is pinned: the LDS-resident whole-run kernel up to 1536 cells, TILE up to 1.5 M cells, WINDOW for calls of
- * >= 64 steps on grids of one round of 80-row windows, TB with fuse_steps (default 4) otherwise, for slab
+ * >= 32 steps on grids of one round of 80-row windows, TB with fuse_steps (default 4) otherwise, for slab
  * chains and whenever fuse_steps, rows_per_block, cols_per_lane, split or use_graph pin a schedule. */
 typedef enum gs_kernel {
     GS_KERNEL_AUTO = 0,    /* best measured variant for the shape                          */
@@ -129,7 +129,7 @@ typedef enum gs_kernel {
                               cells + a k-cell apron; lower windows on the grid's left and right edge, whose cells cost
                               more) in registers and trades its apron with its neighbours every k steps through
                               exchange planes, flags and sc1 accesses (fuse_steps = k: 2, 4, 6 or 8; rows_per_block =
-                              full window rows: 80).  What AUTO runs for calls of >= 64 steps where such windows cover the
+                              full window rows: 80).  What AUTO runs for calls of >= 32 steps where such windows cover the
                               grid: 496 k against TB's 395 k Mcells x steps / s at 1080 x 1920 in 1000-step calls; in
                               32-step calls the two tie (profiles/r05_window_kernel.md).
                               A launch whose workgroups are not all resident (another long-running kernel holds CUs)

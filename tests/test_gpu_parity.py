@@ -148,7 +148,7 @@ def test_ftz_rule_matches_cpu_flush_to_zero():
 # ---- BASELINE config 1: 1080 x 1920, Species::new, default feed/kill, 1000 steps -----------
 @pytest.mark.parametrize("kernel,label", [(capi.GS_KERNEL_AUTO, "window-r5/strict.op"), (capi.GS_KERNEL_TB, "tb-k")])
 def test_config1_1080x1920_1000_steps(kernel, label):
-    """As the library runs it by default (one persistent launch of the window kernel for a call of >= 64 steps on a grid of
+    """As the library runs it by default (one persistent launch of the window kernel for a call of >= 32 steps on a grid of
     one round of windows) and with the marching kernel, which ran it until round 4 and still runs short calls."""
     rows, cols, steps = 1080, 1920, 1000
     sim = Simulation.new(Parameters(), args(kernel=kernel))

@@ -152,7 +152,7 @@ def test_a_launch_that_gives_up_is_run_again_by_the_marching_kernel(monkeypatch)
     monkeypatch.setenv("GS_HIP_WINDOW_PATIENCE", "1")
     rows, cols = 1080, 1920
     u0, v0 = stress_fields((rows, cols), 5)
-    sim = Simulation.new(Parameters(), args())           # kernel = auto: the window kernel for calls of >= 64 steps
+    sim = Simulation.new(Parameters(), args())           # kernel = auto: the window kernel for calls of >= 32 steps
     sp = species_from_arrays(sim, u0, v0)
     sim.prepare_steps(sp, 400)                           # two calls in flight, the second with an odd step count
     sim.prepare_steps(sp, 77)
@@ -211,11 +211,11 @@ def test_only_the_launch_that_gave_up_and_the_later_ones_are_run_again(monkeypat
 
 
 def test_what_kernel_auto_picks_around_the_window_kernel():
-    """kernel = auto: the window kernel for calls of >= 64 steps on single-slab grids from 1.5 M cells up to one window per
+    """kernel = auto: the window kernel for calls of >= 32 steps (the reference's steps per image) on single-slab grids from 1.5 M cells up to one window per
     compute unit when nothing is pinned; the marching kernel for short calls, pinned schedules, slab chains, larger grids."""
     u0, v0 = stress_fields((1080, 1920), 3)
-    ref = {n: oracle.run(u0, v0, n, ftz=True) for n in (64, 40)}
-    for kw, steps, want in ((dict(), 64, "window-r5/"), (dict(), 40, "tb-k"), (dict(fuse_steps=4), 64, "tb-k"),
+    ref = {n: oracle.run(u0, v0, n, ftz=True) for n in (64, 32, 28)}
+    for kw, steps, want in ((dict(), 64, "window-r5/"), (dict(), 32, "window-r5/"), (dict(), 28, "tb-k"), (dict(fuse_steps=4), 64, "tb-k"),
                             (dict(rows_per_block=10), 64, "tb-k"), (dict(devices=[0, 0]), 64, "tb-k"),
                             (dict(boundary=capi.GS_BOUNDARY_ZERO_HALO), 64, "window-r5/")):
         got_u, got_v, info = gpu_run(u0, v0, steps, args=HipArgs(**{"devices": [0], **kw}))
