@@ -568,7 +568,6 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
         if (sl.staged) (void)hipEventDestroy(sl.staged);
         for (auto e : sl.copied)
             if (e) (void)hipEventDestroy(e);
-        if (sl.produced) (void)hipEventDestroy(sl.produced);
         for (auto *v : {&sl.th0, &sl.th1, &sl.tc0, &sl.tc1})
             for (auto e : *v)
                 if (e) (void)hipEventDestroy(e);
@@ -688,7 +687,6 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
         GS_HIP_B(hipStreamCreateWithPriority(&sl.halo, hipStreamNonBlocking, greatest));
         GS_HIP_B(hipStreamCreateWithFlags(&sl.copy, hipStreamNonBlocking));
         GS_HIP_B(hipEventCreateWithFlags(&sl.staged, hipEventDisableTiming));
-        GS_HIP_B(hipEventCreateWithFlags(&sl.produced, hipEventDisableTiming));
         GS_HIP_B(hipEventCreateWithFlags(&sl.copied[0], hipEventDisableTiming));
         GS_HIP_B(hipEventCreateWithFlags(&sl.copied[1], hipEventDisableTiming));
         for (int k = 0; k < 2; ++k) {
@@ -740,8 +738,6 @@ int32_t gs_step(gs_ctx *ctx, gs_field *in_u, gs_field *in_v, gs_field *out_u, gs
 {
     GS_TRY(check_step_fields(ctx, in_u, in_v, out_u, out_v));
     GS_TRY(resolve_window(ctx));
-    GS_TRY(wait_direct(ctx, nullptr, nullptr));
-    ctx->last_was_window = false;
     return step_impl(ctx, in_u, in_v, out_u, out_v);
 }
 
@@ -869,11 +865,9 @@ int32_t run_steps(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_fiel
             if (launched) return GS_OK;
         }
     }
-    // every other kernel reads or overwrites planes that a window launch still in flight may own -- or that a direct
-    // download still reads (the marching kernel writes both slots within two passes)
+    // every other kernel reads or overwrites planes that a window launch still in flight may own
+    // every other kernel reads or overwrites planes that a window launch still in flight may own
     GS_TRY(resolve_window(ctx));
-    GS_TRY(wait_direct(ctx, nullptr, nullptr));
-    ctx->last_was_window = false;
     // The short pass goes first so that a run ends on a full pass -- a full-depth ghost exchange -- and the
     // next run can start without a blocking refresh.  It is sized with the steps per pass in force (a
     // configuration handed in through gs_ctx_set_tuned may fuse fewer steps than `fuse`), which is known

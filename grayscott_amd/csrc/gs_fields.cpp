@@ -12,9 +12,6 @@ int32_t gs_field_destroy(gs_ctx *ctx, gs_field *f)
 {
     if (!f) return GS_OK;
     if (ctx) (void)sync_all(ctx);
-    if (ctx)
-        for (auto &src : ctx->direct_src)
-            if (src == f) src = nullptr; // (its copy has ended: sync_all waits for the copy stream)
     for (size_t i = 0; i < f->s.size(); ++i)
         if (f->s[i].alloc) {
             if (ctx && i < ctx->slabs.size()) (void)hipSetDevice(ctx->slabs[i].device);
@@ -469,33 +466,12 @@ int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host)
     }
     const uint64_t first = f->s.front().g_row0;
     const int last = (int)((ctx->step_no + 1) & 1); // parity of the most recent pass
-    const int k = (int)(ctx->downloads & 1);        // the ring slot (staging buffer, completion event) of this image
-    // Behind a persistent window launch, a dense plane on a single slab is copied to the host STRAIGHT from the plane, on
-    // the copy stream: the next window launch only reads that plane and starts at once, instead of behind a staging copy
-    // on the compute stream (10 us of a 170 us call at 1080 x 1920).  Whoever writes the plane later waits for the copy
-    // (wait_direct).  Everything else goes through the staging buffers: the marching kernel overwrites both slots within
-    // two passes and must not wait for PCIe.
-    const bool direct = ctx->last_was_window && ctx->slabs.size() == 1 && ctx->total_slabs() == 1 && f->pitch == (int32_t)f->cols;
-    if (ctx->direct_src[k]) { // the copy that used this ring slot two images ago: retire it before the slot is reused
-        GS_HIP(hipSetDevice(ctx->slabs[0].device));
-        GS_HIP(hipStreamWaitEvent(ctx->slabs[0].compute, ctx->slabs[0].copied[k], 0));
-        ctx->direct_src[k] = nullptr;
-    }
+    const int k = (int)(ctx->downloads & 1);        // the staging buffer of this image
     for (size_t i = 0; i < f->s.size(); ++i) {
         SlabRt &sl = ctx->slabs[i];
         const FieldSlab &fs = f->s[i];
         GS_HIP(hipSetDevice(sl.device));
         const size_t need = (size_t)fs.rows * f->cols;
-        if (direct) {
-            if (i == 0) GS_TRY(join_bands(ctx, sl.compute));
-            GS_HIP(hipEventRecord(sl.produced, sl.compute));
-            GS_HIP(hipStreamWaitEvent(sl.copy, sl.produced, 0));
-            GS_HIP(hipMemcpyAsync(host + (fs.g_row0 - first) * f->cols, fs.row0, need * sizeof(float), hipMemcpyDeviceToHost, sl.copy));
-            if (w.pending) GS_HIP(hipMemcpyAsync(w.seen, w.words + kWindowMaxTiles, sizeof(int32_t), hipMemcpyDeviceToHost, sl.copy));
-            GS_HIP(hipEventRecord(sl.copied[k], sl.copy));
-            ctx->direct_src[k] = f;
-            continue;
-        }
         if (sl.stage_floats[k] < need) {
             GS_HIP(hipStreamSynchronize(sl.copy));
             if (sl.stage[k]) GS_HIP(hipFree(sl.stage[k]));

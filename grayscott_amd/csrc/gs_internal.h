@@ -95,7 +95,6 @@ struct SlabRt {
     // asynchronous downloads: two dense device staging buffers used in turn, so that the host copy of one image and the
     // staging copy of the next overlap (copied[k]: the host copy that last read stage[k] is done)
     hipEvent_t staged = nullptr, copied[2] = {nullptr, nullptr};
-    hipEvent_t produced = nullptr; // direct downloads: the work that leaves the image in its plane has been enqueued up to here
     float *stage[2] = {nullptr, nullptr};
     size_t stage_floats[2] = {0, 0};
     // gs_ctx_set_pass_timing: per timed pass, events around the halo stream's work (boundary-band kernel +
@@ -124,12 +123,6 @@ struct gs_ctx {
     uint64_t launches = 0;
     uint64_t passes = 0, steps_done = 0, ghost_refreshes = 0; // gs_ctx_stats
     uint64_t downloads = 0;                                   // images enqueued with gs_field_download_async so far
-    // Direct downloads (gs_field_download_async behind a persistent window launch, dense planes): the host copy reads the
-    // PLANE on the copy stream, no staging copy on the compute stream -- the next window launch only reads that plane and
-    // starts at once.  direct_src[k]: the plane a copy that may still be running reads (ring slot k); whoever enqueues a
-    // kernel that WRITES it makes the compute stream wait for copied[k] first (wait_direct).
-    gs_field *direct_src[2] = {nullptr, nullptr};
-    bool last_was_window = false; // the newest launch was a persistent window launch
     uint64_t place_probes = 0, place_drawn = 0;               // gs_fields_place: pair probes timed, extra blocks drawn (gs_debug_place_stats)
     int pass_timing = 0;                                      // passes per slab still to be timed (0 = off)
     // Configuration of the temporally blocked kernel in force (tuned_rpu > 0): unit height, fused steps
@@ -261,8 +254,6 @@ std::vector<GsWindowDesc> plan_windows(int cu_count, bool zero_halo, bool cheap,
                                        int *rpw_out, int *k_out);
 int32_t ensure_window_rt(gs_ctx *ctx, const gs_field *f);
 int32_t resolve_window(gs_ctx *ctx);
-// before a kernel that writes planes `a` and `b` is enqueued (both null: any planes): direct downloads that still read them
-int32_t wait_direct(gs_ctx *ctx, const gs_field *a, const gs_field *b);
 int32_t run_window(gs_ctx *ctx, Run &r, uint64_t steps, bool forced, int32_t *launched, int32_t *result_slot);
 
 // ---- gs_run: state of one call -------------------------------------------------------------------------------------

@@ -127,19 +127,6 @@ int32_t ensure_window_rt(gs_ctx *ctx, const gs_field *f)
 // order, with the marching kernel -- each from its own input planes, which are intact -- their results put where gs_run
 // said they would be, and the context stays with the marching kernel.  Called by everything that waits for or reads
 // results.
-int32_t wait_direct(gs_ctx *ctx, const gs_field *a, const gs_field *b)
-{
-    for (int k = 0; k < 2; ++k) {
-        const gs_field *src = ctx->direct_src[k];
-        if (!src || !((!a && !b) || src == a || src == b)) continue;
-        SlabRt &sl = ctx->slabs[0]; // (direct downloads exist on single-slab contexts only)
-        GS_HIP(hipSetDevice(sl.device));
-        GS_HIP(hipStreamWaitEvent(sl.compute, sl.copied[k], 0));
-        ctx->direct_src[k] = nullptr; // everything enqueued on the compute stream from here on is behind that copy
-    }
-    return GS_OK;
-}
-
 int32_t resolve_window(gs_ctx *ctx)
 {
     gs_ctx::WindowRt &w = ctx->win;
@@ -256,7 +243,6 @@ int32_t run_window(gs_ctx *ctx, Run &r, uint64_t steps, bool forced, int32_t *la
         x.epoch = w.epoch;
         x.patience = gs_env_int("GS_HIP_WINDOW_PATIENCE", 1 << 21, 1, 1 << 30); // polls of ~1 us each: ~2 s
         x.seq = ++w.seq;
-        GS_TRY(wait_direct(ctx, r.u[1 - slot], r.v[1 - slot])); // an image still being copied out of a plane this launch writes
         const char *name = nullptr;
         const hipError_t e = ctx->o.math == GS_MATH_FUSED ? gs_launch_window_fused(a, x, w.plan_rpw, sl.compute, &name)
                                                            : gs_launch_window_strict(a, x, w.plan_rpw, sl.compute, &name);
@@ -266,7 +252,6 @@ int32_t run_window(gs_ctx *ctx, Run &r, uint64_t steps, bool forced, int32_t *la
         w.pending = true;
         w.launched.push_back(gs_ctx::WindowRt::Launch{{r.u[slot], r.v[slot]}, {r.u[1 - slot], r.v[1 - slot]}, n, x.seq, supers});
         ctx->last_kernel = name;
-        ctx->last_was_window = true;
         ctx->launches++;
         ctx->passes += (uint64_t)supers;
         ctx->steps_done += (uint64_t)n;
