@@ -247,7 +247,8 @@ def test_temporal_blocking_large_grid_vs_stream():
     dict(rows=1100, cols=1920, cpl=1, rpu=20),                       # 1 column per lane, 1925 units + edge halves
     dict(rows=1024, cols=2048, cpl=2, rpu=10),                       # 2 columns per lane, short units
     dict(rows=1500, cols=1500, cpl=2, rpu=12, boundary=capi.GS_BOUNDARY_ZERO_HALO),
-    dict(rows=1300, cols=1700, cpl=2, rpu=16, math=capi.GS_MATH_FUSED),
+    dict(rows=1300, cols=1700, cpl=2, rpu=16, math=capi.GS_MATH_FUSED),   # (no in-step form: it needed 129 registers and spilled)
+    dict(rows=1300, cols=1700, cpl=1, rpu=33, math=capi.GS_MATH_FUSED),   # the fused flavour's in-step form
     dict(rows=1300, cols=1700, cpl=1, rpu=33, general=True),         # non-default parameters: the general kernels
     dict(rows=2000, cols=130, cpl=2, rpu=2),                         # two strips, both edge strips, 2-row units in halves
 ])
@@ -265,7 +266,8 @@ def test_in_step_workgroups_bit_exact(case):
     ref_u, ref_v = oracle.run(u0, v0, steps, oracle_params(p), ftz=True,
                               boundary=oracle.ZERO_HALO if kw["boundary"] == capi.GS_BOUNDARY_ZERO_HALO else oracle.CLIPPED)
     got_u, got_v, info = gpu_run(u0, v0, steps, params=p, args=args(**kw))
-    assert info[0].startswith("tb-k4c%df/" % case["cpl"]), info
+    in_step = not (kw["math"] == capi.GS_MATH_FUSED and case["cpl"] == 2)
+    assert info[0].startswith("tb-k4c%d%s/" % (case["cpl"], "f" if in_step else "")), info
     if kw["math"] == capi.GS_MATH_STRICT:
         assert_bits_equal(got_u, ref_u, f"U {case}")
         assert_bits_equal(got_v, ref_v, f"V {case}")

@@ -40,18 +40,20 @@ def main():
     pinned = [pinned_empty((a.rows, a.cols)) for _ in range(3)]
     # the floor a download per call sets: images back to back through the overlapped path, no steps in between
     sim0, sp0 = sims["marching"]
-    for _ in range(2):
+    per_image = per_image_2 = float("inf")
+    for _ in range(4):                                   # (the best of four: an idle chip's first copies run at idle clocks)
+        sim0.perform_steps(sp0, 400)
         t0 = time.perf_counter()
         for i in range(100):
             sp0.write_result_view_after(pinned[i & 1])
             sim0.context.download_wait()
-        per_image = (time.perf_counter() - t0) / 100
+        per_image = min(per_image, (time.perf_counter() - t0) / 100)
         t0 = time.perf_counter()
         for i in range(100):
             sp0.write_result_view_after(pinned[i % 3])
             sim0.context.download_wait(in_flight=1)
         sim0.context.download_wait()
-        per_image_2 = (time.perf_counter() - t0) / 100
+        per_image_2 = min(per_image_2, (time.perf_counter() - t0) / 100)
     print(f"an image alone (staging copy + {cells * 4 / 1e6:.1f} MB over PCIe into pinned memory + wait), back to back, one at a time: {per_image * 1e6:.0f} us = "
           f"{cells * 4 / per_image / 1e9:.1f} GB/s; two in flight: {per_image_2 * 1e6:.0f} us = {cells * 4 / per_image_2 / 1e9:.1f} GB/s: a call of n steps "
           f"with a download each cannot beat {cells / per_image_2 / 1e6:,.0f} x n Mcells x steps / s (n = 32: {32 * cells / per_image_2 / 1e6:,.0f})")
