@@ -105,6 +105,7 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
     static const bool draw_all = gs_env_int("GS_HIP_PLACE_ALL", 0, 0, 1) != 0; // diagnostics: never stop early
     std::vector<float *> blocks;
     for (int i = 0; i < 4; ++i) blocks.push_back(planes[i]->s[0].alloc);
+    constexpr float kNotTimed = 1.0e9f;                                // (a pair the deep stage did not time)
     std::vector<std::vector<float>> T(4, std::vector<float>(4, 0.0f)); // pair times, ms
     int probes = 0;
     auto pair_ms = [&](int i, int j, float *ms) -> int32_t {
@@ -159,6 +160,8 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
     if (st != GS_OK) return st;
     const float first_cost = cost_of(best);
     int drawn = 0;
+    static const bool deep_allowed = gs_env_int("GS_HIP_PLACE_DEEP", 1, 0, 1) != 0;
+    const int deep_cap = deep_allowed && bytes >= ((size_t)512 << 20) ? std::min(124, 4 * candidates) : candidates;
     // Test hook (tests/test_gpu_placement.py): GS_HIP_PLACE_FORCE="a,b,c,d" draws `candidates` blocks and then moves the
     // planes to blocks a, b, c, d of those held (0-3: the planes' own, 4 and up: drawn), whatever the probes say -- every
     // shape of move (a plane into a drawn block, chains, two planes swapping, a cycle through all four) on demand.
@@ -196,6 +199,7 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
         for (int i = 0; i < m; ++i)
             for (int j = i + 1; j < m; ++j) {
                 const float t = T[(size_t)i][(size_t)j];
+                if (t >= kNotTimed) continue;
                 if (lo == 0.0f || t < lo) lo = t;
                 if (t > hi) hi = t;
             }
@@ -212,17 +216,39 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
         if (trace)
             std::fprintf(stderr, "gs_hip placement: %d blocks, pairs %.4f ... %.4f ms, best arrangement %d %d | %d %d = %.4f ms per pass%s\n", m, lo,
                          hi, best[0], best[1], best[2], best[3], 0.5f * cost_of(best), both_fast && contrast ? " (settled)" : "");
-        if ((both_fast && contrast && !draw_all) || drawn >= candidates) break;
+        if ((both_fast && contrast && !draw_all) || drawn >= deep_cap) break;
+        // Beyond `candidates` draws: the DEEP stage.  A fresh box hands out memory in physical order and a region can be
+        // tens of GiB long (bench line r06z: 4 + 12 consecutive blocks of one region, single step 0.654 of 8 TB/s).  While
+        // more than half of the device's memory is free -- nobody else needs it -- the search goes on, up to 4 x
+        // `candidates` blocks, with ONE probe per block (against a block that still lacks a partner); only a block of
+        // another region is timed against the rest of the best arrangement.  Large planes only (their probes have an absolute scale).
+        const bool deep = drawn >= candidates;
+        if (deep) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total_b / 2 + bytes) { (void)hipGetLastError(); break; }
+        }
         float *b = nullptr;
         if (hipMalloc(reinterpret_cast<void **>(&b), bytes) != hipSuccess) { (void)hipGetLastError(); break; } // fewer candidates: fine
         blocks.push_back(b);
         ++drawn;
-        for (auto &row : T) row.push_back(0.0f);
-        T.emplace_back(blocks.size(), 0.0f);
+        for (auto &row : T) row.push_back(kNotTimed);
+        T.emplace_back(blocks.size(), kNotTimed);
         const int nb = (int)blocks.size() - 1;
-        for (int i = 0; i < nb && st == GS_OK; ++i) {
+        auto time_pair = [&](int i) {
+            if (st != GS_OK) return;
             st = pair_ms(i, nb, &T[(size_t)i][(size_t)nb]);
             T[(size_t)nb][(size_t)i] = T[(size_t)i][(size_t)nb];
+        };
+        if (!deep) {
+            for (int i = 0; i < nb; ++i) time_pair(i);
+        } else {
+            // the block that still lacks a partner: a member of the slow pair of the best arrangement so far
+            const float fast_ms = (float)(4.0 * (double)bytes / 5.25e12 * 1e3);
+            const int ref = t01 > fast_ms ? best[0] : best[2];
+            time_pair(ref);
+            if (st == GS_OK && T[(size_t)ref][(size_t)nb] <= fast_ms) // a block of another region: time it against the whole arrangement
+                for (int i = 0; i < 4; ++i)
+                    if (best[i] != ref) time_pair(best[i]);
         }
         if (st != GS_OK) { const int keep[4] = {0, 1, 2, 3}; release_extra(keep); return st; }
     }

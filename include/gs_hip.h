@@ -51,6 +51,8 @@
  *                           of gs_fields_place
  *   Launch-policy switches for A/B timing (defaults are the measured best; grayscott_amd/csrc/gs_experiments.h):
  *     GS_HIP_PLACE_ALL      1 = gs_fields_place draws all its candidates even when two fast pairs are found before
+ *     GS_HIP_PLACE_DEEP     0 = gs_fields_place never draws more than `candidates` blocks (default: up to 4 x as many while more
+ *                           than half of the device's memory is free)
  *     GS_HIP_PLACE_FORCE    "a,b,c,d" = test hook: gs_fields_place draws its candidates and moves the planes to blocks a, b, c, d
  *                           of those it holds (0-3 the planes' own, 4 and up drawn), without probes
  *     GS_HIP_EDGE_KINDS     0 = edge units of the marching kernel all take the general path
@@ -293,7 +295,9 @@ int32_t gs_run(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_field *
  * draws blocks of the planes' size ONE AT A TIME -- at most `candidates` (1..124; the hosts' default is 12: at most
  * 12 GiB held for a moment at 16384^2) --, times each against every block held, stops as soon as two disjoint fast pairs
  * exist, moves the planes that have to move (device copies, one at a time: the planes KEEP THEIR CONTENTS, also when a
- * copy fails) and frees the rest.  It waits for the context's work first and can come at any time.  first_ms / best_ms
+ * copy fails) and frees the rest.  A fresh box can hand out 16 and more consecutive blocks of one region: if `candidates`
+ * draws do not settle it and MORE THAN HALF of the device's memory is free, the search goes on to 4 x `candidates` blocks
+ * with one probe per block (planes of >= 512 MiB; GS_HIP_PLACE_DEEP=0 switches it off).  It waits for the context's work first and can come at any time.  first_ms / best_ms
  * (optional): mean time of the probe pass over the two slots' (U, V) pairs, before and after (0 when nothing was done). */
 int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidates, float *first_ms, float *best_ms);
 

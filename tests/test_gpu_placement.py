@@ -152,3 +152,28 @@ def test_every_shape_of_move_keeps_every_plane(force, monkeypatch):
     assert_bits_equal(in_u.make_scalar_view(ctx), ref_u, f"U after moves {force}")
     assert_bits_equal(in_v.make_scalar_view(ctx), ref_v, f"V after moves {force}")
     ctx.close()
+
+
+def test_deep_stage_goes_on_with_one_probe_per_block(monkeypatch):
+    """Beyond `candidates` draws the search goes on (planes of >= 512 MiB, more than half of the device's memory free) up to
+    4 x `candidates` blocks, timing each new block against ONE block of the best arrangement -- and against the rest of it
+    only when it lies in another region.  GS_HIP_PLACE_ALL=1 keeps it from stopping early, so every draw happens here."""
+    monkeypatch.setenv("GS_HIP_PLACE_ALL", "1")
+    shape = (16384, 8192)                                    # planes of 512 MiB
+    sim = Simulation.new(Parameters(), HipArgs(devices=[0], kernel=capi.GS_KERNEL_STREAM))
+    sp = sim.make_species(shape, place_candidates=2)
+    first, best = sp.placement
+    probes, drawn = sim.context.place_stats()
+    assert drawn == 8 and 0 < best <= first * 1.0001, (sp.placement, probes, drawn)
+    # 6 pairs, two blocks timed against all held (4 + 5), six blocks with 1 probe -- or 4 when of another region
+    assert 6 + 9 + 6 <= probes <= 6 + 9 + 6 * 4, probes
+    monkeypatch.delenv("GS_HIP_PLACE_ALL")
+    monkeypatch.setenv("GS_HIP_PLACE_DEEP", "0")
+    sim.perform_steps(sp, 2)
+    ref = sim.make_species(shape, place_candidates=0)
+    sim.perform_steps(ref, 2)
+    import torch
+    for a, b in zip(sp.in_out()[:2], ref.in_out()[:2]):
+        for (_, _, x), (_, _, y) in zip(a.torch_views(), b.torch_views()):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    sim.context.close()
