@@ -89,7 +89,11 @@ def placement_report(ctx, species, sp_dev, place, slab_rows, cols):
     probes, drawn = ctx.place_stats()
     plane_gib = (slab_rows + 8) * ((cols + 63) // 64 * 64) * 4 / 2 ** 30
     placed = [sp for sp in (species, sp_dev) if sp is not None and getattr(sp, "placement", None)]
-    return {"default": place is None, "max_extra_blocks": 12 if place is None else place,
+    cap = 12 if place is None else place
+    return {"default": place is None, "max_extra_blocks": cap,
+            # (the deep stage: only when `max_extra_blocks` draws found one region only and more than half of the device's
+            # memory is free -- one probe per block)
+            "deep_stage_max_extra_blocks": min(124, 4 * cap), "deep_stage_used": any(sp.placement_drawn > cap for sp in placed),
             "species_placed": len(placed), "probes": probes, "extra_blocks_drawn": drawn,
             "extra_blocks_drawn_per_species": [sp.placement_drawn for sp in placed],
             "transient_GiB": round(max([sp.placement_drawn for sp in placed] or [0]) * plane_gib, 2),

@@ -49,7 +49,10 @@ def test_recorded_bench_line_has_the_contract_keys():
                 # `value` is what the library's defaults give (placement by measurement included); the same launches on
                 # planes as hipMalloc hands them out stand beside it
                 pl = b["config"]["placement"]
-                assert pl["default"] is True and pl["max_extra_blocks"] == 12 and pl["transient_GiB"] <= 16
+                assert pl["default"] is True and pl["max_extra_blocks"] == 12
+                # <= 12 GiB held for a moment, unless 4 + 12 consecutive blocks lay in one region (a fresh box can do that):
+                # then, with more than half of the device's memory free, up to 48
+                assert pl["transient_GiB"] <= (48.1 if pl.get("deep_stage_used") else 12.1), pl
                 assert 0.8 * b["value"] < b["value_unplaced"] < 1.05 * b["value"]
                 ss_pl = b["single_step"]["placement"]
                 assert 0 < ss_pl["chosen_blocks_probe_ms"] <= ss_pl["first_blocks_probe_ms"] * 1.0001
