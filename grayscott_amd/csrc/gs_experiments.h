@@ -45,6 +45,27 @@
 #ifndef GS_WIN_LATE_ROW
 #define GS_WIN_LATE_ROW 0
 #endif
+// GS_WIN_TAGGED    1 = the persistent window kernel's apron exchange hands cells over as data-tagged 8-byte granules
+//                  {value, exchange number}: a workgroup stores its ring and at once polls the granules of its own apron --
+//                  no drain, no flag, no flag poll, one barrier instead of two per exchange (MI355X_MICROARCH.md, price
+//                  list: handoff-1to1 against handoff-flag).  0 = round 4's form: ring, drain, barrier, flag, poll, barrier,
+//                  apron loads.  The exchange planes are sized for granules either way.
+#ifndef GS_WIN_TAGGED
+#define GS_WIN_TAGGED 1
+#endif
+// GS_WIN_FIRST_POLL_SLEEP / GS_WIN_POLL_SLEEP  (tagged exchange) s_sleep units of 64 clocks before the first poll of the apron's
+//                  granules and between polls.
+#ifndef GS_WIN_FIRST_POLL_SLEEP
+#define GS_WIN_FIRST_POLL_SLEEP 20
+#endif
+// GS_WIN_EDGE_POLLS_AT_ONCE  1 = only the windows inside the grid wait before their first poll (measured: 497-501 k against
+//                  508-522 k with every window waiting, profiles/r06_window_kernel.md)
+#ifndef GS_WIN_EDGE_POLLS_AT_ONCE
+#define GS_WIN_EDGE_POLLS_AT_ONCE 0
+#endif
+#ifndef GS_WIN_POLL_SLEEP
+#define GS_WIN_POLL_SLEEP 0
+#endif
 // GS_WIN_TRACE     (defined = on; tools/window_timeline.py) wave 0 of every workgroup of the persistent window kernel
 //                  stamps the 100 MHz real-time counter at seven points of each of its last 8 super-steps.
 // GS_TB_TRACE      (defined = on; tools/wave_timeline.py) every wave of gs_step_tb_k leaves five stamps of the

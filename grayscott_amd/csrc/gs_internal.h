@@ -171,6 +171,7 @@ struct gs_ctx {
         uint64_t plan_rows = 0, plan_cols = 0;                   // the tiling `desc` holds ...
         int plan_rpw = 0, plan_k = 0, plan_n = 0, plan_key = -1; // ... its windows, and what else it was made for
         uint64_t rows = 0, pitch = 0;
+        size_t plane_bytes = 0;
         int32_t epoch = 0;
         bool pending = false;  // a launch has been enqueued since the abort word was last read
         bool disabled = false; // a launch gave up once: this context stays with the marching kernel

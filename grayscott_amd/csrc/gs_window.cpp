@@ -107,13 +107,19 @@ int32_t ensure_window_rt(gs_ctx *ctx, const gs_field *f)
             if (p) GS_HIP(hipFree(p));
             p = nullptr;
         }
-        const size_t bytes = (size_t)(f->rows + 1) * (size_t)f->pitch * sizeof(float);
-        for (auto &p : w.planes) GS_HIP(hipMalloc(reinterpret_cast<void **>(&p), bytes));
+        // granules {value, exchange number}: 8 bytes per cell (GS_WIN_TAGGED); zeroed: no cell may carry a number by chance
+        const size_t bytes = (size_t)(f->rows + 1) * (size_t)f->pitch * 2 * sizeof(float);
+        for (auto &p : w.planes) {
+            GS_HIP(hipMalloc(reinterpret_cast<void **>(&p), bytes));
+            GS_HIP(hipMemsetAsync(p, 0, bytes, ctx->slabs[0].compute));
+        }
+        w.plane_bytes = bytes;
         w.rows = f->rows;
         w.pitch = (uint64_t)f->pitch;
     }
     if (w.epoch > (1 << 30)) { // keep flag arithmetic far from wrapping: start over behind everything enqueued
         GS_HIP(hipMemsetAsync(w.words, 0, kWindowMaxTiles * sizeof(int32_t), ctx->slabs[0].compute));
+        for (auto p : w.planes) GS_HIP(hipMemsetAsync(p, 0, w.plane_bytes, ctx->slabs[0].compute)); // (granules carry exchange numbers)
         w.epoch = 0;
     }
     return GS_OK;
@@ -144,6 +150,14 @@ int32_t resolve_window(gs_ctx *ctx)
     images.swap(w.images);
     if (w.seen) *w.seen = 0;
     if (!gave_up) return GS_OK;
+    if (gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1)) {
+        std::vector<int32_t> words((size_t)kWindowMaxTiles);
+        if (hipMemcpy(words.data(), w.words, words.size() * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int g = 0; g < kWindowMaxTiles / 2; ++g)
+                if (words[(size_t)2 * g] || words[(size_t)2 * g + 1])
+                    std::fprintf(stderr, "gs_hip window: launch %d gave up: workgroup %d wave %d at exchange %d after %d polls\n", gave_up, g,
+                                 words[(size_t)2 * g] >> 24, words[(size_t)2 * g] & 0xffffff, words[(size_t)2 * g + 1]);
+    }
     GS_HIP(hipMemsetAsync(w.words, 0, (kWindowMaxTiles + 1) * sizeof(int32_t), sl.compute));
     w.epoch = 0;
     w.disabled = true;
@@ -203,8 +217,10 @@ int32_t run_window(gs_ctx *ctx, Run &r, uint64_t steps, bool forced, int32_t *la
         if (!plan.empty()) {
             GS_TRY(ensure_window_rt(ctx, u0));
             GS_HIP(hipMemcpy(w.desc, plan.data(), plan.size() * sizeof(GsWindowDesc), hipMemcpyHostToDevice));
-            // the flags belong to the workgroups of the old tiling: start over
+            // the flags belong to the workgroups of the old tiling: start over (the exchange numbers with them: no granule
+            // of the old tiling may be taken for one of the new)
             GS_HIP(hipMemsetAsync(w.words, 0, kWindowMaxTiles * sizeof(int32_t), sl.compute));
+            for (auto p : w.planes) GS_HIP(hipMemsetAsync(p, 0, w.plane_bytes, sl.compute));
             w.epoch = 0;
         }
     }

@@ -156,7 +156,8 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
             grow = __builtin_amdgcn_readfirstlane(grow);
         }
         publish(buf);
-        if constexpr (SHARE) {
+        auto shared_step = [&]() {
+          if constexpr ((FAST & 5) == 5 && !GS_MATH_FUSED) {
             const RowT<2> first = widen(u[0], v[0]), second = widen(u[1], v[1]); // old rows 0 and 1: row 0 waits for the barrier
             TapCarry<2> c = win_carry_of(a, first, second);                     // row 0's S / SE / SW taps: row 1's N / NW / NE
             RowT<2> cur = second;
@@ -184,7 +185,21 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
             TapCarry<2> ca = win_carry_of(a, above, first);
             cells_vshare<FAST, 2>(a, first, second, ca, nu, nv);
             u[0][0] = nu[0]; u[0][1] = nu[1]; v[0][0] = nv[0]; v[0][1] = nv[1];
+          }
+        };
+        if constexpr (SHARE) {
+            shared_step();
             continue;
+        }
+        // ... and in the windows on the grid's top or bottom edge (not in a corner), for every wave whose band and the rows
+        // above and below it lie inside the grid: all but the wave that holds the grid's first or last row.  Those windows
+        // set the pace of the whole grid (every workgroup waits for its neighbours at every exchange): 12.2-12.3 us per 4
+        // steps against the 10.96 of the windows inside (profiles/r06_window_kernel.md).
+        if constexpr (EDGE == 4 && (FAST & 5) == 5 && !GS_MATH_FUSED && RPW >= 3) {
+            if (grow >= 1 && grow + RPW < a.rows) { // (wave-uniform)
+                shared_step();
+                continue;
+            }
         }
         // Top down with a sliding window of widened OLD rows: a row is widened just before the row above it is
         // overwritten, so at most five widened rows are alive -- the window of three, old row 1 (kept for row 0) and
@@ -271,6 +286,93 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
         window_steps<RPW, EDGE, FAST, ZH>(a, lds, (s == 0 && x.steps % K) ? x.steps % K : K, step, gr, gc, wave, lane, u, v);
         GS_WIN_TRACE_AT(1);
         if (s == supers - 1) break;
+#if GS_WIN_TAGGED
+        // ---- exchange s, data-tagged granules: ring out, then every lane polls the granules of its own apron cells ----
+        // A granule is {value, tag}: 8 bytes, naturally aligned, written by ONE sc1 store (a lane's two columns: one 16-byte
+        // store of two granules) and read by sc1 loads; the tag is the number of the exchange (epoch + s + 1: unique over
+        // the launches of a context; the planes are zeroed when the numbering starts over).  A reader that finds the tag it
+        // waits for has the value that belongs to it: no drain, no flag, no barrier between a neighbour's stores and my
+        // loads (the hand-off form MI355X_MICROARCH.md prices as handoff-1to1, 1.7-1.9x cheaper than a drained flag).
+        // Exchanges alternate between two sets of planes: a neighbour that is one exchange ahead never overwrites what I
+        // still have to read (it cannot be two ahead: it needs my ring of the exchange in between).
+        // (granules travel as integer vectors: a tag is a small integer -- as a float a sub-normal, which this build's float
+        // mode would flush to zero in any instruction that treats it as a number)
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t xu = win_rsrc(x.xu[s & 1]), xv = win_rsrc(x.xv[s & 1]);
+        const int tag_i = x.epoch + s + 1;
+        const unsigned tag = (unsigned)tag_i;
+        auto bits = [](float f) { return __builtin_bit_cast(unsigned, f); };
+        auto flt = [](unsigned w) { return __builtin_bit_cast(float, w); };
+        const bool lane_owned = wc >= K && wc < K + OW && gc < a.cols;
+        const bool lane_ring = wc < 2 * K || wc >= OW;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int wr = wave * RPW + r; // wave-uniform
+            const bool row_owned = wr >= K && wr < K + OH && gr + r < a.rows;
+            const bool row_ring = wr < 2 * K || wr >= OH;
+            if (row_owned && lane_owned && (row_ring || lane_ring)) {
+                const int off = ((gr + r) * a.pitch + gc) * (int)(2 * sizeof(float)); // granules: 8 bytes per cell
+                const v4u su = {bits(u[r][0]), tag, bits(u[r][1]), tag}, sv = {bits(v[r][0]), tag, bits(v[r][1]), tag};
+                __builtin_amdgcn_raw_buffer_store_b128(su, xu, off, 0, SC1);
+                __builtin_amdgcn_raw_buffer_store_b128(sv, xv, off, 0, SC1);
+            }
+        }
+        GS_WIN_TRACE_AT(2);
+        GS_WIN_TRACE_AT(3);
+        const bool lane_in = gc >= 0 && gc < a.cols;
+        const bool lane_apron = (wc < K || wc >= K + OW) && wc < 2 * K + OW && lane_in;
+        const bool in1 = gc + 1 < a.cols;
+        {
+            int spins = 0;
+            bool failed = false;
+#if GS_WIN_FIRST_POLL_SLEEP > 0
+            // The neighbours' stores need about half a microsecond to land, and a poll that comes too early costs a whole
+            // round trip (1.8 us): every window waits that long before its first poll (496 k -> 508-522 k at 1080 x 1920; 8 ... 28
+            // units tried, 20-24 best; the edge windows polling at once, whose neighbours have stored when they arrive: 497-501 k).
+            if constexpr (EDGE == 0 || !GS_WIN_EDGE_POLLS_AT_ONCE) __builtin_amdgcn_s_sleep(GS_WIN_FIRST_POLL_SLEEP);
+#endif
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const int wr = wave * RPW + r;
+                    const bool row_in = gr + r >= 0 && gr + r < a.rows;
+                    const bool row_apron = (wr < K || wr >= K + OH) && wr < 2 * K + OH;
+                    if (row_in && ((row_apron && lane_in && wc < 2 * K + OW) || (lane_apron && wr < 2 * K + OH))) {
+                        const int off = ((gr + r) * a.pitch + gc) * (int)(2 * sizeof(float));
+                        const v4u fu = __builtin_amdgcn_raw_buffer_load_b128(xu, off, 0, SC1);
+                        const v4u fv = __builtin_amdgcn_raw_buffer_load_b128(xv, off, 0, SC1);
+                        const bool here = fu[1] == tag && fv[1] == tag && (!in1 || (fu[3] == tag && fv[3] == tag));
+                        if (here) {
+                            u[r][0] = flt(fu[0]); u[r][1] = in1 ? flt(fu[2]) : 0.0f;
+                            v[r][0] = flt(fv[0]); v[r][1] = in1 ? flt(fv[2]) : 0.0f;
+                        }
+                        ok = ok && here;
+                    }
+                }
+                if (!__builtin_amdgcn_ballot_w64(!ok)) break; // every lane of this wave has its apron
+                // bounded: neighbours that are not resident never store (the GPU is shared with another long-running
+                // kernel); a workgroup of this launch that gave up says so in the abort word
+                if (++spins > x.patience || ((spins & 63) == 0 && __builtin_amdgcn_raw_buffer_load_b32(win_rsrc(x.abort), 0, 0, SC1) != 0)) { failed = true; break; }
+#if GS_WIN_POLL_SLEEP > 0
+                __builtin_amdgcn_s_sleep(GS_WIN_POLL_SLEEP);
+#endif
+            }
+            if (failed && lane == 0) {
+                __builtin_amdgcn_raw_buffer_store_b32(x.seq, win_rsrc(x.abort), 0, 0, SC1);
+                // (diagnostics, read by resolve_window under GS_HIP_TRACE_TUNER: which wave of which workgroup ran out of patience
+                // at which exchange, after how many polls -- the flag words are not used by this form of the exchange)
+                __builtin_amdgcn_raw_buffer_store_b32((wave << 24) | (s & 0xffffff), win_rsrc(x.flags), wg * 8, 0, SC1);
+                __builtin_amdgcn_raw_buffer_store_b32(spins, win_rsrc(x.flags), wg * 8 + 4, 0, SC1);
+                *go = 0;
+            }
+        }
+        GS_WIN_TRACE_AT(4);
+        __syncthreads(); // (the waves agree: all go on or all leave)
+        if (!*go) return;
+        GS_WIN_TRACE_AT(5);
+        GS_WIN_TRACE_AT(6);
+#else
         // ---- exchange s: ring out, flag, poll, apron in -------------------------------------------------------
         const __amdgpu_buffer_rsrc_t xu = win_rsrc(x.xu[s & 1]), xv = win_rsrc(x.xv[s & 1]);
         const bool lane_owned = wc >= K && wc < K + OW && gc < a.cols;
@@ -335,6 +437,7 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         GS_WIN_TRACE_AT(6);
+#endif
     }
     // the cells this workgroup owns, where they lie in the grid (8-byte stores; a second column beyond `cols` lands in
     // the planes' padding columns, which nothing reads)
@@ -392,7 +495,9 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
             const int n = (s == 0 && x.steps % K) ? x.steps % K : K;
             for (int i = 0; i < n; ++i) __syncthreads();
             if (s == supers - 1) break;
+#if !GS_WIN_TAGGED
             __syncthreads();
+#endif
             __syncthreads();
             if (!go) return;
         }
