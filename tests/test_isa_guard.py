@@ -127,9 +127,9 @@ def test_window_kernel_has_no_scratch_and_no_spill_traffic_in_its_step_loops(ker
         assert len(inner) >= 3, (name, len(inner))
         for l in inner:
             assert sum(bool(re.match(lane_ops, t)) for t in l) == 0, (name, len(l))
-        # ... and what surrounds a step loop inside a super-step reads back one lane at most
+        # ... and what surrounds a step loop inside a super-step (executed once per K steps) reads back a few lanes at most
         for l in step_like:
-            assert sum(bool(re.match(lane_ops, t)) for t in l) <= 1, (name, len(l))
+            assert sum(bool(re.match(lane_ops, t)) for t in l) <= 4, (name, len(l))
 
 
 def test_no_kernel_touches_scratch(kernels):
