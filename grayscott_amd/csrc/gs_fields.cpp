@@ -101,8 +101,9 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
     const size_t pitch = (size_t)f0->pitch;
     const size_t n = (size_t)(f0->s[0].rows + 2 * kGhostRows) * pitch + 2 * kGuardFloats; // (a multiple of 64 floats)
     const size_t bytes = n * sizeof(float);
-    static const bool trace = gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1) != 0;
-    static const bool draw_all = gs_env_int("GS_HIP_PLACE_ALL", 0, 0, 1) != 0; // diagnostics: never stop early
+    // (read at every call: the tests switch them between calls of one process)
+    const bool trace = gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1) != 0;
+    const bool draw_all = gs_env_int("GS_HIP_PLACE_ALL", 0, 0, 1) != 0; // diagnostics: never stop early
     std::vector<float *> blocks;
     for (int i = 0; i < 4; ++i) blocks.push_back(planes[i]->s[0].alloc);
     constexpr float kNotTimed = 1.0e9f;                                // (a pair the deep stage did not time)
@@ -160,7 +161,7 @@ int32_t gs_fields_place(gs_ctx *ctx, gs_field *const planes[4], int32_t candidat
     if (st != GS_OK) return st;
     const float first_cost = cost_of(best);
     int drawn = 0;
-    static const bool deep_allowed = gs_env_int("GS_HIP_PLACE_DEEP", 1, 0, 1) != 0;
+    const bool deep_allowed = gs_env_int("GS_HIP_PLACE_DEEP", 1, 0, 1) != 0;
     const int deep_cap = deep_allowed && bytes >= ((size_t)512 << 20) ? std::min(124, 4 * candidates) : candidates;
     // Test hook (tests/test_gpu_placement.py): GS_HIP_PLACE_FORCE="a,b,c,d" draws `candidates` blocks and then moves the
     // planes to blocks a, b, c, d of those held (0-3: the planes' own, 4 and up: drawn), whatever the probes say -- every
