@@ -66,6 +66,30 @@
 #ifndef GS_WIN_POLL_SLEEP
 #define GS_WIN_POLL_SLEEP 0
 #endif
+// GS_WIN_PAIR_SYNC 1 = inside a step of the persistent window kernel a wave waits for the waves above and below it only (one LDS
+//                  word per wave) instead of the workgroup's barrier: the waves of a SIMD get out of phase, and the LDS read burst
+//                  and the lone last wave behind every barrier go.  0 = one workgroup barrier per step.
+#ifndef GS_WIN_PAIR_SYNC
+#define GS_WIN_PAIR_SYNC 1
+#endif
+// GS_WIN_PAIR_PRIO (with GS_WIN_PAIR_SYNC) 0 = the SIMD's own arbitration (priority, then age); 1 = s_setprio rotates over a SIMD's
+//                  four waves with the step; 2 = by feedback: a wave that had to wait for its neighbours steps back, one whose
+//                  neighbours are a step ahead goes first.  GS_WIN_PAIR_POLL_SLEEP: s_sleep units between polls of the words.
+#ifndef GS_WIN_PAIR_PRIO
+#define GS_WIN_PAIR_PRIO 2
+#endif
+#ifndef GS_WIN_PRIO_AHEAD
+#define GS_WIN_PRIO_AHEAD 0
+#endif
+#ifndef GS_WIN_PRIO_LEVEL
+#define GS_WIN_PRIO_LEVEL 1
+#endif
+#ifndef GS_WIN_PRIO_BEHIND
+#define GS_WIN_PRIO_BEHIND 3
+#endif
+#ifndef GS_WIN_PAIR_POLL_SLEEP
+#define GS_WIN_PAIR_POLL_SLEEP 0
+#endif
 // GS_WIN_TRACE     (defined = on; tools/window_timeline.py) wave 0 of every workgroup of the persistent window kernel
 //                  stamps the 100 MHz real-time counter at seven points of each of its last 8 super-steps.
 // GS_TB_TRACE      (defined = on; tools/wave_timeline.py) every wave of gs_step_tb_k leaves five stamps of the

@@ -41,7 +41,9 @@ constexpr int kWinPitch = 2 * kWinHalf;
 constexpr int kWinWaves = 16;
 __host__ __device__ constexpr int win_rows(int rpw) { return kWinWaves * rpw; }
 // 2 buffers x 2 species x 16 waves x (first row, last row) x pitch
-__host__ __device__ constexpr size_t win_lds_bytes() { return (size_t)2 * 2 * kWinWaves * 2 * kWinPitch * sizeof(float); }
+__host__ __device__ constexpr size_t win_rows_floats() { return (size_t)2 * 2 * kWinWaves * 2 * kWinPitch; }
+// ... + one word per wave: the number of the step whose rows the wave has published (GS_WIN_PAIR_SYNC)
+__host__ __device__ constexpr size_t win_lds_bytes() { return (win_rows_floats() + kWinWaves) * sizeof(float); }
 
 // The S / SE / SW taps of the cells of row `z` with respect to the row `p` below it, in the slots cells_vshare (gs_march.h)
 // keeps them in: what that function leaves in its carry after the row z -- here for a row that is not updated at this
@@ -57,6 +59,37 @@ __device__ __forceinline__ TapCarry<2> win_carry_of(const GsStepArgs &a, const R
     }
     return c;
 }
+
+#if defined(GS_WIN_TRACE)
+__device__ unsigned long long gs_win_trace[1024 * 8 * 8];
+#endif
+#if defined(GS_WIN_TRACE) && GS_WIN_TRACE == 2
+// GS_WIN_TRACE=2 (tools/window_step_timeline.py): EVERY wave of the first 256 workgroups stamps four points of each of the
+// launch's last 4 steps: step begins, at the barrier, past the barrier, the neighbouring waves' rows are in registers.
+#define GS_WIN_STEP_AT(SLOT)                                                                                       \
+    do {                                                                                                           \
+        if (lane == 0 && blockIdx.x < 256) {                                                                       \
+            unsigned long long t_;                                                                                 \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+            gs_win_trace[((blockIdx.x * 16 + wave) * 4 + (step & 3)) * 4 + (SLOT)] = t_;                           \
+        }                                                                                                          \
+    } while (0)
+#define GS_WIN_TRACE_AT(SLOT) do { } while (0)
+#elif defined(GS_WIN_TRACE)
+#define GS_WIN_STEP_AT(SLOT) do { } while (0)
+#define GS_WIN_TRACE_AT(SLOT)                                                                                      \
+    do {                                                                                                           \
+        if (wave == 0 && lane == 0 && s >= supers - 8) {                                                           \
+            unsigned long long t_;                                                                                 \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+            gs_win_trace[(wg * 8 + ((s - (supers - 8)) & 7)) * 8 + (SLOT)] = t_;                                   \
+            if ((SLOT) == 0) gs_win_trace[(wg * 8 + ((s - (supers - 8)) & 7)) * 8 + 7] = (unsigned long long)EDGE;  \
+        }                                                                                                          \
+    } while (0)
+#else
+#define GS_WIN_STEP_AT(SLOT) do { } while (0)
+#define GS_WIN_TRACE_AT(SLOT) do { } while (0)
+#endif
 
 // `n` time steps of a window.  EDGE: 0 = window inside the grid; 1 = general path for every cell; 2 / 3 = window on the
 // grid's left / right edge, touching neither top nor bottom (cell<2> / cell<3>); 4 = window on the top or bottom edge
@@ -74,6 +107,48 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
     // row `which` (0 = first, 1 = last row of a wave's band) of wave w, species sp, buffer buf
     // (element of this lane's FIRST column; its second column is kWinHalf further on)
     auto row_of = [&](int buf, int sp, int w, int which) { return lds + ((((buf * 2 + sp) * kWinWaves + w) * 2 + which) * P) + 1 + lane; };
+#if GS_WIN_PAIR_SYNC
+    // Waves wait for their two neighbours only: a wave says which step's rows it has published (one LDS word per wave, written
+    // behind the rows: the LDS serves a wave's operations in order) and, where a barrier stood, polls the words of the waves
+    // above and below.  Two buffers suffice as with the barrier: a wave overwrites the rows of step s at step s + 2, which it
+    // reaches only after both neighbours have published step s + 1, i.e. have read what they needed of step s.
+    // (an LDS pointer by type: through a generic pointer a volatile access is a flat_load with a 64-bit address)
+    typedef __attribute__((address_space(3))) volatile int *SaidPtr;
+    const SaidPtr said = (SaidPtr)(lds + win_rows_floats());
+    auto announce = [&](int st) {
+        asm volatile("" ::: "memory");
+        if (lane == 0) said[wave] = st + 1;
+        asm volatile("" ::: "memory");
+    };
+    auto await = [&](int st) {
+        bool waited = false;
+        for (;;) {
+            const int fa = said[wave > 0 ? wave - 1 : 0], fb = said[wave < kWinWaves - 1 ? wave + 1 : kWinWaves - 1];
+            const int m = __builtin_amdgcn_readfirstlane(fa < fb ? fa : fb);
+            if (m > st) {
+#if GS_WIN_PAIR_PRIO == 2
+                // the SIMD issues by priority, then age: left alone, its oldest wave runs a step ahead and its youngest finishes
+                // the super-step alone, at half the issue rate.  A wave that had to wait is ahead and steps back; one whose
+                // neighbours are a step further is behind and goes first.
+                if (waited) __builtin_amdgcn_s_setprio(GS_WIN_PRIO_AHEAD);
+                else if (m > st + 1) __builtin_amdgcn_s_setprio(GS_WIN_PRIO_BEHIND);
+                else __builtin_amdgcn_s_setprio(GS_WIN_PRIO_LEVEL);
+#endif
+                break;
+            }
+            waited = true;
+#if GS_WIN_PAIR_POLL_SLEEP > 0
+            __builtin_amdgcn_s_sleep(GS_WIN_PAIR_POLL_SLEEP);
+#endif
+        }
+        asm volatile("" ::: "memory");
+    };
+#define GS_WIN_STEP_SYNC(ST) await(ST)
+#define GS_WIN_STEP_SAY(ST) announce(ST)
+#else
+#define GS_WIN_STEP_SYNC(ST) __syncthreads()
+#define GS_WIN_STEP_SAY(ST) do { } while (0)
+#endif
     // cells outside the grid are zeros and stay zeros: rows are wave-uniform (scalar tests), columns per lane
     bool col_in[2];
     uint32_t la[2], ra[2];
@@ -155,7 +230,18 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
             asm volatile("" : "+s"(grow));
             grow = __builtin_amdgcn_readfirstlane(grow);
         }
+        GS_WIN_STEP_AT(0);
+#if GS_WIN_PAIR_SYNC && GS_WIN_PAIR_PRIO == 1
+        // (every step another of a SIMD's four waves goes first: SIMD = wave % 4)
+        switch (((wave >> 2) + step) & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#endif
         publish(buf);
+        GS_WIN_STEP_SAY(step);
         auto shared_step = [&]() {
           if constexpr ((FAST & 5) == 5 && !GS_MATH_FUSED) {
             const RowT<2> first = widen(u[0], v[0]), second = widen(u[1], v[1]); // old rows 0 and 1: row 0 waits for the barrier
@@ -169,7 +255,9 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
                 u[r][0] = nu[0]; u[r][1] = nu[1]; v[r][0] = nv[0]; v[r][1] = nv[1];
                 cur = next;
             }
-            __syncthreads();
+            GS_WIN_STEP_AT(1);
+            GS_WIN_STEP_SYNC(step);
+            GS_WIN_STEP_AT(2);
             RowT<2> above, below;
             {
                 auto get = [](const float *p, float (&w)[4]) { w[1] = p[0]; w[3] = p[1]; w[0] = p[kWinHalf - 1]; w[2] = p[kWinHalf]; };
@@ -178,6 +266,7 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
                 get(row_of(buf, 0, wb, 0), below.u);
                 get(row_of(buf, 1, wb, 0), below.v);
             }
+            GS_WIN_STEP_AT(3);
             // the band's last row: its N taps from the carry, its S taps from the row below it (another wave's)
             cells_vshare<FAST, 2>(a, cur, below, c, nu, nv);
             u[RPW - 1][0] = nu[0]; u[RPW - 1][1] = nu[1]; v[RPW - 1][0] = nv[0]; v[RPW - 1][1] = nv[1];
@@ -219,7 +308,7 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
             cur = next;
         }
         // now (kLate = 0): prev = old row RPW - 2, cur = old row RPW - 1 (RPW >= 3); RPW == 2: prev = old row 0, cur = old row 1
-        __syncthreads();
+        GS_WIN_STEP_SYNC(step);
         RowT<2> above, below;
         {
             // [0] = second column of lane - 1, [1] [2] = own columns, [3] = first column of lane + 1
@@ -244,6 +333,9 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
     }
 }
 
+#undef GS_WIN_STEP_SYNC
+#undef GS_WIN_STEP_SAY
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t win_rsrc(const void *p)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000);
@@ -255,20 +347,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t win_rsrc(const void *p)
 // GS_WIN_TRACE (diagnostic builds, tools/window_timeline.py): wave 0 of every workgroup stamps the 100 MHz real-time
 // counter at seven points of each of its last 8 super-steps: start, steps done, ring stored and drained, barrier
 // passed, poll matched, barrier passed, apron loaded.
-#if defined(GS_WIN_TRACE)
-__device__ unsigned long long gs_win_trace[1024 * 8 * 8];
-#define GS_WIN_TRACE_AT(SLOT)                                                                                      \
-    do {                                                                                                           \
-        if (wave == 0 && lane == 0 && s >= supers - 8) {                                                           \
-            unsigned long long t_;                                                                                 \
-            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
-            gs_win_trace[(wg * 8 + ((s - (supers - 8)) & 7)) * 8 + (SLOT)] = t_;                                   \
-            if ((SLOT) == 0) gs_win_trace[(wg * 8 + ((s - (supers - 8)) & 7)) * 8 + 7] = (unsigned long long)EDGE;  \
-        }                                                                                                          \
-    } while (0)
-#else
-#define GS_WIN_TRACE_AT(SLOT) do { } while (0)
-#endif
 
 template <int RPW, int EDGE, int FAST, int ZH>
 __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowArgs &x, const GsWindowDesc *d, int OH, int OW, float *lds,
@@ -475,6 +553,10 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
     // word for the whole workgroup: waves that read it for themselves could disagree (a workgroup of this launch may
     // give up at any time) and a barrier below would wait for waves that have left.
     if (wave == 0 && lane == 0) go = __builtin_amdgcn_raw_buffer_load_b32(win_rsrc(x.abort), 0, 0, SC1) == 0;
+#if GS_WIN_PAIR_SYNC
+    // (a wave beyond the window's rows in use has published its zeros for every step to come)
+    if (lane == 0) ((__attribute__((address_space(3))) volatile int *)(lds + win_rows_floats()))[wave] = wave * RPW >= d->active ? 0x7fffffff : 0;
+#endif
     __syncthreads();
     if (!go) return; // (workgroup-uniform)
     // elements 0 and 65 of both arrays of this wave's published rows (window columns -2, -1, 128, 129) are never written by
@@ -490,10 +572,15 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
 #pragma unroll
         for (int b = 0; b < 8; ++b)
             { float *p = lds + (((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + 1 + lane; p[0] = 0.0f; p[kWinHalf] = 0.0f; }
+#if GS_WIN_PAIR_SYNC
+        __syncthreads(); // (the zeros are there before anybody reads them: no barrier inside the steps)
+#endif
         const int supers = (x.steps + K - 1) / K;
         for (int s = 0; s < supers; ++s) {
+#if !GS_WIN_PAIR_SYNC
             const int n = (s == 0 && x.steps % K) ? x.steps % K : K;
             for (int i = 0; i < n; ++i) __syncthreads();
+#endif
             if (s == supers - 1) break;
 #if !GS_WIN_TAGGED
             __syncthreads();
@@ -503,6 +590,9 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
         }
         return;
     }
+#if GS_WIN_PAIR_SYNC
+    __syncthreads();
+#endif
     float u[RPW][2], v[RPW][2];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {

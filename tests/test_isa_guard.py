@@ -113,23 +113,27 @@ def test_window_kernel_has_no_scratch_and_no_spill_traffic_in_its_step_loops(ker
     """gs_run_window_k (the reference's default 1080 x 1920 in long calls): eight kinds of window, one branch each, in one
     persistent kernel.  Values that only the exchange between super-steps needs may be parked in VGPR lanes around the
     step loops (SGPR spills: v_writelane before, v_readlane after), but nothing may go to scratch and no step loop -- the
-    innermost loops around the one workgroup barrier of a step -- may contain a lane read or write (round 5 had 528 SGPR
-    spills, 2 VGPR spills, 8 B of scratch and up to 25 v_readlane per step in the corner windows)."""
+    innermost loops around a step: rows published to LDS, the wave's wait for the waves above and below it, its priority
+    set by how it stands to them -- may contain a lane read or write (round 5 had 528 SGPR spills, 2 VGPR spills, 8 B of
+    scratch and up to 25 v_readlane per step in the corner windows) or a workgroup barrier (one per step until round 6:
+    the LDS read burst of 16 waves in lock-step and the lone last wave in front of it cost 8 % of a step)."""
     for name in ("gs_run_window_k_strict<5, 7>", "gs_run_window_k_strict<5, 3>", "gs_run_window_k_strict<5, 0>", "gs_run_window_k_fused<5, 0>"):
         k = kernels[name]
         assert k.vgpr <= 128 and k.agpr == 0 and k.vgpr_spill == 0 and k.scratch == 0 and not k.dynamic_stack, (name, k.vgpr, k.vgpr_spill, k.scratch)
         assert k.count(r"^scratch_") == 0, name
         lane_ops = r"^v_(readlane|writelane)_b32"
-        # a step loop: around the workgroup barrier(s) of a step (two where a kind of window has two forms of a step), hundreds
-        # of VALU instructions, and none of the exchange's stores to the exchange planes
-        step_like = [l for l in k.loops() if sum(t.startswith("s_barrier") for t in l) >= 1 and sum(t.startswith("v_") for t in l) >= 300
-                     and not any(t.startswith("buffer_store") for t in l)]
+        # a step loop: rows published (ds_write2), the wave's priority set behind its wait for its neighbours, hundreds of VALU
+        # instructions, and none of the exchange's stores to the exchange planes
+        step_like = [l for l in k.loops() if sum(t.startswith("s_setprio") for t in l) >= 3 and sum(t.startswith("ds_write2") for t in l) >= 4
+                     and sum(t.startswith("v_") for t in l) >= 300 and not any(t.startswith("buffer_store") for t in l)]
         assert len(step_like) >= 6, (name, len(step_like))             # every kind of window has one
         # innermost: no other step-like loop is a proper part of it
         inner = [l for l in step_like if not any(len(m) < len(l) and " ".join(m) in " ".join(l) for m in step_like)]
         assert len(inner) >= 3, (name, len(inner))
         for l in inner:
             assert sum(bool(re.match(lane_ops, t)) for t in l) == 0, (name, len(l))
+            assert not any(t.startswith("s_barrier") for t in l), (name, len(l))
+            assert not any(t.startswith(("flat_", "global_", "scratch_")) for t in l), (name, len(l))
         # ... and what surrounds a step loop inside a super-step (executed once per K steps) reads back a few lanes at most
         for l in step_like:
             assert sum(bool(re.match(lane_ops, t)) for t in l) <= 4, (name, len(l))
