@@ -78,6 +78,11 @@
 #ifndef GS_WIN_PAIR_PRIO
 #define GS_WIN_PAIR_PRIO 2
 #endif
+// GS_WIN_WAVES_LEAVE_ALONE (with GS_WIN_PAIR_SYNC and GS_WIN_TAGGED) 1 = no workgroup barrier behind an exchange either: a wave that has
+//                  its apron goes on; 0 = one barrier per exchange (the waves agree whether the launch goes on).
+#ifndef GS_WIN_WAVES_LEAVE_ALONE
+#define GS_WIN_WAVES_LEAVE_ALONE 1
+#endif
 #ifndef GS_WIN_PRIO_AHEAD
 #define GS_WIN_PRIO_AHEAD 0
 #endif

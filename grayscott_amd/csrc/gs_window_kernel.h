@@ -176,10 +176,11 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
     // step, or the compiler keeps fifteen loop-invariant row conditions as 64-bit masks in thirty SGPRs across the loop
     // and spills them to VGPR lanes -- 25 v_readlane inside the step loop of the corner windows)
     int grow = gr;
+    const int nrows = a.rows;
     auto update = [&](int r, const RowT<2> &m, const RowT<2> &z, const RowT<2> &p) {
         const int row = grow + r; // wave-uniform
-        if (EDGE != 0 && (row < 0 || row >= a.rows)) return; // a row outside the grid: zeros that stay zeros
-        const bool mrow = !ROWS || row > 0, prow = !ROWS || row + 1 < a.rows;
+        if (EDGE != 0 && (row < 0 || row >= nrows)) return; // a row outside the grid: zeros that stay zeros
+        const bool mrow = !ROWS || row > 0, prow = !ROWS || row + 1 < nrows;
         float nu[2], nv[2];
         if constexpr (EDGE == 0 || EDGE == 7) {
             cells_interior<FAST, 2, ZH>(a, m, z, p, nu, nv);
@@ -285,7 +286,7 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
         // set the pace of the whole grid (every workgroup waits for its neighbours at every exchange): 12.2-12.3 us per 4
         // steps against the 10.96 of the windows inside (profiles/r06_window_kernel.md).
         if constexpr (EDGE == 4 && (FAST & 5) == 5 && !GS_MATH_FUSED && RPW >= 3) {
-            if (grow >= 1 && grow + RPW < a.rows) { // (wave-uniform)
+            if (grow >= 1 && grow + RPW < nrows) { // (wave-uniform)
                 shared_step();
                 continue;
             }
@@ -400,9 +401,9 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
         const bool lane_in = gc >= 0 && gc < a.cols;
         const bool lane_apron = (wc < K || wc >= K + OW) && wc < 2 * K + OW && lane_in;
         const bool in1 = gc + 1 < a.cols;
+        bool failed = false;
         {
             int spins = 0;
-            bool failed = false;
 #if GS_WIN_FIRST_POLL_SLEEP > 0
             // The neighbours' stores need about half a microsecond to land, and a poll that comes too early costs a whole
             // round trip (1.8 us): every window waits that long before its first poll (496 k -> 508-522 k at 1080 x 1920; 8 ... 28
@@ -446,8 +447,22 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
             }
         }
         GS_WIN_TRACE_AT(4);
+#if GS_WIN_PAIR_SYNC && GS_WIN_WAVES_LEAVE_ALONE
+        // No barrier: a wave that has its apron goes on (inside the steps it waits for the waves above and below it only).  A
+        // wave that gave up says that its rows will never come and leaves; the others compute on with what they have -- the
+        // launch is void -- until their own next exchange finds the abort word.  The exchange planes stay safe without the
+        // barrier: a wave w that stores exchange s + 2 has finished super-step s + 2, so the waves next to it are inside that
+        // super-step and have passed exchange s + 1, for which the waves of other windows whose cells they read -- among
+        // them every wave that reads cells of w -- had stored exchange s + 1, i.e. had passed exchange s.
+        if (failed) {
+            if (lane == 0) ((__attribute__((address_space(3))) volatile int *)(lds + win_rows_floats()))[wave] = 0x7fffffff;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_endpgm(); // (the wave ends here: no way out of the loop for the compiler to keep values for)
+        }
+#else
         __syncthreads(); // (the waves agree: all go on or all leave)
         if (!*go) return;
+#endif
         GS_WIN_TRACE_AT(5);
         GS_WIN_TRACE_AT(6);
 #else
@@ -574,6 +589,9 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
             { float *p = lds + (((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + 1 + lane; p[0] = 0.0f; p[kWinHalf] = 0.0f; }
 #if GS_WIN_PAIR_SYNC
         __syncthreads(); // (the zeros are there before anybody reads them: no barrier inside the steps)
+#endif
+#if GS_WIN_PAIR_SYNC && GS_WIN_TAGGED && GS_WIN_WAVES_LEAVE_ALONE
+        return; // (no barrier left to keep count of)
 #endif
         const int supers = (x.steps + K - 1) / K;
         for (int s = 0; s < supers; ++s) {

@@ -136,7 +136,7 @@ def test_window_kernel_has_no_scratch_and_no_spill_traffic_in_its_step_loops(ker
             assert not any(t.startswith(("flat_", "global_", "scratch_")) for t in l), (name, len(l))
         # ... and what surrounds a step loop inside a super-step (executed once per K steps) reads back a few lanes at most
         for l in step_like:
-            assert sum(bool(re.match(lane_ops, t)) for t in l) <= 4, (name, len(l))
+            assert sum(bool(re.match(lane_ops, t)) for t in l) <= 6, (name, len(l))
 
 
 def test_no_kernel_touches_scratch(kernels):
