@@ -75,6 +75,27 @@ __device__ unsigned long long gs_win_trace[1024 * 8 * 8];
         }                                                                                                          \
     } while (0)
 #define GS_WIN_TRACE_AT(SLOT) do { } while (0)
+#elif defined(GS_WIN_TRACE) && GS_WIN_TRACE == 4
+// GS_WIN_TRACE=4 (tools/window_wave_budget.py): every wave adds up, in shader clocks, what it spends waiting for the waves above
+// and below it inside the steps (word 0; word 3: how many of those waits found the rows not there yet), between its last
+// step and its apron (word 1), and in all (word 2).
+#define GS_WIN_BUDGET 1
+#define GS_WIN_BUDGET_ADD(SLOT, V) do { if (lane == 0 && blockIdx.x < 256) atomicAdd(&gs_win_trace[(blockIdx.x * 16 + wave) * 4 + (SLOT)], (unsigned long long)(V)); } while (0)
+#define GS_WIN_STEP_AT(SLOT) do { } while (0)
+#define GS_WIN_TRACE_AT(SLOT) do { } while (0)
+#elif defined(GS_WIN_TRACE) && GS_WIN_TRACE == 3
+// GS_WIN_TRACE=3 (tools/window_wave_timeline.py): EVERY wave of the first 256 workgroups stamps three points of each of its last
+// four super-steps -- begins, steps done (before the ring stores), apron in -- and leaves the number of polls in the fourth word.
+#define GS_WIN_STEP_AT(SLOT) do { } while (0)
+#define GS_WIN_TRACE_AT(SLOT)                                                                                      \
+    do {                                                                                                           \
+        if (lane == 0 && wg < 256 && s >= supers - 4 && ((SLOT) == 0 || (SLOT) == 1 || (SLOT) == 4)) {             \
+            unsigned long long t_;                                                                                 \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+            gs_win_trace[((wg * 16 + wave) * 4 + ((s - (supers - 4)) & 3)) * 4 + ((SLOT) == 4 ? 2 : (SLOT))] = t_; \
+            if ((SLOT) == 4) gs_win_trace[((wg * 16 + wave) * 4 + ((s - (supers - 4)) & 3)) * 4 + 3] = (unsigned long long)trace_polls; \
+        }                                                                                                          \
+    } while (0)
 #elif defined(GS_WIN_TRACE)
 #define GS_WIN_STEP_AT(SLOT) do { } while (0)
 #define GS_WIN_TRACE_AT(SLOT)                                                                                      \
@@ -122,6 +143,9 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
     };
     auto await = [&](int st) {
         bool waited = false;
+#if defined(GS_WIN_BUDGET)
+        const unsigned long long await_t0 = __builtin_amdgcn_s_memtime();
+#endif
         for (;;) {
             const int fa = said[wave > 0 ? wave - 1 : 0], fb = said[wave < kWinWaves - 1 ? wave + 1 : kWinWaves - 1];
             const int m = __builtin_amdgcn_readfirstlane(fa < fb ? fa : fb);
@@ -141,6 +165,10 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
             __builtin_amdgcn_s_sleep(GS_WIN_PAIR_POLL_SLEEP);
 #endif
         }
+#if defined(GS_WIN_BUDGET)
+        GS_WIN_BUDGET_ADD(0, __builtin_amdgcn_s_memtime() - await_t0);
+        if (waited) GS_WIN_BUDGET_ADD(3, 1);
+#endif
         asm volatile("" ::: "memory");
     };
 #define GS_WIN_STEP_SYNC(ST) await(ST)
@@ -358,13 +386,21 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
     typedef float v2f __attribute__((ext_vector_type(2)));
     const int K = x.k, wc = 2 * lane; // wc: this lane's first window column
     int step = 0;
+#if defined(GS_WIN_BUDGET)
+    const unsigned long long run_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const int supers = (x.steps + K - 1) / K;
     for (int s = 0; s < supers; ++s) {
+        int trace_polls = 0; // (GS_WIN_TRACE == 3)
+        (void)trace_polls;
         GS_WIN_TRACE_AT(0);
         // the short super-step first
         window_steps<RPW, EDGE, FAST, ZH>(a, lds, (s == 0 && x.steps % K) ? x.steps % K : K, step, gr, gc, wave, lane, u, v);
         GS_WIN_TRACE_AT(1);
         if (s == supers - 1) break;
+#if defined(GS_WIN_BUDGET)
+        const unsigned long long xchg_t0 = __builtin_amdgcn_s_memtime();
+#endif
 #if GS_WIN_TAGGED
         // ---- exchange s, data-tagged granules: ring out, then every lane polls the granules of its own apron cells ----
         // A granule is {value, tag}: 8 bytes, naturally aligned, written by ONE sc1 store (a lane's two columns: one 16-byte
@@ -437,6 +473,7 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
                 __builtin_amdgcn_s_sleep(GS_WIN_POLL_SLEEP);
 #endif
             }
+            trace_polls = spins + 1;
             if (failed && lane == 0) {
                 __builtin_amdgcn_raw_buffer_store_b32(x.seq, win_rsrc(x.abort), 0, 0, SC1);
                 // (diagnostics, read by resolve_window under GS_HIP_TRACE_TUNER: which wave of which workgroup ran out of patience
@@ -447,6 +484,9 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
             }
         }
         GS_WIN_TRACE_AT(4);
+#if defined(GS_WIN_BUDGET)
+        GS_WIN_BUDGET_ADD(1, __builtin_amdgcn_s_memtime() - xchg_t0);
+#endif
 #if GS_WIN_PAIR_SYNC && GS_WIN_WAVES_LEAVE_ALONE
         // No barrier: a wave that has its apron goes on (inside the steps it waits for the waves above and below it only).  A
         // wave that gave up says that its rows will never come and leaves; the others compute on with what they have -- the
@@ -532,6 +572,9 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
         GS_WIN_TRACE_AT(6);
 #endif
     }
+#if defined(GS_WIN_BUDGET)
+    GS_WIN_BUDGET_ADD(2, __builtin_amdgcn_s_memtime() - run_t0);
+#endif
     // the cells this workgroup owns, where they lie in the grid (8-byte stores; a second column beyond `cols` lands in
     // the planes' padding columns, which nothing reads)
     if (wc >= K && wc < K + OW && gc < a.cols) {
@@ -557,10 +600,10 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
     constexpr int SC1 = 16;
     typedef float v2f __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int K = x.k;
     const int wg = (int)blockIdx.x;
     const GsWindowDesc *d = x.desc + wg;                    // (uniform: scalar loads)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int H = d->active, OH = d->oh, OW = d->ow;        // window rows in use; owned rows and columns
     const int gr0 = d->r0 - K, gc0 = d->c0 - K;             // global coordinates of window cell (0, 0)
     const int gr = gr0 + wave * RPW, gc = gc0 + 2 * lane;   // this lane's first cell
