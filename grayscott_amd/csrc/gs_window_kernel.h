@@ -16,18 +16,20 @@ namespace {
 // columns for the whole run: a wave keeps RPW whole rows in registers, two columns per lane (10 cells per lane at
 // RPW = 5).  Per step the columns next to a lane's two come from the adjacent lanes (DPP wave shifts), only the
 // first and the last row of a wave's band go through LDS for the waves above and below (double-buffered by the
-// step's parity: one workgroup barrier per step, reached after the RPW - 2 rows that need nothing from other waves),
-// and every cell is updated by the same cell<> code as in every other kernel: bit-identical.  The window's outer K
-// cells are an apron: they lose their validity one ring per step.  After K steps the workgroup stores the K-cell
-// ring of the cells it OWNS (the window shrunk by K) into an exchange plane with sc1 stores, drains, raises its
-// flag, polls the flags of its up to 8 neighbours and reloads its apron from their rings with sc1 loads -- the
-// hand-off form MI355X_MICROARCH.md lists as valid for one workgroup per CU (one lane signals for all stores of the
-// workgroup behind a barrier; the polling wave joins a barrier before anybody loads; all stores and loads sc1),
-// measured for exactly this shape in tools/ubench/handoff_probe.hip: 4.3 us per exchange, no stale word.  Exchanges
-// alternate between two sets of exchange planes, so a workgroup that is one exchange ahead never overwrites what a
-// neighbour still has to read.  The input planes are only read and the output planes only written at the very end.
-// Every poll is bounded: a workgroup that runs out of patience (its neighbours are not resident: the GPU is shared
-// with another long-running kernel) sets a sticky abort word and every workgroup leaves; gs_sync reports it.
+// step's parity), and every cell is updated by the same cell<> code as in every other kernel: bit-identical.
+// Inside a step a wave waits for the waves above and below it only (one LDS word per wave says which step's rows it
+// has published; round 6 -- a workgroup barrier per step until then), after the RPW - 2 rows that need nothing from
+// other waves, and sets its priority by how it stands to them.  The window's outer K cells are an apron: they lose
+// their validity one ring per step.  After K steps every wave stores its part of the K-cell ring of the cells the
+// workgroup OWNS (the window shrunk by K) into an exchange plane as data-tagged granules {value, exchange number}
+// (8 bytes, one sc1 store) and polls the granules of its own apron cells with sc1 loads until they carry the number it
+// waits for -- the hand-off MI355X_MICROARCH.md prices as handoff-1to1; no drain, no flag, and no barrier: a wave
+// that has its apron goes on.  (Round 4's form -- ring, drain, barrier, flag, poll of the neighbours' flags, barrier,
+// apron loads -- is -DGS_WIN_TAGGED=0.)  Exchanges alternate between two sets of exchange planes, so a wave that is
+// one exchange ahead never overwrites what a neighbour still has to read.  The input planes are only read and the
+// output planes only written at the very end.  Every poll of the exchange is bounded: a wave that runs out of
+// patience (its neighbours are not resident: the GPU is shared with another long-running kernel) sets a sticky abort
+// word and ends, and every other wave leaves at its next exchange; gs_sync reports it and the host replays the launch.
 // Edge windows use the cheap kinds of edge path of the marching kernel (cell<2>, cell<3>, general rows only for the
 // grid's first and last row) under the clipped rule and interior code over zeros under the zero-halo rule.
 // ------------------------------------------------------------------------------------
@@ -47,7 +49,7 @@ __host__ __device__ constexpr size_t win_lds_bytes() { return (win_rows_floats()
 
 // The S / SE / SW taps of the cells of row `z` with respect to the row `p` below it, in the slots cells_vshare (gs_march.h)
 // keeps them in: what that function leaves in its carry after the row z -- here for a row that is not updated at this
-// point (the row above a wave's band, which another wave owns; the band's first row, whose own update waits for the barrier).
+// point (the row above a wave's band, which another wave owns; the band's first row, whose own update waits for the neighbouring waves' rows).
 __device__ __forceinline__ TapCarry<2> win_carry_of(const GsStepArgs &a, const RowT<2> &z, const RowT<2> &p)
 {
     TapCarry<2> c;
@@ -243,7 +245,8 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
         put(row_of(buf, 0, wave, 1), u[RPW - 1][0], u[RPW - 1][1]);
         put(row_of(buf, 1, wave, 1), v[RPW - 1][0], v[RPW - 1][1]);
     };
-    // A step: publish, the rows that need nothing from other waves (the other waves' rows arrive meanwhile), barrier, the
+    // A step: publish, the rows that need nothing from other waves (the other waves' rows arrive meanwhile), the wait
+    // for the waves above and below (GS_WIN_STEP_SYNC: their LDS words; the workgroup's barrier in the round-5 build), the
     // rows above and below from LDS, the band's first and last row.  (Reads first and the publish for the next step
     // right before the barrier -- the LDS latency behind the middle rows -- was measured: the waves of a workgroup
     // drift apart, 418 k against 461 k at 1080 x 1920, profiles/r04_window_kernel.md.)
@@ -273,7 +276,7 @@ __device__ __forceinline__ void window_steps(const GsStepArgs &a, float *lds, in
         GS_WIN_STEP_SAY(step);
         auto shared_step = [&]() {
           if constexpr ((FAST & 5) == 5 && !GS_MATH_FUSED) {
-            const RowT<2> first = widen(u[0], v[0]), second = widen(u[1], v[1]); // old rows 0 and 1: row 0 waits for the barrier
+            const RowT<2> first = widen(u[0], v[0]), second = widen(u[1], v[1]); // old rows 0 and 1: row 0 waits for the row above
             TapCarry<2> c = win_carry_of(a, first, second);                     // row 0's S / SE / SW taps: row 1's N / NW / NE
             RowT<2> cur = second;
             float nu[2], nv[2];
@@ -418,6 +421,15 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
         const unsigned tag = (unsigned)tag_i;
         auto bits = [](float f) { return __builtin_bit_cast(unsigned, f); };
         auto flt = [](unsigned w) { return __builtin_bit_cast(float, w); };
+        const bool lane_in = gc >= 0 && gc < a.cols;
+        const bool lane_apron = (wc < K || wc >= K + OW) && wc < 2 * K + OW && lane_in;
+        const bool in1 = gc + 1 < a.cols;
+        auto wants = [&](int r) { // (does this lane hold an apron cell in row r of its band?)
+            const int wr = wave * RPW + r;
+            const bool row_in = gr + r >= 0 && gr + r < a.rows;
+            const bool row_apron = (wr < K || wr >= K + OH) && wr < 2 * K + OH;
+            return row_in && ((row_apron && lane_in && wc < 2 * K + OW) || (lane_apron && wr < 2 * K + OH));
+        };
         const bool lane_owned = wc >= K && wc < K + OW && gc < a.cols;
         const bool lane_ring = wc < 2 * K || wc >= OW;
 #pragma unroll
@@ -434,9 +446,6 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
         }
         GS_WIN_TRACE_AT(2);
         GS_WIN_TRACE_AT(3);
-        const bool lane_in = gc >= 0 && gc < a.cols;
-        const bool lane_apron = (wc < K || wc >= K + OW) && wc < 2 * K + OW && lane_in;
-        const bool in1 = gc + 1 < a.cols;
         bool failed = false;
         {
             int spins = 0;
@@ -450,10 +459,7 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
                 bool ok = true;
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
-                    const int wr = wave * RPW + r;
-                    const bool row_in = gr + r >= 0 && gr + r < a.rows;
-                    const bool row_apron = (wr < K || wr >= K + OH) && wr < 2 * K + OH;
-                    if (row_in && ((row_apron && lane_in && wc < 2 * K + OW) || (lane_apron && wr < 2 * K + OH))) {
+                    if (wants(r)) {
                         const int off = ((gr + r) * a.pitch + gc) * (int)(2 * sizeof(float));
                         const v4u fu = __builtin_amdgcn_raw_buffer_load_b128(xu, off, 0, SC1);
                         const v4u fv = __builtin_amdgcn_raw_buffer_load_b128(xv, off, 0, SC1);
@@ -626,7 +632,7 @@ __global__ __launch_bounds__(kWinWaves * 64) void GS_SUFFIX(gs_run_window_k)(GsS
             lds[(((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + (lane & 1) * kWinHalf + (lane >> 1) * (kWinHalf - 1)] = 0.0f;
     if (wave * RPW >= H) {
         // A wave beyond the window's rows in use publishes zeros once (the last wave in use reads them as its row below)
-        // and then only keeps the workgroup's barrier count: one per step, two per exchange.
+        // and (builds with barriers inside the run) then only keeps the workgroup's barrier count.
 #pragma unroll
         for (int b = 0; b < 8; ++b)
             { float *p = lds + (((b >> 1) * kWinWaves + wave) * 2 + (b & 1)) * kWinPitch + 1 + lane; p[0] = 0.0f; p[kWinHalf] = 0.0f; }
