@@ -66,6 +66,7 @@ int32_t sync_all(gs_ctx *ctx)
         GS_HIP(hipStreamSynchronize(sl.halo));
         GS_HIP(hipStreamSynchronize(sl.compute));
         GS_HIP(hipStreamSynchronize(sl.copy));
+        GS_HIP(hipStreamSynchronize(sl.copy2));
     }
     for (auto &b : ctx->bands) {
         GS_HIP(hipSetDevice(b.device));
@@ -572,6 +573,7 @@ int32_t gs_ctx_destroy(gs_ctx *ctx)
             for (auto e : *v)
                 if (e) (void)hipEventDestroy(e);
         if (sl.copy) { (void)hipStreamSynchronize(sl.copy); (void)hipStreamDestroy(sl.copy); }
+        if (sl.copy2) { (void)hipStreamSynchronize(sl.copy2); (void)hipStreamDestroy(sl.copy2); }
         for (auto p : sl.stage)
             if (p) (void)hipFree(p);
         if (sl.halo) (void)hipStreamDestroy(sl.halo);
@@ -686,6 +688,7 @@ int32_t gs_ctx_create(gs_ctx **out, const gs_params *params, const gs_options *o
         GS_HIP_B(hipStreamCreateWithPriority(&sl.compute, hipStreamNonBlocking, least));
         GS_HIP_B(hipStreamCreateWithPriority(&sl.halo, hipStreamNonBlocking, greatest));
         GS_HIP_B(hipStreamCreateWithFlags(&sl.copy, hipStreamNonBlocking));
+        GS_HIP_B(hipStreamCreateWithFlags(&sl.copy2, hipStreamNonBlocking));
         GS_HIP_B(hipEventCreateWithFlags(&sl.staged, hipEventDisableTiming));
         GS_HIP_B(hipEventCreateWithFlags(&sl.copied[0], hipEventDisableTiming));
         GS_HIP_B(hipEventCreateWithFlags(&sl.copied[1], hipEventDisableTiming));

@@ -486,8 +486,8 @@ int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host)
     if (w.pending) {
         if (!w.seen) {
             GS_HIP(hipSetDevice(ctx->slabs[0].device));
-            GS_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.seen), sizeof(int32_t), hipHostMallocDefault));
-            *w.seen = 0;
+            GS_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.seen), 2 * sizeof(int32_t), hipHostMallocDefault));
+            w.seen[0] = w.seen[1] = 0;
         }
         w.images.push_back(gs_ctx::WindowRt::Image{f, host, w.seq});
     }
@@ -500,7 +500,7 @@ int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host)
         GS_HIP(hipSetDevice(sl.device));
         const size_t need = (size_t)fs.rows * f->cols;
         if (sl.stage_floats[k] < need) {
-            GS_HIP(hipStreamSynchronize(sl.copy));
+            GS_HIP(hipStreamSynchronize(sl.image_stream(k)));
             if (sl.stage[k]) GS_HIP(hipFree(sl.stage[k]));
             sl.stage[k] = nullptr;
             sl.stage_floats[k] = 0;
@@ -514,15 +514,17 @@ int32_t gs_field_download_async(gs_ctx *ctx, gs_field *f, float *host)
         GS_HIP(hipStreamWaitEvent(sl.compute, sl.copied[k], 0));
         if (ctx->total_slabs() > 1 && ctx->step_no > 0) GS_HIP(hipStreamWaitEvent(sl.compute, sl.halod[last], 0));
         if (i == 0) GS_TRY(join_bands(ctx, sl.compute));
-        GS_HIP(hipMemcpy2DAsync(sl.stage[k], (size_t)f->cols * sizeof(float), fs.row0, (size_t)f->pitch * sizeof(float),
-                                (size_t)f->cols * sizeof(float), (size_t)fs.rows, hipMemcpyDeviceToDevice, sl.compute));
+        GS_HIP(gs_launch_pack_rows(fs.row0, f->pitch, (int32_t)fs.rows, (int32_t)f->cols, sl.stage[k], sl.compute));
         GS_HIP(hipEventRecord(sl.staged, sl.compute));
-        GS_HIP(hipStreamWaitEvent(sl.copy, sl.staged, 0));
+        // (every other image on a stream of its own: behind one another on ONE stream two host copies leave 13 us of the link
+        // unused between them -- an 8.3 MB image every 168 us where the link takes 152, tools/ubench/d2h_probe.hip)
+        const hipStream_t cs = sl.image_stream(k);
+        GS_HIP(hipStreamWaitEvent(cs, sl.staged, 0));
         GS_HIP(hipMemcpyAsync(host + (fs.g_row0 - first) * f->cols, sl.stage[k], need * sizeof(float),
-                              hipMemcpyDeviceToHost, sl.copy));
+                              hipMemcpyDeviceToHost, cs));
         if (w.pending && i == 0) // the abort word as it stands once the launches this image depends on have ended
-            GS_HIP(hipMemcpyAsync(w.seen, w.words + kWindowMaxTiles, sizeof(int32_t), hipMemcpyDeviceToHost, sl.copy));
-        GS_HIP(hipEventRecord(sl.copied[k], sl.copy));
+            GS_HIP(hipMemcpyAsync(w.seen + k, w.words + kWindowMaxTiles, sizeof(int32_t), hipMemcpyDeviceToHost, cs));
+        GS_HIP(hipEventRecord(sl.copied[k], cs));
     }
     ctx->downloads++;
     return GS_OK;
@@ -568,7 +570,10 @@ int32_t gs_download_wait_but(gs_ctx *ctx, int32_t in_flight)
     if (in_flight == 1 && ctx->downloads < 2) return GS_OK; // nothing older than the newest
     for (auto &sl : ctx->slabs) {
         GS_HIP(hipSetDevice(sl.device));
-        if (in_flight == 0) GS_HIP(hipStreamSynchronize(sl.copy));
+        if (in_flight == 0) {
+            GS_HIP(hipStreamSynchronize(sl.copy));
+            GS_HIP(hipStreamSynchronize(sl.copy2));
+        }
         else GS_HIP(hipEventSynchronize(sl.copied[(ctx->downloads - 2) & 1])); // the image before the newest
     }
     // images enqueued behind persistent window launches: did one of those launches give up?  (Then the launches are run
@@ -576,7 +581,7 @@ int32_t gs_download_wait_but(gs_ctx *ctx, int32_t in_flight)
     // stay pending; only the images waited for are settled here.
     gs_ctx::WindowRt &w = ctx->win;
     if (!w.images.empty()) {
-        if (w.seen && *w.seen != 0) GS_TRY(resolve_window(ctx));
+        if (w.seen && (w.seen[0] != 0 || w.seen[1] != 0)) GS_TRY(resolve_window(ctx)); // (sticky: either word will do)
         if (w.images.size() > (size_t)in_flight) w.images.erase(w.images.begin(), w.images.end() - in_flight);
     }
     return GS_OK;

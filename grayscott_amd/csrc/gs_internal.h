@@ -90,6 +90,8 @@ constexpr int kGhostRows = 4;    // ghost rows kept above and below every slab (
 struct SlabRt {
     int device = 0;
     hipStream_t compute = nullptr, halo = nullptr, copy = nullptr;
+    hipStream_t copy2 = nullptr;   // the host copies of every other image (gs_field_download_async): two images share the link
+    hipStream_t image_stream(int k) const { return k ? copy2 : copy; }
     hipEvent_t done[2] = {nullptr, nullptr}, halod[2] = {nullptr, nullptr};
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // asynchronous downloads: two dense device staging buffers used in turn, so that the host copy of one image and the
@@ -189,7 +191,7 @@ struct gs_ctx {
         // resolve_window fetches the image again right after it has run that launch again.
         struct Image { gs_field *f; float *host; int32_t after_seq; };
         std::vector<Image> images;
-        int32_t *seen = nullptr; // pinned: the abort word as the copy stream last saw it
+        int32_t *seen = nullptr; // pinned, two words: the abort word as either image stream last saw it
     } win;
     int share_now = kShareDefault; // form of difference sharing in force when gs_options.share_taps leaves the choice open (share_mode)
     int cu_count = 0; // compute units of the first slab's device

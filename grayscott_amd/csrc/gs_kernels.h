@@ -127,5 +127,7 @@ hipError_t gs_launch_colormap(const float *row0, int32_t pitch, int32_t rows, in
                               const uint8_t *palette, int32_t n, uint8_t *rgb, hipStream_t s);
 hipError_t gs_launch_fill_rect(float *row0, int32_t pitch, int32_t r0, int32_t r1, int32_t c0,
                                int32_t c1, float value, hipStream_t s);
+// rows x cols of a plane (row pitch `pitch` floats) to a dense array: gs_field_download_async's staging copy.
+hipError_t gs_launch_pack_rows(const float *row0, int32_t pitch, int32_t rows, int32_t cols, float *dst, hipStream_t s);
 // gs_fields_place's probe: reads `bytes` (a multiple of 16, 16-byte aligned) of x and of y and writes them back unchanged.
 hipError_t gs_launch_pair_probe(void *x, void *y, size_t bytes, hipStream_t s);

@@ -15,6 +15,17 @@ __global__ __launch_bounds__(256) void gs_fill_rect_k(float *row0, int pitch, in
     const int c = c0 + blockIdx.x * 256 + threadIdx.x;
     if (c < c1) row0[(ptrdiff_t)r * pitch + c] = value;
 }
+// A plane's `cols` columns without its padding, row after row: the staging copy of gs_field_download_async.  (Not
+// hipMemcpy2DAsync: a device-to-device copy may go to the same copy engines that carry the images to the host, and an
+// image then leaves every 168 us where the link takes 152 -- tools/ubench/d2h_probe.hip, tools/call_pattern.py.)
+template <typename T>
+__global__ __launch_bounds__(256) void gs_pack_rows_k(const float *row0, int pitch, int rows, int cols_t, T *dst)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols_t) return;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y)
+        dst[(size_t)r * cols_t + c] = reinterpret_cast<const T *>(row0 + (ptrdiff_t)r * pitch)[c];
+}
 // Colour mapping of a result plane, data-to-pics/src/main.rs:139-144:
 //     let color = ui::GRADIENT.eval_continuous((ui::AMPLITUDE_SCALE * value).into());
 // i.e. an f32 multiply, widened to f64, handed to colorous 1.0.16 (Cargo.lock:389-392; the crate is not
@@ -78,6 +89,21 @@ hipError_t gs_launch_colormap(const float *row0, int32_t pitch, int32_t rows, in
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+hipError_t gs_launch_pack_rows(const float *row0, int32_t pitch, int32_t rows, int32_t cols, float *dst, hipStream_t s)
+{
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    const unsigned gy = (unsigned)(rows < 32768 ? rows : 32768);
+    // 16 bytes per lane where the rows allow it (the planes' pitch is a multiple of 64 floats, hipMalloc aligns to 256 B)
+    if (cols % 4 == 0 && pitch % 4 == 0 && (reinterpret_cast<uintptr_t>(row0) | reinterpret_cast<uintptr_t>(dst)) % 16 == 0) {
+        const int ct = cols / 4;
+        hipLaunchKernelGGL(gs_pack_rows_k<float4>, dim3((unsigned)((ct + 255) / 256), gy), dim3(256), 0, s, row0, pitch, rows, ct,
+                           reinterpret_cast<float4 *>(dst));
+    } else {
+        hipLaunchKernelGGL(gs_pack_rows_k<float>, dim3((unsigned)((cols + 255) / 256), gy), dim3(256), 0, s, row0, pitch, rows, cols, dst);
+    }
+    return hipGetLastError();
 }
 
 hipError_t gs_launch_fill_rect(float *row0, int32_t pitch, int32_t r0, int32_t r1, int32_t c0,

@@ -148,7 +148,7 @@ int32_t resolve_window(gs_ctx *ctx)
     launched.swap(w.launched);
     std::vector<gs_ctx::WindowRt::Image> images;
     images.swap(w.images);
-    if (w.seen) *w.seen = 0;
+    if (w.seen) w.seen[0] = w.seen[1] = 0;
     if (!gave_up) return GS_OK;
     if (gs_env_int("GS_HIP_TRACE_TUNER", 0, 0, 1)) {
         std::vector<int32_t> words((size_t)kWindowMaxTiles);
@@ -185,6 +185,7 @@ int32_t resolve_window(gs_ctx *ctx)
             if (im.after_seq == l.seq) {
                 GS_HIP(hipStreamSynchronize(sl.compute));
                 GS_HIP(hipStreamSynchronize(sl.copy));
+                GS_HIP(hipStreamSynchronize(sl.copy2));
                 const FieldSlab &fs = im.f->s[0];
                 GS_HIP(hipMemcpy2D(im.host, (size_t)im.f->cols * sizeof(float), fs.row0, (size_t)im.f->pitch * sizeof(float),
                                    (size_t)im.f->cols * sizeof(float), (size_t)fs.rows, hipMemcpyDeviceToHost));

@@ -27,19 +27,25 @@ def main():
     ap.add_argument("--cols", type=int, default=1920)
     ap.add_argument("--calls", type=int, default=200)
     ap.add_argument("--lengths", default="8,16,32,64,128,1000")
+    ap.add_argument("--kinds", default="", help="auto,marching,window (default: all three)")
     a = ap.parse_args()
     cells = a.rows * a.cols
     kinds = (("auto", {}), ("marching", {"kernel": capi.GS_KERNEL_TB}), ("window", {"kernel": capi.GS_KERNEL_WINDOW}))
-    sims = {}
-    for name, kw in kinds:
+    only = [k for k in kinds if not a.kinds or k[0] in a.kinds.split(",")]
+
+    # ONE context alive at a time, as in the reference's `simulate`: a process holds few hardware queues, and streams of
+    # several contexts that land on one of them wait for each other (three contexts side by side: the same kernel 364 k in
+    # one context and 419 k in another, profiles/r06_logs/call_pattern_pack_kernel.log).
+    def fresh(kw):
         sim = Simulation.new(Parameters(), HipArgs(devices=[0], **kw))
         sp = sim.make_species([a.rows, a.cols])
         sim.perform_steps(sp, 4000)                       # on-line tuning done
-        sims[name] = (sim, sp)
+        return sim, sp
+
     image = np.empty((a.rows, a.cols), np.float32)
     pinned = [pinned_empty((a.rows, a.cols)) for _ in range(3)]
     # the floor a download per call sets: images back to back through the overlapped path, no steps in between
-    sim0, sp0 = sims["marching"]
+    sim0, sp0 = fresh({"kernel": capi.GS_KERNEL_TB})
     per_image = per_image_2 = float("inf")
     for _ in range(4):                                   # (the best of four: an idle chip's first copies run at idle clocks)
         sim0.perform_steps(sp0, 400)
@@ -54,16 +60,18 @@ def main():
             sim0.context.download_wait(in_flight=1)
         sim0.context.download_wait()
         per_image_2 = min(per_image_2, (time.perf_counter() - t0) / 100)
+    sim0.context.close()
     print(f"an image alone (staging copy + {cells * 4 / 1e6:.1f} MB over PCIe into pinned memory + wait), back to back, one at a time: {per_image * 1e6:.0f} us = "
           f"{cells * 4 / per_image / 1e9:.1f} GB/s; two in flight: {per_image_2 * 1e6:.0f} us = {cells * 4 / per_image_2 / 1e9:.1f} GB/s: a call of n steps "
           f"with a download each cannot beat {cells / per_image_2 / 1e6:,.0f} x n Mcells x steps / s (n = 32: {32 * cells / per_image_2 / 1e6:,.0f})")
-    print(f"grid {a.rows} x {a.cols}, {a.calls} calls per figure, median of 3; Mcells x steps / s")
-    print("| steps per call | kernel (label) | steps only | + blocking V download | + overlapped V download |")
+    print(f"grid {a.rows} x {a.cols}, {a.calls} calls per figure, median of 3; Mcells x steps / s; one context at a time")
+    print("| kernel (label) | steps per call | steps only | + blocking V download | + overlapped V download |")
     print("|---|---|---|---|---|")
-    for n in (int(x) for x in a.lengths.split(",")):
-        calls = max(20, min(a.calls, 40000 // n))
-        for name, (sim, sp) in sims.items():
-            ctx = sim.context
+    for name, kw in only:
+        sim, sp = fresh(kw)
+        ctx = sim.context
+        for n in (int(x) for x in a.lengths.split(",")):
+            calls = max(20, min(a.calls, 40000 // n))
 
             def steps_only():
                 for _ in range(calls):
@@ -95,9 +103,8 @@ def main():
                     ctx.sync()
                     rates.append(cells * n * calls / (time.perf_counter() - t0) / 1e6)
                 row.append(statistics.median(rates))
-            print(f"| {n} | {name} (`{ctx.info()[0]}`) | {row[0]:,.0f} | {row[1]:,.0f} | {row[2]:,.0f} |", flush=True)
-    for sim, _ in sims.values():
-        sim.context.close()
+            print(f"| {name} (`{ctx.info()[0]}`) | {n} | {row[0]:,.0f} | {row[1]:,.0f} | {row[2]:,.0f} |", flush=True)
+        ctx.close()
     return 0
 
 
