@@ -801,6 +801,26 @@ int32_t run_steps(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_fiel
         if (result_slot) *result_slot = slot;
         return GS_OK;
     }
+    // Grids of one round of register-resident windows (single slab; the reference's default 1080 x 1920 is 252 of them):
+    // the whole call is ONE persistent launch of gs_run_window_k, which trades the windows' aprons between workgroups
+    // itself every k steps.  kernel = auto takes it from kWindowAutoCells up to the largest grid that is one workgroup per CU
+    // when nothing is pinned and the call is long enough to pay for the launch's fixed cost (kWindowAutoSteps);
+    // GS_KERNEL_WINDOW forces it (fuse_steps = steps per exchange, rows_per_block = window rows: 80).
+    // 640-660 k against 391-416 k Mcells x steps / s at 1080 x 1920, both boundary rules (profiles/r06_window_kernel.md).
+    const uint64_t cells = u0->rows * u0->cols;
+    if (allow_window && single && cells > 0 && steps > 0 && !ctx->win.disabled) {
+        const bool forced = ctx->o.kernel == GS_KERNEL_WINDOW;
+        const bool automatic = ctx->o.kernel == GS_KERNEL_AUTO && ctx->o.fuse_steps == 0 && ctx->o.rows_per_block == 0 &&
+                               ctx->o.cols_per_lane == 0 && ctx->o.split <= 1 && !ctx->o.use_graph && cells >= kWindowAutoCells &&
+                               steps >= kWindowAutoSteps;
+        if (forced || automatic) {
+            int32_t launched = 0;
+            GS_TRY(run_window(ctx, r, steps, forced, &launched, result_slot));
+            if (launched) return GS_OK;
+        }
+    }
+    // every other kernel reads or overwrites planes that a window launch still in flight may own
+    GS_TRY(resolve_window(ctx));
     // Mid-size grids (single slab): K <= 8 steps per launch on LDS-resident windows (gs_run_tile_k), where a
     // pass of the temporally blocked kernel is bound by the length of a wave's march and a launch per <= 4
     // steps.  kernel = auto picks it between the resident kernel's 1536 cells and 1.5 M cells when nothing
@@ -808,7 +828,6 @@ int32_t run_steps(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_fiel
     // 10: 2.2x at 64 x 128 and 128 x 256, 1.8x at 256 x 512, 1.4x at 512 x 1024; at 1080 x 1920 the marching
     // kernel is ahead again); GS_KERNEL_TILE forces it (tile_shape and fuse_steps then choose the window
     // and the steps per launch).
-    const uint64_t cells = u0->rows * u0->cols;
     int auto_shape = -1, auto_k = 0;
     if (single && ctx->o.kernel == GS_KERNEL_AUTO && ctx->o.fuse_steps == 0 && ctx->o.rows_per_block == 0 &&
         ctx->o.cols_per_lane == 0 && ctx->o.split <= 1 && !ctx->o.use_graph && cells > (uint64_t)kGsResidentCells &&
@@ -850,27 +869,6 @@ int32_t run_steps(gs_ctx *ctx, gs_field *u0, gs_field *v0, gs_field *u1, gs_fiel
         if (result_slot) *result_slot = slot;
         return GS_OK;
     }
-    // Grids of one round of register-resident windows (single slab; the reference's default 1080 x 1920 is 252 of them):
-    // the whole call is ONE persistent launch of gs_run_window_k, which trades the windows' aprons between workgroups
-    // itself every k steps.  kernel = auto takes it from the LDS-window kernel's upper end (1.5 M cells) up to the largest
-    // grid that is one workgroup per CU when nothing is pinned and the call is long enough to pay for the launch's fixed
-    // cost (64 steps: a launch costs ~9 us plus 4.5 us per step against 4.8 us per step for the marching kernel);
-    // GS_KERNEL_WINDOW forces it (fuse_steps = steps per exchange, rows_per_block = window rows: 80 or 96).
-    // 461 k against 435 k Mcells x steps / s at 1080 x 1920, both boundary rules (profiles/r04_window_kernel.md).
-    if (allow_window && single && cells > 0 && steps > 0 && !ctx->win.disabled) {
-        const bool forced = ctx->o.kernel == GS_KERNEL_WINDOW;
-        const bool automatic = ctx->o.kernel == GS_KERNEL_AUTO && ctx->o.fuse_steps == 0 && ctx->o.rows_per_block == 0 &&
-                               ctx->o.cols_per_lane == 0 && ctx->o.split <= 1 && !ctx->o.use_graph && cells >= kTileAutoCells &&
-                               steps >= 32; // (from the reference's 32 steps per image on: profiles/r06_window_kernel.md)
-        if (forced || automatic) {
-            int32_t launched = 0;
-            GS_TRY(run_window(ctx, r, steps, forced, &launched, result_slot));
-            if (launched) return GS_OK;
-        }
-    }
-    // every other kernel reads or overwrites planes that a window launch still in flight may own
-    // every other kernel reads or overwrites planes that a window launch still in flight may own
-    GS_TRY(resolve_window(ctx));
     // The short pass goes first so that a run ends on a full pass -- a full-depth ghost exchange -- and the
     // next run can start without a blocking refresh.  It is sized with the steps per pass in force (a
     // configuration handed in through gs_ctx_set_tuned may fuse fewer steps than `fuse`), which is known

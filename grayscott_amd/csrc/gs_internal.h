@@ -251,6 +251,12 @@ void remember_tuned(gs_ctx *ctx, const gs_ctx::Tuned &t);
 int32_t tune_online(Run &r, int fuse);
 // kernel = auto runs the LDS-window kernel (gs_run_tile_k) below this many cells:
 constexpr uint64_t kTileAutoCells = 1536 * 1024; // above, the marching kernel is ahead (1080 x 1920: 380-420 k vs 350 k)
+// ... and the persistent window kernel (gs_run_window_k) from this many cells on, in calls of >= kWindowAutoSteps steps, where one
+// round of windows covers the grid: 331 k against 236 k at 720 x 1280, 374 k against 297 k at 1024 x 1024, 509 k against 316 k at
+// 900 x 1600 in 1000-step calls (273 / 220, 305 / 269, 407 / 290 in 64-step calls); at 512 x 1024 the LDS-window kernel is
+// ahead, 242 k against 188 k (profiles/r06_logs/window_small_grids_k.log)
+constexpr uint64_t kWindowAutoCells = 800 * 1024;
+constexpr uint64_t kWindowAutoSteps = 32; // (the reference's steps per image: profiles/r06_window_kernel.md)
 // gs_window.cpp
 std::vector<GsWindowDesc> plan_windows(const gs_ctx *ctx, uint64_t rows, uint64_t cols, int want_rpw, int want_k, int *rpw_out, int *k_out);
 std::vector<GsWindowDesc> plan_windows(int cu_count, bool zero_halo, bool cheap, uint64_t rows, uint64_t cols, int want_rpw, int want_k,

@@ -15,9 +15,21 @@ std::vector<GsWindowDesc> plan_windows(const gs_ctx *ctx, uint64_t rows, uint64_
 std::vector<GsWindowDesc> plan_windows(int cu_count, bool zero_halo, bool cheap, uint64_t rows, uint64_t cols, int want_rpw, int want_k,
                                        int *rpw_out, int *k_out)
 {
+    // Steps per exchange when the caller does not say: as many as still leave one window per compute unit.  A step takes the
+    // same time whatever the number of windows (a window's waves wait for each other's rows and for their aprons, not for
+    // issue slots) and an exchange costs about one step and a half, so the deeper apron pays wherever it fits: 8 rather than 4
+    // steps per exchange is +8-10 % on grids of 0.9-1.5 M cells (profiles/r06_window_kernel.md, "smaller grids"); the
+    // reference's 1080 x 1920 fits with 4 only.
+    if (want_k <= 0) {
+        for (int k : {8, 6, 4}) {
+            std::vector<GsWindowDesc> plan = plan_windows(cu_count, zero_halo, cheap, rows, cols, want_rpw, k, rpw_out, k_out);
+            if (!plan.empty()) return plan;
+        }
+        return std::vector<GsWindowDesc>();
+    }
     std::vector<GsWindowDesc> plan;
     if (cu_count <= 0 || rows == 0 || cols == 0 || rows > 0x7fffff || cols > 0x7fffff) return plan;
-    const int k = want_k > 0 ? want_k : 4;
+    const int k = want_k;
     if (k < 2 || k > 8 || (k & 1)) return plan;
     const long wo = 128 - 2 * k;
     const long tiles_c = (long)((cols + wo - 1) / wo);

@@ -211,8 +211,8 @@ def test_only_the_launch_that_gave_up_and_the_later_ones_are_run_again(monkeypat
 
 
 def test_what_kernel_auto_picks_around_the_window_kernel():
-    """kernel = auto: the window kernel for calls of >= 32 steps (the reference's steps per image) on single-slab grids from 1.5 M cells up to one window per
-    compute unit when nothing is pinned; the marching kernel for short calls, pinned schedules, slab chains, larger grids."""
+    """kernel = auto: the window kernel for calls of >= 32 steps (the reference's steps per image) on single-slab grids from 0.8 M cells up to one window per
+    compute unit when nothing is pinned; the marching (or, below 1.5 M cells, the LDS-window) kernel for short calls, pinned schedules, slab chains, other grids."""
     u0, v0 = stress_fields((1080, 1920), 3)
     ref = {n: oracle.run(u0, v0, n, ftz=True) for n in (64, 32, 28)}
     for kw, steps, want in ((dict(), 64, "window-r5/"), (dict(), 32, "window-r5/"), (dict(), 28, "tb-k"), (dict(fuse_steps=4), 64, "tb-k"),
@@ -223,6 +223,17 @@ def test_what_kernel_auto_picks_around_the_window_kernel():
         if "boundary" not in kw:
             assert_bits_equal(got_u, ref[steps][0], f"auto U {kw} {steps}")
             assert_bits_equal(got_v, ref[steps][1], f"auto V {kw} {steps}")
+    # ... and from 0.8 M cells on (round 6: the window kernel without its barriers is ahead of the LDS-window kernel there),
+    # with as many steps per exchange as leave one window per compute unit (8 here)
+    a0, b0 = stress_fields((720, 1280), 5)
+    for steps, want in ((64, "window-r5/"), (32, "window-r5/"), (28, "tile")):
+        got_u, got_v, info = gpu_run(a0, b0, steps, args=args())
+        assert info[0].startswith(want), (steps, info)
+        ref_u, ref_v = oracle.run(a0, b0, steps, ftz=True)
+        assert_bits_equal(got_u, ref_u, f"auto U 720 x 1280, {steps}")
+        assert_bits_equal(got_v, ref_v, f"auto V 720 x 1280, {steps}")
+    a0, b0 = stress_fields((512, 1024), 4)                # 0.5 M cells: the LDS-window kernel
+    assert gpu_run(a0, b0, 64, args=args())[2][0].startswith("tile")
     a0, b0 = stress_fields((2048, 2048), 4)               # 4.2 M cells: more than one window per CU
     assert gpu_run(a0, b0, 64, args=args())[2][0].startswith("tb-k")
     a0, b0 = stress_fields((1200, 2000), 4)               # 2.4 M cells: more than one round of 80-row windows
