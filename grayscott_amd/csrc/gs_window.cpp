@@ -19,9 +19,10 @@ std::vector<GsWindowDesc> plan_windows(int cu_count, bool zero_halo, bool cheap,
     // same time whatever the number of windows (a window's waves wait for each other's rows and for their aprons, not for
     // issue slots) and an exchange costs about one step and a half, so the deeper apron pays wherever it fits: 8 rather than 4
     // steps per exchange is +8-10 % on grids of 0.9-1.5 M cells (profiles/r06_window_kernel.md, "smaller grids"); the
-    // reference's 1080 x 1920 fits with 4 only.
+    // reference's 1080 x 1920 fits with 4 only, its criterion grid's 1024 x 2048 with 2 only (533 k against the marching kernel's
+    // 421 k in 1000-step calls, 453 k against 354 k in 64-step calls).
     if (want_k <= 0) {
-        for (int k : {8, 6, 4}) {
+        for (int k : {8, 6, 4, 2}) {
             std::vector<GsWindowDesc> plan = plan_windows(cu_count, zero_halo, cheap, rows, cols, want_rpw, k, rpw_out, k_out);
             if (!plan.empty()) return plan;
         }
