@@ -112,9 +112,10 @@ typedef struct gs_params {
 typedef enum gs_math { GS_MATH_STRICT = 0, GS_MATH_FUSED = 1 } gs_math;
 
 /* Which step kernel runs.  AUTO = STREAM for a single gs_step; inside gs_run, by grid size when nothing
- * is pinned: the LDS-resident whole-run kernel up to 1536 cells, TILE up to 1.5 M cells, WINDOW for calls of
- * >= 32 steps on grids of one round of 80-row windows, TB with fuse_steps (default 4) otherwise, for slab
- * chains and whenever fuse_steps, rows_per_block, cols_per_lane, split or use_graph pin a schedule. */
+ * is pinned: the LDS-resident whole-run kernel up to 1536 cells; WINDOW for calls of >= 32 steps on grids
+ * from 0.8 M cells that one round of 80-row windows covers (one per compute unit; 8, 6, 4 or 2 steps per
+ * exchange, as many as fit); TILE otherwise up to 1.5 M cells; TB with fuse_steps (default 4) otherwise, for
+ * slab chains and whenever fuse_steps, rows_per_block, cols_per_lane, split or use_graph pin a schedule. */
 typedef enum gs_kernel {
     GS_KERNEL_AUTO = 0,    /* best measured variant for the shape                          */
     GS_KERNEL_SIMPLE = 1,  /* one thread per cell, global loads only (cross-check kernel)  */
