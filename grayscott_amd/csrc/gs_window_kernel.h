@@ -498,11 +498,13 @@ __device__ __forceinline__ void window_run(const GsStepArgs &a, const GsWindowAr
         // wave that gave up says that its rows will never come and ends; the others compute on with what they have -- the
         // launch is void -- until their own next exchange finds the abort word.  The exchange planes stay safe without the
         // barrier.  Let wave w store exchange s + 2 over its granules of exchange s, and let y (of another window) be a reader
-        // of one of them, c.  c lies within K cells of a cell c* that y's window owns and y itself holds (its band's own
-        // ring cell next to its apron), and c* lies in the apron of w's window, in a band at most two away from w's (K <= 8
-        // rows, bands of 5).  w has finished super-step s + 2, so the bands one and two away are inside that super-step (its
-        // last step needed the neighbours' last step, theirs the step before from the bands next to them): the reader of c*
-        // has passed exchange s + 1, so y had stored exchange s + 1 -- after having passed exchange s, i.e. after reading c.
+        // of one of them, c.  c lies within K cells of a cell c* that y's window owns, held by y itself or (aprons deeper than a
+        // band: a window's first and last band own nothing) by the band next to y; and c* lies in the apron of w's window, in
+        // a band at most two away from w's (K <= 8 rows, bands of 5).  w has finished super-step s + 2, so the bands one and
+        // two away from it are inside that super-step (its last step needed the neighbours' last step, theirs the step
+        // before from the bands next to them): the reader of c* has passed exchange s + 1, so c* had been stored for
+        // exchange s + 1 -- by a band that had finished super-step s + 1, whose last step needed y in that step: y had passed
+        // exchange s, i.e. had read c.
         if (failed) {
             if (lane == 0) ((__attribute__((address_space(3))) volatile int *)(lds + win_rows_floats()))[wave] = 0x7fffffff;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
