@@ -275,6 +275,50 @@ def test_window_kernel_soak_against_the_marching_kernel():
     ref.context.close()
 
 
+def test_window_launches_whose_workgroups_start_far_apart():
+    """Uneven load (MI355X_MICROARCH.md: test every hand-off under it): right before every window launch another stream
+    starts kernels that hold compute units for tens to hundreds of microseconds, so the launch's workgroups become
+    resident at very different times -- the early ones poll their aprons hundreds of times (the bounded-wait path, the
+    check of the abort word every 64 polls), waves of one window start their steps far apart -- for 120 launches of
+    uneven lengths, four, two and eight steps per exchange and the default size with its 12-wave edge windows.  Every word
+    against the marching kernel; no launch may have given up (the hogs are far shorter than the patience)."""
+    import torch
+
+    import bench
+
+    hog_stream = torch.cuda.Stream()
+    hog = torch.zeros(1 << 26, device="cuda")
+    for (rows, cols), k in (((1080, 1920), 0), ((1024, 2048), 0), ((900, 1600), 0), ((1080, 1920), 2)):
+        u0, v0 = bench.developed_start(rows, cols)
+        ref = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_TB))
+        sr = bench.upload_species(ref, u0, v0)
+        sim = Simulation.new(Parameters(), args(kernel=capi.GS_KERNEL_WINDOW, fuse_steps=k))
+        sp = bench.upload_species(sim, u0, v0)
+        rng = np.random.default_rng(rows + k)
+        total = 0
+        for call in range(30):
+            n = int(rng.integers(1, 90))
+            with torch.cuda.stream(hog_stream):
+                for _ in range(int(rng.integers(1, 4))):      # elementwise kernels over 256 MB: ~0.1 ms each, three per round,
+                    hog.mul_(1.0001).add_(0.5).sin_()          # their workgroups draining off the CUs while the launch comes on
+            sim.prepare_steps(sp, n)
+            ref.prepare_steps(sr, n)
+            total += n
+            if call % 10 == 9:
+                sim.context.sync()
+        sim.context.sync()
+        ref.context.sync()
+        torch.cuda.synchronize()
+        st = sim.context.stats()
+        assert st["window_fallbacks"] == 0 and sim.context.info()[0].startswith("window-r5/"), (st, sim.context.info())
+        for name, a, b in (("U", sp.in_out()[0], sr.in_out()[0]), ("V", sp.in_out()[1], sr.in_out()[1])):
+            (_, _, x), = a.torch_views()
+            (_, _, y), = b.torch_views()
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), f"{name} differs after {total} steps at {rows} x {cols}, k = {k}"
+        sim.context.close()
+        ref.context.close()
+
+
 def test_images_enqueued_behind_window_launches_never_wait_and_are_right(monkeypatch):
     """The reference's driver loop (simulate/src/main.rs:99-115) on the window kernel: prepare_steps, then the image of
     the newest state enqueued BEHIND the launch (gs_field_download_async no longer waits for a window launch in flight),
