@@ -1,3 +1,6 @@
+# A/B of builds of the persistent window kernel at the reference's default size, 1000-step calls, median of 5:
+#   bash tools/ab_window.sh LOGNAME VARIANT...     VARIANT = a tools/ab_build.py name, or "shipped" for the library as built
+# (log: gpurun_out/r06ad/LOGNAME.log; what the variants of round 6 read: profiles/r06_window_kernel.md, sections (e)-(f))
 mkdir -p gpurun_out/r06ad
 out=gpurun_out/r06ad/$1.log; shift
 : > $out
