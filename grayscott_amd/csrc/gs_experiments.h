@@ -132,7 +132,7 @@ __device__ __forceinline__ unsigned long long trace_now()
 //                         multi-round launches); GS_HIP_XCD_M_STREAM: the same for the single-step kernel
 //   GS_HIP_TILE_LDS_FLOOR bytes of dynamic LDS the LDS-window kernel asks for at least (limits workgroups per CU)
 //   GS_HIP_WINDOW_PATIENCE polls (2-3 us each) a wave of the persistent window kernel waits for its neighbours' cells
-//                         before the launch gives up (default 2^21, ~5 s; tests set 1 to provoke it)
+//                         before the launch gives up (default 2^20, 2-3 s; tests set 1 to provoke it)
 //   GS_HIP_WINDOW_WAVES   "left,interior,right": waves in use per window of the left-most / inner / right-most tile column
 //                         of the persistent window kernel's tiling (gs_window.cpp: plan_windows)
 constexpr int kGsXcdGroupMax = 512; // 8 * 512 workgroups per renumbered group at most

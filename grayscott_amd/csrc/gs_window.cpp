@@ -271,7 +271,7 @@ int32_t run_window(gs_ctx *ctx, Run &r, uint64_t steps, bool forced, int32_t *la
         x.steps = n;
         x.k = w.plan_k;
         x.epoch = w.epoch;
-        x.patience = gs_env_int("GS_HIP_WINDOW_PATIENCE", 1 << 21, 1, 1 << 30); // polls of 2-3 us each: ~5 s
+        x.patience = gs_env_int("GS_HIP_WINDOW_PATIENCE", 1 << 20, 1, 1 << 30); // polls of 2-3 us each: 2-3 s
         x.seq = ++w.seq;
         const char *name = nullptr;
         const hipError_t e = ctx->o.math == GS_MATH_FUSED ? gs_launch_window_fused(a, x, w.plan_rpw, sl.compute, &name)

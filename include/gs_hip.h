@@ -63,7 +63,7 @@
  *     GS_HIP_XCD_M_STREAM   the same for the single-step kernel
  *     GS_HIP_TILE_LDS_FLOOR least dynamic LDS (bytes) of the LDS-window kernel: limits its workgroups per CU
  *     GS_HIP_WINDOW_PATIENCE polls (2-3 us each) a wave of the persistent window kernel waits for its neighbours' cells
- *                           before the launch gives up (default 2^21: ~5 s)
+ *                           before the launch gives up (default 2^20: 2-3 s)
  *     GS_HIP_WINDOW_WAVES   "left,interior,right": waves in use (of 16) in the windows of the grid's left-most, inner
  *                           and right-most tile column (default 12,16,12 under the clipped rule, 16,16,16 otherwise)
  */
